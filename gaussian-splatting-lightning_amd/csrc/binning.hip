@@ -1,0 +1,221 @@
+// binning.hip — tile binning: per-Gaussian tile counts, prefix sum, (tile|depth) key emission,
+// stable LSD radix sort, per-tile ranges (gfx950).
+//
+// Replaces gsplat `isect_tiles` + `isect_offset_encode` (internal/renderers/gsplat_v1_renderer.py:446-458)
+// and the binning half of v0 `rasterize_gaussians` / Inria `GaussianRasterizer`
+// (gsplat_renderer.py:86-99, vanilla_renderer.py:111-120).  Key layout is the one the reference
+// pins in Python: internal/utils/gaussian_projection.py:159-208
+//     key = (tile_id << 32) | bits(depth as f32),  tile_id = y * tile_w + x,  value = Gaussian id,
+// emitted per Gaussian in row-major tile order, so that after a *stable* sort equal-depth ties
+// stay in Gaussian-id order.
+//
+// Roofline: HBM-bound.  Emit: 16 B read per visible Gaussian + 12 B written per intersection.
+// Sort: 12 B x I x 2 x ceil(bits/8) with bits = 32 + ceil(log2(tiles)).
+// The scan and the sort are rocPRIM device primitives (header-only, compiled here for gfx950);
+// only the significant key bits are sorted.
+#include <cstring>
+#include <cstdlib>
+#include "gspl_device.h"
+#include "gspl_host.h"
+#include <rocprim/rocprim.hpp>
+
+namespace gspl {
+
+// tile rectangle of one splat, per API convention
+template <int MODE>
+__device__ __forceinline__ void tile_rect(float x, float y, int radius, int tile_size, int tile_w, int tile_h,
+                                          int& minx, int& miny, int& maxx, int& maxy) {
+    const float ts = (float)tile_size;
+    const float r = (float)radius;
+    if (MODE == GSPL_MODE_GSPLAT) {
+        // gaussian_projection.py:117-125 : trunc((p - r)/T), trunc((p + r)/T) + 1
+        minx = (int)((x - r) / ts); miny = (int)((y - r) / ts);
+        maxx = (int)((x + r) / ts) + 1; maxy = (int)((y + r) / ts) + 1;
+    } else {
+        // Inria getRect: (int)((p - r)/T), (int)((p + r + T - 1)/T)
+        minx = (int)((x - r) / ts); miny = (int)((y - r) / ts);
+        maxx = (int)((x + r + ts - 1.f) / ts); maxy = (int)((y + r + ts - 1.f) / ts);
+    }
+    minx = min(max(minx, 0), tile_w); maxx = min(max(maxx, 0), tile_w);
+    miny = min(max(miny, 0), tile_h); maxy = min(max(maxy, 0), tile_h);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void isect_count_kernel(
+    int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+    int tile_size, int tile_w, int tile_h, int32_t* __restrict__ tiles_per_gauss, int64_t* __restrict__ counts64) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    int n = 0;
+    const int radius = radii[g];
+    if (radius > 0) {
+        int minx, miny, maxx, maxy;
+        tile_rect<MODE>(means2d[g * 2 + 0], means2d[g * 2 + 1], radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+        n = max(maxx - minx, 0) * max(maxy - miny, 0);
+    }
+    tiles_per_gauss[g] = n;
+    counts64[g] = n;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void isect_emit_kernel(
+    int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+    const int64_t* __restrict__ cum_tiles, int tile_size, int tile_w, int tile_h,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const int radius = radii[g];
+    if (radius <= 0) return;
+    int minx, miny, maxx, maxy;
+    tile_rect<MODE>(means2d[g * 2 + 0], means2d[g * 2 + 1], radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+    int64_t off = (g == 0) ? 0 : cum_tiles[g - 1];
+    const uint64_t depth_bits = (uint64_t)__float_as_uint(depths[g]);
+    for (int ty = miny; ty < maxy; ++ty) {
+        for (int tx = minx; tx < maxx; ++tx) {
+            const uint64_t tile = (uint64_t)(ty * tile_w + tx);
+            keys[off] = (tile << 32) | depth_bits;
+            vals[off] = (uint32_t)g;
+            ++off;
+        }
+    }
+}
+
+// offsets[t] = first index i with tile(keys[i]) >= t ; offsets has tile_w*tile_h entries.
+__global__ __launch_bounds__(256) void isect_offsets_kernel(
+    int64_t n_isects, const int64_t* __restrict__ keys, int n_tiles, int32_t* __restrict__ offsets) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_isects) return;
+    const int cur = (int)((uint64_t)keys[i] >> 32);
+    if (i == 0) {
+        for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
+    } else {
+        const int prev = (int)((uint64_t)keys[i - 1] >> 32);
+        for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
+    }
+    if (i == n_isects - 1) {
+        for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
+    }
+}
+
+__global__ void fill_i32_kernel(int n, int32_t v, int32_t* __restrict__ p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline int key_bits(int n_tiles) {
+    int b = 0;
+    while ((1ll << b) < (long long)n_tiles) ++b;
+    return 32 + b;
+}
+
+struct IsectWorkspace {
+    size_t counts_off, scan_tmp_off, scan_tmp_bytes;
+    size_t keys_off, vals_off, sort_tmp_off, sort_tmp_bytes;
+    size_t total;
+};
+
+static int plan_workspace(int N, int64_t n_isects, IsectWorkspace& w) {
+    size_t scan_tmp = 0, sort_tmp = 0;
+    hipError_t e = rocprim::inclusive_scan(nullptr, scan_tmp, (const int64_t*)nullptr, (int64_t*)nullptr, (size_t)(N > 0 ? N : 1),
+                                           rocprim::plus<int64_t>(), (hipStream_t)0);
+    if (e != hipSuccess) return check_hip(e, "isect: scan size query");
+    const size_t ni = (size_t)(n_isects > 0 ? n_isects : 1);
+    e = rocprim::radix_sort_pairs(nullptr, sort_tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 64, (hipStream_t)0);
+    if (e != hipSuccess) return check_hip(e, "isect: sort size query");
+    size_t off = 0;
+    w.counts_off = off; off = align_up(off + sizeof(int64_t) * (size_t)(N > 0 ? N : 1), 256);
+    w.scan_tmp_off = off; w.scan_tmp_bytes = scan_tmp; off = align_up(off + scan_tmp, 256);
+    w.keys_off = off; off = align_up(off + sizeof(uint64_t) * ni, 256);
+    w.vals_off = off; off = align_up(off + sizeof(uint32_t) * ni, 256);
+    w.sort_tmp_off = off; w.sort_tmp_bytes = sort_tmp; off = align_up(off + sort_tmp, 256);
+    w.total = off;
+    return GSPL_OK;
+}
+
+}  // namespace gspl
+
+extern "C" size_t gspl_isect_workspace_bytes(int N, int64_t n_isects) {
+    gspl::IsectWorkspace w;
+    if (gspl::plan_workspace(N, n_isects, w) != GSPL_OK) return 0;
+    return w.total;
+}
+
+extern "C" int gspl_isect_count(int N, int mode, const float* means2d, const int32_t* radii,
+                                int tile_size, int tile_w, int tile_h,
+                                int32_t* tiles_per_gauss, int64_t* cum_tiles,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gspl;
+    if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("isect_count: bad sizes");
+    if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("isect_count: bad mode");
+    if (N == 0) return GSPL_OK;
+    if (!means2d || !radii || !tiles_per_gauss || !cum_tiles || !workspace) return fail_arg("isect_count: NULL required pointer");
+    IsectWorkspace w;
+    int rc = plan_workspace(N, 0, w);
+    if (rc != GSPL_OK) return rc;
+    if (workspace_bytes < w.scan_tmp_off + w.scan_tmp_bytes) return fail_ws("isect_count");
+    char* ws = (char*)workspace;
+    int64_t* counts = (int64_t*)(ws + w.counts_off);
+    const int grid = (N + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == GSPL_MODE_GSPLAT)
+        hipLaunchKernelGGL(isect_count_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, tile_size, tile_w, tile_h, tiles_per_gauss, counts);
+    else
+        hipLaunchKernelGGL(isect_count_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, tile_size, tile_w, tile_h, tiles_per_gauss, counts);
+    rc = check_launch("isect_count");
+    if (rc != GSPL_OK) return rc;
+    size_t tmp = w.scan_tmp_bytes;
+    hipError_t e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp, counts, cum_tiles, (size_t)N, rocprim::plus<int64_t>(), s);
+    return check_hip(e, "isect_count: inclusive_scan");
+}
+
+extern "C" int gspl_isect_emit_sort(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
+                                    const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h, int64_t n_isects,
+                                    int64_t* isect_ids, int32_t* flatten_ids,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gspl;
+    if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("isect_emit_sort: bad sizes");
+    if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("isect_emit_sort: bad mode");
+    if (N == 0 || n_isects == 0) return GSPL_OK;
+    if (n_isects > 0x7fffffffll) return fail_arg("isect_emit_sort: more than 2^31-1 intersections");
+    if (!means2d || !radii || !depths || !cum_tiles || !isect_ids || !flatten_ids || !workspace) return fail_arg("isect_emit_sort: NULL required pointer");
+    IsectWorkspace w;
+    int rc = plan_workspace(N, n_isects, w);
+    if (rc != GSPL_OK) return rc;
+    if (workspace_bytes < w.total) return fail_ws("isect_emit_sort");
+    char* ws = (char*)workspace;
+    uint64_t* keys = (uint64_t*)(ws + w.keys_off);
+    uint32_t* vals = (uint32_t*)(ws + w.vals_off);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (N + 255) / 256;
+    if (mode == GSPL_MODE_GSPLAT)
+        hipLaunchKernelGGL(isect_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, cum_tiles, tile_size, tile_w, tile_h, keys, vals);
+    else
+        hipLaunchKernelGGL(isect_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, cum_tiles, tile_size, tile_w, tile_h, keys, vals);
+    rc = check_launch("isect_emit");
+    if (rc != GSPL_OK) return rc;
+    size_t tmp = w.sort_tmp_bytes;
+    const int bits = key_bits(tile_w * tile_h);
+    hipError_t e = rocprim::radix_sort_pairs(ws + w.sort_tmp_off, tmp, keys, (uint64_t*)isect_ids, vals, (uint32_t*)flatten_ids,
+                                             (size_t)n_isects, 0, bits, s);
+    return check_hip(e, "isect_emit_sort: radix_sort_pairs");
+}
+
+extern "C" int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids, int tile_w, int tile_h,
+                                  int32_t* offsets, void* stream) {
+    using namespace gspl;
+    if (n_isects < 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("isect_offsets: bad sizes");
+    if (!offsets) return fail_arg("isect_offsets: NULL offsets");
+    const int n_tiles = tile_w * tile_h;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_isects == 0) {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, n_tiles, 0, offsets);
+        return check_launch("isect_offsets(fill)");
+    }
+    if (!isect_ids) return fail_arg("isect_offsets: NULL isect_ids");
+    const int64_t grid = (n_isects + 255) / 256;
+    hipLaunchKernelGGL(isect_offsets_kernel, dim3((unsigned)grid), dim3(256), 0, s, n_isects, isect_ids, n_tiles, offsets);
+    return check_launch("isect_offsets");
+}

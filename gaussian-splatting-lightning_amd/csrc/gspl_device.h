@@ -1,0 +1,218 @@
+// gspl_device.h — device-side math shared by the projection / preprocess kernels (gfx950).
+//
+// Everything here is per-Gaussian scalar fp32 math executed by one lane; the kernels that use it
+// are HBM-bound, so the code favours clarity over instruction count.
+//
+// Reference restated (not copied): internal/utils/gaussian_projection.py:211-287
+// (build_rotation_matrix, compute_cov_3d, compute_cov_2d).  The backward formulas are derived by
+// hand from those forward definitions and are checked against fp64 autograd of
+// the oracle restatement in tests/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gspl_hip.h"   // GSPL_MODE_* / GSPL_LAYOUT_* enums
+
+namespace gspl {
+
+// ---- per-API constants -------------------------------------------------
+template <int MODE> struct ModeTraits;
+template <> struct ModeTraits<GSPL_MODE_GSPLAT> {
+    static constexpr float kAlphaMax = 0.999f;
+    static constexpr float kPixelCentre = 0.5f;
+    static constexpr bool kStopInclusive = true;    // stop when next_T <= 1e-4
+    static constexpr bool kClampKillsGrad = true;   // d min(amax, x)/dx = 0 when clamped
+};
+template <> struct ModeTraits<GSPL_MODE_INRIA> {
+    static constexpr float kAlphaMax = 0.99f;
+    static constexpr float kPixelCentre = 0.0f;
+    static constexpr bool kStopInclusive = false;   // stop when test_T < 1e-4
+    static constexpr bool kClampKillsGrad = false;  // Inria backward ignores the clamp
+};
+static constexpr float kAlphaMin = 1.0f / 255.0f;
+static constexpr float kTStop = 1e-4f;
+
+// ---- rotation from quaternion (w,x,y,z), used as given (gaussian_projection.py:211-232) --------
+__device__ __forceinline__ void quat_to_rotmat(const float q[4], float R[9]) {
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z);       R[2] = 2.f * (x * z + w * y);
+    R[3] = 2.f * (x * y + w * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
+    R[6] = 2.f * (x * z - w * y);       R[7] = 2.f * (y * z + w * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = (R S)(R S)^T, S = diag(s).  Returns the 6 unique entries (xx, xy, xz, yy, yz, zz)
+// (same order as the reference's cov3D_precomp, internal/utils/general_utils.py:126-139).
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s[3], const float R[9], float S6[6]) {
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = R[i * 3 + j] * s[j];
+    S6[0] = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    S6[1] = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    S6[2] = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    S6[3] = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    S6[4] = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    S6[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+}
+
+// G6 = dL/dSigma as a full symmetric matrix (each off-diagonal *position* holds G_ij, so the
+// derivative w.r.t. the single parameter sigma_ij, i != j, is 2*G_ij).
+// v_M = 2 G M ; M = R S  ->  v_s[j] = sum_i v_M[i][j] R[i][j],  v_R[i][j] = v_M[i][j] s[j].
+__device__ __forceinline__ void cov3d_bwd(const float s[3], const float q[4], const float G6[6],
+                                          float v_s[3], float v_q[4]) {
+    float R[9];
+    quat_to_rotmat(q, R);
+    const float G[9] = {G6[0], G6[1], G6[2], G6[1], G6[3], G6[4], G6[2], G6[4], G6[5]};
+    float vR[9];
+    v_s[0] = v_s[1] = v_s[2] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // v_M[i][j] = 2 * sum_k G[i][k] * M[k][j],  M[k][j] = R[k][j]*s[j]
+            const float vm = 2.f * s[j] * (G[i * 3 + 0] * R[0 * 3 + j] + G[i * 3 + 1] * R[1 * 3 + j] + G[i * 3 + 2] * R[2 * 3 + j]);
+            v_s[j] += vm * R[i * 3 + j];
+            vR[i * 3 + j] = vm * s[j];
+        }
+    }
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    v_q[0] = 2.f * (-z * vR[1] + y * vR[2] + z * vR[3] - x * vR[5] - y * vR[6] + x * vR[7]);
+    v_q[1] = 2.f * (y * vR[1] + z * vR[2] + y * vR[3] - 2.f * x * vR[4] - w * vR[5] + z * vR[6] + w * vR[7] - 2.f * x * vR[8]);
+    v_q[2] = 2.f * (-2.f * y * vR[0] + x * vR[1] + w * vR[2] + x * vR[3] + z * vR[5] - w * vR[6] + z * vR[7] - 2.f * y * vR[8]);
+    v_q[3] = 2.f * (-2.f * z * vR[0] - w * vR[1] + x * vR[2] + w * vR[3] - 2.f * z * vR[4] + y * vR[5] + x * vR[6] + y * vR[7]);
+}
+
+// ---- EWA: cov2d = T Sigma T^T with T = J W (gaussian_projection.py:257-287) ---------------------
+// pc: camera-space mean; W: 3x3 world->camera rotation (row-major, standard orientation);
+// limx/limy = 1.3 * tan(fov/2).  Outputs the *un-blurred* 2x2 entries (a0, b0, c0).
+struct EwaCtx {
+    float T0[3], T1[3];   // rows of T
+    float tx, ty;         // clamped x, y used in J
+    bool  in_x, in_y;     // clamp inactive (gradient passes to x / y)
+    float ux, uy;         // clamped x/z, y/z
+};
+
+__device__ __forceinline__ void ewa_fwd(const float pc[3], const float S6[6], const float W[9],
+                                        float fx, float fy, float limx, float limy,
+                                        float& a0, float& b0, float& c0, EwaCtx& ctx) {
+    const float z = pc[2];
+    const float rz = 1.f / z;
+    const float txtz = pc[0] * rz, tytz = pc[1] * rz;
+    ctx.in_x = (txtz >= -limx) && (txtz <= limx);
+    ctx.in_y = (tytz >= -limy) && (tytz <= limy);
+    ctx.ux = fminf(limx, fmaxf(-limx, txtz));
+    ctx.uy = fminf(limy, fmaxf(-limy, tytz));
+    ctx.tx = ctx.ux * z;
+    ctx.ty = ctx.uy * z;
+    const float J00 = fx * rz, J02 = -fx * ctx.tx * rz * rz;
+    const float J11 = fy * rz, J12 = -fy * ctx.ty * rz * rz;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ctx.T0[j] = J00 * W[0 * 3 + j] + J02 * W[2 * 3 + j];
+        ctx.T1[j] = J11 * W[1 * 3 + j] + J12 * W[2 * 3 + j];
+    }
+    // Sigma * T0^T, Sigma * T1^T
+    const float s0x = S6[0] * ctx.T0[0] + S6[1] * ctx.T0[1] + S6[2] * ctx.T0[2];
+    const float s0y = S6[1] * ctx.T0[0] + S6[3] * ctx.T0[1] + S6[4] * ctx.T0[2];
+    const float s0z = S6[2] * ctx.T0[0] + S6[4] * ctx.T0[1] + S6[5] * ctx.T0[2];
+    const float s1x = S6[0] * ctx.T1[0] + S6[1] * ctx.T1[1] + S6[2] * ctx.T1[2];
+    const float s1y = S6[1] * ctx.T1[0] + S6[3] * ctx.T1[1] + S6[4] * ctx.T1[2];
+    const float s1z = S6[2] * ctx.T1[0] + S6[4] * ctx.T1[1] + S6[5] * ctx.T1[2];
+    a0 = ctx.T0[0] * s0x + ctx.T0[1] * s0y + ctx.T0[2] * s0z;
+    b0 = ctx.T0[0] * s1x + ctx.T0[1] * s1y + ctx.T0[2] * s1z;
+    c0 = ctx.T1[0] * s1x + ctx.T1[1] * s1y + ctx.T1[2] * s1z;
+}
+
+// Backward of ewa_fwd.  (va, vb, vc) = dL/d(a0, b0, c0) with vb the derivative w.r.t. the single
+// off-diagonal parameter.  Accumulates into v_pc; writes G6 (see cov3d_bwd).
+// EXACT_CLAMP: true  -> exact derivative of clamp(x/z)*z (autograd of the reference Python);
+//              false -> Inria behaviour: clamped coordinate contributes no gradient at all.
+template <bool EXACT_CLAMP>
+__device__ __forceinline__ void ewa_bwd(const float pc[3], const float S6[6], const float W[9],
+                                        float fx, float fy, const EwaCtx& ctx,
+                                        float va, float vb, float vc,
+                                        float v_pc[3], float G6[6]) {
+    const float* T0 = ctx.T0;
+    const float* T1 = ctx.T1;
+    const float hb = 0.5f * vb;
+    G6[0] = va * T0[0] * T0[0] + vb * T0[0] * T1[0] + vc * T1[0] * T1[0];
+    G6[3] = va * T0[1] * T0[1] + vb * T0[1] * T1[1] + vc * T1[1] * T1[1];
+    G6[5] = va * T0[2] * T0[2] + vb * T0[2] * T1[2] + vc * T1[2] * T1[2];
+    G6[1] = va * T0[0] * T0[1] + hb * (T0[0] * T1[1] + T1[0] * T0[1]) + vc * T1[0] * T1[1];
+    G6[2] = va * T0[0] * T0[2] + hb * (T0[0] * T1[2] + T1[0] * T0[2]) + vc * T1[0] * T1[2];
+    G6[4] = va * T0[1] * T0[2] + hb * (T0[1] * T1[2] + T1[1] * T0[2]) + vc * T1[1] * T1[2];
+
+    // Sigma*T0, Sigma*T1
+    const float s0[3] = {S6[0] * T0[0] + S6[1] * T0[1] + S6[2] * T0[2],
+                         S6[1] * T0[0] + S6[3] * T0[1] + S6[4] * T0[2],
+                         S6[2] * T0[0] + S6[4] * T0[1] + S6[5] * T0[2]};
+    const float s1[3] = {S6[0] * T1[0] + S6[1] * T1[1] + S6[2] * T1[2],
+                         S6[1] * T1[0] + S6[3] * T1[1] + S6[4] * T1[2],
+                         S6[2] * T1[0] + S6[4] * T1[1] + S6[5] * T1[2]};
+    float vT0[3], vT1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        vT0[j] = 2.f * va * s0[j] + vb * s1[j];
+        vT1[j] = 2.f * vc * s1[j] + vb * s0[j];
+    }
+    const float vJ00 = vT0[0] * W[0] + vT0[1] * W[1] + vT0[2] * W[2];
+    const float vJ02 = vT0[0] * W[6] + vT0[1] * W[7] + vT0[2] * W[8];
+    const float vJ11 = vT1[0] * W[3] + vT1[1] * W[4] + vT1[2] * W[5];
+    const float vJ12 = vT1[0] * W[6] + vT1[1] * W[7] + vT1[2] * W[8];
+
+    const float z = pc[2];
+    const float rz = 1.f / z, rz2 = rz * rz, rz3 = rz2 * rz;
+    float vz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * ctx.tx * rz3 * vJ02 + 2.f * fy * ctx.ty * rz3 * vJ12;
+    const float vtx = -fx * rz2 * vJ02;
+    const float vty = -fy * rz2 * vJ12;
+    if (EXACT_CLAMP) {
+        // tx = clamp(x/z) * z
+        if (ctx.in_x) v_pc[0] += vtx; else vz += vtx * ctx.ux;
+        if (ctx.in_y) v_pc[1] += vty; else vz += vty * ctx.uy;
+    } else {
+        if (ctx.in_x) v_pc[0] += vtx;
+        if (ctx.in_y) v_pc[1] += vty;
+    }
+    v_pc[2] += vz;
+}
+
+// conic (A,B,C) = inverse of [[a,b],[b,c]]; given dL/d(A,B,C) (vB w.r.t. the single parameter B)
+// return dL/d(a,b,c).
+__device__ __forceinline__ void conic_bwd(float a, float b, float c, float vA, float vB, float vC,
+                                          float& va, float& vb, float& vc) {
+    const float det = a * c - b * b;
+    const float rd2 = 1.f / (det * det);
+    va = rd2 * (-c * c * vA + b * c * vB - b * b * vC);
+    vc = rd2 * (-b * b * vA + a * b * vB - a * a * vC);
+    vb = rd2 * (2.f * b * c * vA - (a * c + b * b) * vB + 2.f * a * b * vC);
+}
+
+// ---- wave64 helpers -----------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(moved);
+}
+// Sum over the 64 lanes of the wave; the total is valid in lane 63 (row 3).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);   // row_mirror          -> every lane holds its 16-row sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3
+    return v;
+}
+
+// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"), so consecutive tiles are dealt to different L2s.  Remap so that each XCD
+// owns a contiguous band of tiles (neighbouring tiles share splat records -> L2 hits).  Speed only.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int per = n >> 3;          // full rounds
+    const int body = per << 3;
+    if (b >= body) return b;         // tail handled in place
+    return (b & 7) * per + (b >> 3);
+}
+
+}  // namespace gspl

@@ -1,0 +1,47 @@
+// gspl_host.h — host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/gspl_hip.h"
+
+namespace gspl {
+
+// thread-local last-error text, exposed through gspl_last_error()
+void set_error(const char* where, const char* what);
+
+inline int fail_arg(const char* msg) {
+    set_error(msg, "invalid argument");
+    return GSPL_ERR_INVALID_ARG;
+}
+inline int fail_ws(const char* msg) {
+    set_error(msg, "workspace too small");
+    return GSPL_ERR_WORKSPACE;
+}
+inline int check_launch(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(where, hipGetErrorString(e));
+        return GSPL_ERR_LAUNCH;
+    }
+    return GSPL_OK;
+}
+inline int check_hip(hipError_t e, const char* where) {
+    if (e != hipSuccess) {
+        set_error(where, hipGetErrorString(e));
+        return GSPL_ERR_LAUNCH;
+    }
+    return GSPL_OK;
+}
+
+}  // namespace gspl
+
+// internal launchers shared between translation units (sh.hip -> inria.hip)
+namespace gspl {
+int sh_fwd_launch(int N, int degree, const float* dirs, const float* origin,
+                  const float* dc, int dc_stride, const float* rest, int rest_stride,
+                  const uint8_t* mask, const int32_t* mask32, int flags,
+                  float* colors, uint8_t* clamped, void* stream);
+int sh_bwd_launch(int N, int degree, int n_coeffs, const float* dirs, const float* origin,
+                  const float* dc, int dc_stride, const float* rest, int rest_stride,
+                  const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
+                  const float* v_colors, float* v_dc, float* v_rest, float* v_dirs, void* stream);
+}  // namespace gspl

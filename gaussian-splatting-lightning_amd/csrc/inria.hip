@@ -1,0 +1,288 @@
+// inria.hip — Inria-convention preprocess (front half of the fused `GaussianRasterizer`), fwd + bwd.
+//
+// Replaces the part of `diff_gaussian_rasterization.GaussianRasterizer` that runs before the sort,
+// at the reference call sites internal/renderers/vanilla_renderer.py:62-77,111-120 (forward) and
+// its autograd backward.  The package is not vendored in the reference; the algorithm restated
+// here is the published 3DGS preprocess with the constants of SURVEY.md Appendix B:
+//   cull view-z <= 0.2 ; cov3D = (R S)(R S)^T ; EWA cov2D with x/z, y/z clamped to 1.3 tan(fov/2),
+//   focal = W / (2 tan(fov/2)) ; +0.3 on the cov2D diagonal (no compensation) ; cull det == 0 ;
+//   radius = ceil(3 sqrt(mid + sqrt(max(0.1, mid^2 - det)))) ; mean2D = ((ndc + 1) S - 1) / 2 with
+//   ndc = (P p).xy / ((P p).w + 1e-7) ; tile rect [(p-r)/16, (p+r+15)/16) ; cull empty rect ;
+//   colour = max(0, SH(dir = normalise(p - campos)) + 0.5) with the clamp recorded for backward.
+// The reference hands matrices over in its transposed (row-vector) storage
+// (internal/cameras/cameras.py:147-189): p_view = p V[:3,:3] + V[3,:3].
+//
+// The colour stage reuses the LDS-staged SH kernels of sh.hip (dirs = means, origin = campos,
+// GSPL_SH_ADD_HALF_CLAMP, masked by radii); backward writes dL/d(dir) into v_means first and the
+// geometry kernel then accumulates the projection/covariance terms on top.
+// Roofline: HBM-bound elementwise.
+#include "gspl_device.h"
+#include "gspl_host.h"
+
+namespace gspl {
+
+struct InriaCam {
+    float V[16];   // row-vector storage: p_view[c] = sum_r p[r] V[r*4+c] + V[12+c]
+    float P[16];
+};
+
+__device__ __forceinline__ void load_inria_cam(const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, InriaCam& c) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c.V[i] = viewmatrix[i]; c.P[i] = projmatrix[i]; }
+}
+
+// common geometry: returns false when culled; fills everything needed by fwd and bwd
+struct InriaGeom {
+    float pv[3];        // view-space mean
+    float hom[4];       // P p
+    float S6[6];
+    float Wstd[9];      // standard-orientation rotation (row i, col j) = V[j*4+i]
+    EwaCtx ctx;
+    float a, b, c;      // blurred cov2D
+    float det;
+    float fx, fy;
+};
+
+__device__ __forceinline__ bool inria_geom(const InriaCam& cam, const float p[3], const float* S6_in,
+                                           int width, int height, float tanfovx, float tanfovy, InriaGeom& G) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G.pv[c] = p[0] * cam.V[0 * 4 + c] + p[1] * cam.V[1 * 4 + c] + p[2] * cam.V[2 * 4 + c] + cam.V[12 + c];
+    if (G.pv[2] <= 0.2f) return false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) G.hom[c] = p[0] * cam.P[0 * 4 + c] + p[1] * cam.P[1 * 4 + c] + p[2] * cam.P[2 * 4 + c] + cam.P[12 + c];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) G.S6[k] = S6_in[k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) G.Wstd[i * 3 + j] = cam.V[j * 4 + i];
+    G.fx = (float)width / (2.f * tanfovx);
+    G.fy = (float)height / (2.f * tanfovy);
+    float a0, b0, c0;
+    ewa_fwd(G.pv, G.S6, G.Wstd, G.fx, G.fy, 1.3f * tanfovx, 1.3f * tanfovy, a0, b0, c0, G.ctx);
+    G.a = a0 + 0.3f; G.b = b0; G.c = c0 + 0.3f;
+    G.det = G.a * G.c - G.b * G.b;
+    return G.det != 0.f;
+}
+
+__global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
+    int N,
+    const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
+    const float* __restrict__ cov3d_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    int width, int height, int tile_size, float tanfovx, float tanfovy, float scale_modifier,
+    int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
+    float* __restrict__ conics, float* __restrict__ cov3d) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    InriaCam cam;
+    load_inria_cam(viewmatrix, projmatrix, cam);
+    const float p[3] = {means[g * 3 + 0], means[g * 3 + 1], means[g * 3 + 2]};
+
+    float S6[6];
+    if (cov3d_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S6[k] = cov3d_precomp[g * 6 + k];
+    } else {
+        const float s[3] = {scales[g * 3 + 0] * scale_modifier, scales[g * 3 + 1] * scale_modifier, scales[g * 3 + 2] * scale_modifier};
+        const float q[4] = {quats[g * 4 + 0], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+        float R[9];
+        quat_to_rotmat(q, R);
+        cov3d_from_scale_rot(s, R, S6);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3d[g * 6 + k] = S6[k];
+
+    int o_radius = 0;
+    float o_xy[2] = {0.f, 0.f}, o_depth = 0.f, o_conic[3] = {0.f, 0.f, 0.f};
+    InriaGeom G;
+    if (inria_geom(cam, p, S6, width, height, tanfovx, tanfovy, G)) {
+        const float inv_det = 1.f / G.det;
+        const float mid = 0.5f * (G.a + G.c);
+        const float lambda = mid + sqrtf(fmaxf(0.1f, mid * mid - G.det));
+        const int radius = (int)ceilf(3.f * sqrtf(lambda));
+        const float pw = 1.f / (G.hom[3] + 1e-7f);
+        const float x2d = ((G.hom[0] * pw + 1.f) * (float)width - 1.f) * 0.5f;
+        const float y2d = ((G.hom[1] * pw + 1.f) * (float)height - 1.f) * 0.5f;
+        const int grid_x = (width + tile_size - 1) / tile_size, grid_y = (height + tile_size - 1) / tile_size;
+        const float ts = (float)tile_size, rf = (float)radius;
+        const int minx = min(grid_x, max(0, (int)((x2d - rf) / ts)));
+        const int miny = min(grid_y, max(0, (int)((y2d - rf) / ts)));
+        const int maxx = min(grid_x, max(0, (int)((x2d + rf + ts - 1.f) / ts)));
+        const int maxy = min(grid_y, max(0, (int)((y2d + rf + ts - 1.f) / ts)));
+        if ((maxx - minx) * (maxy - miny) > 0) {
+            o_radius = radius;
+            o_xy[0] = x2d; o_xy[1] = y2d;
+            o_depth = G.pv[2];
+            o_conic[0] = G.c * inv_det; o_conic[1] = -G.b * inv_det; o_conic[2] = G.a * inv_det;
+        }
+    }
+    radii[g] = o_radius;
+    means2d[g * 2 + 0] = o_xy[0]; means2d[g * 2 + 1] = o_xy[1];
+    depths[g] = o_depth;
+    conics[g * 3 + 0] = o_conic[0]; conics[g * 3 + 1] = o_conic[1]; conics[g * 3 + 2] = o_conic[2];
+}
+
+// ACCUM: v_means already holds dL/d(dir) from the SH backward and is accumulated into.
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
+    int N,
+    const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
+    const float* __restrict__ cov3d,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
+    int width, int height, float tanfovx, float tanfovy, float scale_modifier,
+    const int32_t* __restrict__ radii,
+    const float* __restrict__ v_means2d, const float* __restrict__ v_conics,
+    float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
+    float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    float vp[3] = {0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
+    float G6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ndc[2] = {0.f, 0.f};
+    if (radii[g] > 0) {
+        InriaCam cam;
+        load_inria_cam(viewmatrix, projmatrix, cam);
+        const float p[3] = {means[g * 3 + 0], means[g * 3 + 1], means[g * 3 + 2]};
+        float S6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S6[k] = cov3d[g * 6 + k];
+        InriaGeom G;
+        inria_geom(cam, p, S6, width, height, tanfovx, tanfovy, G);
+
+        // 2D mean (pixels) -> clip space
+        ndc[0] = v_means2d[g * 2 + 0] * 0.5f * (float)width;
+        ndc[1] = v_means2d[g * 2 + 1] * 0.5f * (float)height;
+        const float mw = 1.f / (G.hom[3] + 1e-7f);
+        const float vh0 = ndc[0] * mw, vh1 = ndc[1] * mw;
+        const float vh3 = -(ndc[0] * G.hom[0] + ndc[1] * G.hom[1]) * mw * mw;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) vp[r] = cam.P[r * 4 + 0] * vh0 + cam.P[r * 4 + 1] * vh1 + cam.P[r * 4 + 3] * vh3;
+
+        // conic -> cov2D -> (view-space mean, cov3D)
+        float va, vb, vc;
+        conic_bwd(G.a, G.b, G.c, v_conics[g * 3 + 0], v_conics[g * 3 + 1], v_conics[g * 3 + 2], va, vb, vc);
+        float vpv[3] = {0.f, 0.f, 0.f};
+        ewa_bwd<false>(G.pv, S6, G.Wstd, G.fx, G.fy, G.ctx, va, vb, vc, vpv, G6);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) vp[r] += cam.V[r * 4 + 0] * vpv[0] + cam.V[r * 4 + 1] * vpv[1] + cam.V[r * 4 + 2] * vpv[2];
+
+        if (v_scales) {
+            const float s[3] = {scales[g * 3 + 0] * scale_modifier, scales[g * 3 + 1] * scale_modifier, scales[g * 3 + 2] * scale_modifier};
+            const float q[4] = {quats[g * 4 + 0], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+            cov3d_bwd(s, q, G6, vs, vq);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vs[j] *= scale_modifier;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (ACCUM) v_means[g * 3 + j] += vp[j];
+        else v_means[g * 3 + j] = vp[j];
+    }
+    if (v_scales) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v_scales[g * 3 + j] = vs[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v_quats[g * 4 + j] = vq[j];
+    }
+    if (v_cov3d_precomp) {
+        v_cov3d_precomp[g * 6 + 0] = G6[0]; v_cov3d_precomp[g * 6 + 1] = 2.f * G6[1]; v_cov3d_precomp[g * 6 + 2] = 2.f * G6[2];
+        v_cov3d_precomp[g * 6 + 3] = G6[3]; v_cov3d_precomp[g * 6 + 4] = 2.f * G6[4]; v_cov3d_precomp[g * 6 + 5] = G6[5];
+    }
+    v_means2d_ndc[g * 3 + 0] = ndc[0]; v_means2d_ndc[g * 3 + 1] = ndc[1]; v_means2d_ndc[g * 3 + 2] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void masked_copy3_kernel(int N, const int32_t* __restrict__ radii,
+                                                           const float* __restrict__ src, float* __restrict__ dst,
+                                                           uint8_t* __restrict__ clamped) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= N) return;
+    const bool live = radii[g] > 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dst[g * 3 + c] = live ? src[g * 3 + c] : 0.f;
+        if (clamped) clamped[g * 3 + c] = 0;
+    }
+}
+
+}  // namespace gspl
+
+extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
+                                         const float* means, const float* scales, const float* quats,
+                                         const float* cov3d_precomp, const float* shs, const float* colors_precomp,
+                                         const float* viewmatrix, const float* projmatrix, const float* campos,
+                                         int width, int height, int tile_size,
+                                         float tanfovx, float tanfovy, float scale_modifier,
+                                         int32_t* radii, float* means2d, float* depths, float* conics,
+                                         float* colors, uint8_t* clamped, float* cov3d, void* stream) {
+    using namespace gspl;
+    if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0) return fail_arg("inria_preprocess_fwd: bad sizes");
+    if (N == 0) return GSPL_OK;
+    if (!means || !viewmatrix || !projmatrix || !radii || !means2d || !depths || !conics || !colors || !clamped || !cov3d)
+        return fail_arg("inria_preprocess_fwd: NULL required pointer");
+    if (!cov3d_precomp && (!scales || !quats)) return fail_arg("inria_preprocess_fwd: need scales+quats or cov3d_precomp");
+    if (!colors_precomp && (!shs || !campos)) return fail_arg("inria_preprocess_fwd: need shs+campos or colors_precomp");
+    if (shs && !colors_precomp && (degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)))
+        return fail_arg("inria_preprocess_fwd: bad degree / n_coeffs");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (N + 255) / 256;
+    hipLaunchKernelGGL(inria_preprocess_fwd_kernel, dim3(grid), dim3(256), 0, s,
+                       N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
+                       tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d);
+    int rc = check_launch("inria_preprocess_fwd");
+    if (rc != GSPL_OK) return rc;
+    if (colors_precomp) {
+        hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, colors_precomp, colors, clamped);
+        return check_launch("inria_preprocess_fwd(colors_precomp)");
+    }
+    const int stride = 3 * n_coeffs;
+    return sh_fwd_launch(N, degree, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
+                         GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream);
+}
+
+extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
+                                         const float* means, const float* scales, const float* quats,
+                                         const float* cov3d, const float* shs,
+                                         const float* viewmatrix, const float* projmatrix, const float* campos,
+                                         int width, int height, float tanfovx, float tanfovy, float scale_modifier,
+                                         const int32_t* radii, const uint8_t* clamped,
+                                         const float* v_means2d, const float* v_conics, const float* v_colors,
+                                         float* v_means, float* v_scales, float* v_quats,
+                                         float* v_cov3d_precomp, float* v_shs, float* v_colors_precomp,
+                                         float* v_means2d_ndc, void* stream) {
+    using namespace gspl;
+    if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
+    if (N == 0) return GSPL_OK;
+    if (!means || !cov3d || !viewmatrix || !projmatrix || !radii || !v_means2d || !v_conics || !v_colors || !v_means || !v_means2d_ndc)
+        return fail_arg("inria_preprocess_bwd: NULL required pointer");
+    if ((v_scales == nullptr) != (v_quats == nullptr)) return fail_arg("inria_preprocess_bwd: v_scales and v_quats go together");
+    if (v_scales && (!scales || !quats)) return fail_arg("inria_preprocess_bwd: scales/quats missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (N + 255) / 256;
+    bool accum = false;
+    if (v_shs) {
+        if (!shs || !campos || !clamped) return fail_arg("inria_preprocess_bwd: shs/campos/clamped missing");
+        if (degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("inria_preprocess_bwd: bad degree / n_coeffs");
+        const int stride = 3 * n_coeffs;
+        // dL/d(dir) lands in v_means; the geometry kernel accumulates on top
+        int rc = sh_bwd_launch(N, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
+                               GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, v_shs, v_shs + 3, v_means, stream);
+        if (rc != GSPL_OK) return rc;
+        accum = true;
+    }
+    if (v_colors_precomp) {
+        hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, v_colors, v_colors_precomp, (uint8_t*)nullptr);
+        int rc = check_launch("inria_preprocess_bwd(colors_precomp)");
+        if (rc != GSPL_OK) return rc;
+    }
+    if (accum)
+        hipLaunchKernelGGL(inria_preprocess_bwd_kernel<true>, dim3(grid), dim3(256), 0, s,
+                           N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
+                           radii, v_means2d, v_conics, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
+    else
+        hipLaunchKernelGGL(inria_preprocess_bwd_kernel<false>, dim3(grid), dim3(256), 0, s,
+                           N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
+                           radii, v_means2d, v_conics, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
+    return check_launch("inria_preprocess_bwd");
+}
