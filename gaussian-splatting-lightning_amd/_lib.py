@@ -1,0 +1,162 @@
+"""
+_lib.py — ctypes binding of libgspl_hip.so (the C-ABI declared in include/gspl_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every compute call goes
+through the C-ABI with raw device pointers.  There is NO fallback: if the library is missing, or
+a tensor is not on the GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libgspl_hip.so")
+ABI_VERSION = 1
+
+GSPL_MODE_GSPLAT = 0
+GSPL_MODE_INRIA = 1
+GSPL_LAYOUT_HWC = 0
+GSPL_LAYOUT_CHW = 1
+GSPL_SH_ADD_HALF_CLAMP = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "gspl_abi_version": (c_int, []),
+    "gspl_last_error": (ctypes.c_char_p, []),
+    "gspl_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int,
+                                 c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float,
+                                 _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_sh_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
+    "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "gspl_isect_workspace_bytes": (c_size_t, [c_int, c_int64]),
+    "gspl_isect_count": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "gspl_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "gspl_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, _P, _P]),
+    "gspl_composite_fwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                   c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gspl_composite_bwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                   c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
+                                   _P, _P, _P, _P, _P, _P]),
+    "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                          c_int, c_int, c_int, c_float, c_float, c_float,
+                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+                                          c_int, c_int, c_float, c_float, c_float,
+                                          _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_LIB = None
+
+
+def exported_symbols():
+    """Names include/gspl_hip.h declares (used by the no-GPU ABI test)."""
+    return sorted(_SIGNATURES)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG_DIR, "csrc"), "-j8"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise HipLibraryError("building libgspl_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib():
+    """Load libgspl_hip.so (once).  Raises HipLibraryError when it is absent — there is no CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is the only compute path of this package. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
+            f"{os.path.join(_PKG_DIR, 'csrc')}`.")
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"could not load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = handle.gspl_abi_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {got}, python binding {ABI_VERSION}; rebuild the extension")
+    _LIB = handle
+    return _LIB
+
+
+# Optional per-call device timing (bench.py): a list that receives (name, start_event, end_event).
+# Events are recorded on torch's current stream, which is the stream every kernel is launched on.
+_PROFILE = None
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop():
+    """Returns {name: [ms, ...]} (synchronises)."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in rec or []:
+        out.setdefault(name, []).append(e0.elapsed_time(e1))
+    return out
+
+
+def call(name: str, *args):
+    """Invoke one C-ABI entry point and raise on a non-zero status."""
+    fn = getattr(lib(), name)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        _PROFILE.append((name, e0, e1))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().gspl_last_error()
+        raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t, dtype=None, offset_bytes: int = 0):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("gspl ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("gspl ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return c_void_p(t.data_ptr() + offset_bytes)
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

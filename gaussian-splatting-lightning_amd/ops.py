@@ -1,0 +1,529 @@
+"""
+ops.py — torch.autograd.Function wrappers over the C-ABI, mirroring the operator interfaces the
+reference's renderers call (same names, argument meaning and error behaviour):
+
+  gsplat v1 (internal/renderers/gsplat_v1_renderer.py:8-20)
+      fully_fused_projection, isect_tiles, isect_offset_encode, rasterize_to_pixels,
+      spherical_harmonics, spherical_harmonics_decomposed
+  gsplat v0 (internal/renderers/gsplat_renderer.py:2-4, pypreprocess_gsplat_renderer.py:1-2)
+      project_gaussians, rasterize_gaussians
+  Inria (internal/renderers/vanilla_renderer.py:14)
+      GaussianRasterizationSettings, GaussianRasterizer
+
+Host side only: shape checks, buffer allocation through torch's caching allocator, stream hand-off.
+All arithmetic happens in libgspl_hip.so; nothing here falls back to PyTorch math.
+"""
+from __future__ import annotations
+
+import math
+from typing import NamedTuple, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+_SUPPORTED_D = (1, 2, 3, 4, 8)
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _grad_or_zeros(g: Optional[Tensor], like_shape, device) -> Tensor:
+    if g is None:
+        return torch.zeros(like_shape, dtype=torch.float32, device=device)
+    return _f32c(g)
+
+
+# =============================================================================================
+# projection
+# =============================================================================================
+class _ProjectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier,
+                eps2d, near_plane, far_plane, radius_clip, calc_compensations, want_tiles):
+        lib = L.lib()
+        means, scales, quats, viewmats, Ks = map(_f32c, (means, scales, quats, viewmats, Ks))
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+        means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+        conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+        comps = torch.empty((C, N), dtype=torch.float32, device=dev) if calc_compensations else None
+        tiles = torch.empty((C, N), dtype=torch.int32, device=dev) if want_tiles else None
+        L.call("gspl_project_fwd", 
+            C, N, L.ptr(means), L.ptr(scales), L.ptr(quats), L.ptr(viewmats), L.ptr(Ks),
+            int(width), int(height), int(tile_size), float(scale_modifier), float(eps2d), float(near_plane),
+            float(far_plane), float(radius_clip),
+            L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(tiles), L.stream())
+        ctx.save_for_backward(means, scales, quats, viewmats, Ks, radii)
+        ctx.cfg = (int(width), int(height), float(scale_modifier), float(eps2d), bool(calc_compensations))
+        ctx.mark_non_differentiable(radii)
+        outs = [radii, means2d, depths, conics]
+        outs.append(comps if comps is not None else torch.empty(0, device=dev))
+        if tiles is not None:
+            ctx.mark_non_differentiable(tiles)
+        outs.append(tiles if tiles is not None else torch.empty(0, dtype=torch.int32, device=dev))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, _v_tiles):
+        lib = L.lib()
+        means, scales, quats, viewmats, Ks, radii = ctx.saved_tensors
+        width, height, scale_modifier, eps2d, calc_comp = ctx.cfg
+        C, N = radii.shape
+        dev = means.device
+        v_means2d = _grad_or_zeros(v_means2d, (C, N, 2), dev)
+        v_depths = _grad_or_zeros(v_depths, (C, N), dev)
+        v_conics = _grad_or_zeros(v_conics, (C, N, 3), dev)
+        v_comps = _grad_or_zeros(v_comps, (C, N), dev) if calc_comp else None
+        alloc = torch.empty if C == 1 else torch.zeros
+        v_means = alloc((N, 3), dtype=torch.float32, device=dev)
+        v_scales = alloc((N, 3), dtype=torch.float32, device=dev)
+        v_quats = alloc((N, 4), dtype=torch.float32, device=dev)
+        L.call("gspl_project_bwd", 
+            C, N, L.ptr(means), L.ptr(scales), L.ptr(quats), L.ptr(viewmats), L.ptr(Ks),
+            width, height, scale_modifier, eps2d, L.ptr(radii),
+            L.ptr(v_means2d), L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comps),
+            L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.stream())
+        return (v_means, v_scales, v_quats) + (None,) * 12
+
+
+def fully_fused_projection(
+        means: Tensor, covars: Optional[Tensor], quats: Tensor, scales: Tensor, viewmats: Tensor, Ks: Tensor,
+        width: int, height: int, eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10,
+        radius_clip: float = 0.0, packed: bool = False, sparse_grad: bool = False,
+        calc_compensations: bool = False, camera_model: str = "pinhole", tile_size: int = 16,
+        scale_modifier: float = 1.0):
+    """gsplat-v1 signature (reference call: gsplat_v1_renderer.py:408-421).
+    means [N,3], quats [N,4] (wxyz), scales [N,3], viewmats [C,4,4] (world->camera, NOT transposed),
+    Ks [C,3,3].  Returns (radii [C,N] i32, means2d [C,N,2], depths [C,N], conics [C,N,3],
+    compensations [C,N] | None)."""
+    if covars is not None:
+        raise NotImplementedError("covars input is not part of the reference's call sites")
+    if packed:
+        raise NotImplementedError("packed=True is not used by the reference (always packed=False)")
+    if camera_model != "pinhole":
+        raise NotImplementedError(f"camera_model={camera_model!r}: only the pinhole model is built")
+    assert means.dim() == 2 and means.shape[1] == 3, means.shape
+    assert quats.shape == (means.shape[0], 4) and scales.shape == (means.shape[0], 3)
+    assert viewmats.dim() == 3 and viewmats.shape[1:] == (4, 4) and Ks.shape == (viewmats.shape[0], 3, 3)
+    radii, means2d, depths, conics, comps, _ = _ProjectFn.apply(
+        means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier, eps2d, near_plane, far_plane,
+        radius_clip, calc_compensations, False)
+    return radii, means2d, depths, conics, (comps if calc_compensations else None)
+
+
+def project_gaussians(
+        means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor, viewmat: Tensor,
+        fx, fy, cx, cy, img_height: int, img_width: int, block_width: int,
+        clip_thresh: float = 0.01, filter_2d_kernel_size: float = 0.3):
+    """gsplat-v0 signature (reference call: gsplat_renderer.py:64-79).  viewmat [3|4, 4] world->camera.
+    Returns (xys [N,2], depths [N], radii [N] i32, conics [N,3], compensation [N], num_tiles_hit [N] i32,
+    cov3d).  cov3d is returned as None: no in-scope renderer of the reference consumes it."""
+    dev = means3d.device
+    vm = torch.eye(4, dtype=torch.float32, device=dev)
+    vm[: viewmat.shape[0], :] = viewmat.to(torch.float32)
+    if isinstance(fx, Tensor):
+        K = torch.zeros(3, 3, dtype=torch.float32, device=dev)
+        K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[2, 2] = fx, fy, cx, cy, 1.0
+    else:
+        K = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    radii, xys, depths, conics, comps, tiles = _ProjectFn.apply(
+        means3d, scales, quats, vm[None], K[None], img_width, img_height, block_width, glob_scale,
+        filter_2d_kernel_size, clip_thresh, 1e10, 0.0, True, True)
+    return xys[0], depths[0], radii[0], conics[0], comps[0], tiles[0], None
+
+
+# =============================================================================================
+# spherical harmonics
+# =============================================================================================
+class _SHFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, dirs, origin, dc, rest, masks, flags):
+        """dc: [N,K,3] merged (rest is None) or [N,1,3]; rest: [N,K-1,3] or None."""
+        lib = L.lib()
+        dirs, dc, rest = _f32c(dirs), _f32c(dc), _f32c(rest)
+        origin = _f32c(origin)
+        N = dirs.shape[0]
+        dev = dirs.device
+        merged = rest is None
+        if merged:
+            K = dc.shape[1]
+            dc_stride = rest_stride = 3 * K
+            rest_ptr = L.ptr(dc, offset_bytes=12) if K > 1 else None
+            n_coeffs = K
+        else:
+            assert dc.shape[1] == 1
+            dc_stride, rest_stride = 3, 3 * rest.shape[1]
+            rest_ptr = L.ptr(rest) if rest.shape[1] > 0 else None
+            n_coeffs = 1 + rest.shape[1]
+        if (degree + 1) ** 2 > n_coeffs:
+            raise ValueError(f"degree {degree} needs {(degree + 1) ** 2} coefficients, got {n_coeffs}")
+        mask8 = None
+        if masks is not None:
+            mask8 = masks.to(torch.uint8).contiguous()
+        colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev) if (flags & L.GSPL_SH_ADD_HALF_CLAMP) else None
+        L.call("gspl_sh_fwd", N, int(degree), L.ptr(dirs), L.ptr(origin), L.ptr(dc), dc_stride, rest_ptr, rest_stride,
+                                L.ptr(mask8), int(flags), L.ptr(colors), L.ptr(clamped), L.stream())
+        ctx.save_for_backward(dirs, origin, dc, rest, mask8, clamped)
+        ctx.cfg = (int(degree), int(flags), merged, n_coeffs, dc_stride, rest_stride)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        lib = L.lib()
+        dirs, origin, dc, rest, mask8, clamped = ctx.saved_tensors
+        degree, flags, merged, n_coeffs, dc_stride, rest_stride = ctx.cfg
+        N = dirs.shape[0]
+        dev = dirs.device
+        v_colors = _f32c(v_colors)
+        need_dirs = ctx.needs_input_grad[1]
+        v_dirs = torch.empty((N, 3), dtype=torch.float32, device=dev) if need_dirs else None
+        v_dc = torch.empty_like(dc)
+        if merged:
+            v_rest = None
+            v_rest_ptr = L.ptr(v_dc, offset_bytes=12) if n_coeffs > 1 else None
+            rest_ptr = L.ptr(dc, offset_bytes=12) if n_coeffs > 1 else None
+        else:
+            v_rest = torch.empty_like(rest)
+            v_rest_ptr = L.ptr(v_rest) if n_coeffs > 1 else None
+            rest_ptr = L.ptr(rest) if n_coeffs > 1 else None
+        L.call("gspl_sh_bwd", N, degree, n_coeffs, L.ptr(dirs), L.ptr(origin), L.ptr(dc), dc_stride, rest_ptr, rest_stride,
+                                L.ptr(mask8), flags, L.ptr(clamped), L.ptr(v_colors),
+                                L.ptr(v_dc), v_rest_ptr, L.ptr(v_dirs), L.stream())
+        return None, v_dirs, None, v_dc, v_rest, None, None
+
+
+def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor] = None) -> Tensor:
+    """gsplat signature (reference call: gsplat_renderer.py:105, gsplat_v1_renderer.py:124).
+    dirs [N,3] (need not be unit), coeffs [N,K,3], masks [N] bool -> colours [N,3] (no +0.5)."""
+    assert dirs.shape[-1] == 3 and coeffs.dim() == 3 and coeffs.shape[-1] == 3 and coeffs.shape[0] == dirs.shape[0]
+    return _SHFn.apply(degrees_to_use, dirs, None, coeffs, None, masks, 0)
+
+
+def spherical_harmonics_decomposed(degrees_to_use: int, dirs: Tensor, dc: Tensor, coeffs: Tensor,
+                                   masks: Optional[Tensor] = None) -> Tensor:
+    """yzslab-fork signature (reference call: gsplat_v1_renderer.py:124-130): dc [N,1,3], coeffs [N,K-1,3]."""
+    return _SHFn.apply(degrees_to_use, dirs, None, dc, coeffs, masks, 0)
+
+
+def sh_view_colors(degree: int, means: Tensor, camera_center: Tensor, dc: Tensor, rest: Optional[Tensor],
+                   masks: Optional[Tensor] = None, detach_means: bool = True) -> Tensor:
+    """Fused `clamp(SH(means - camera_center) + 0.5, min=0)` (gsplat_renderer.py:104-106) in one kernel:
+    no viewdirs tensor, no separate clamp pass.  dc [N,1,3] + rest [N,K-1,3], or dc = merged [N,K,3] with rest None."""
+    m = means.detach() if detach_means else means
+    return _SHFn.apply(degree, m, camera_center, dc, rest, masks, L.GSPL_SH_ADD_HALF_CLAMP)
+
+
+# =============================================================================================
+# tile binning
+# =============================================================================================
+def _isect(mode: int, means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_w: int, tile_h: int):
+    lib = L.lib()
+    means2d, depths = _f32c(means2d.detach()), _f32c(depths.detach())
+    radii = radii.to(torch.int32).contiguous()
+    N = means2d.shape[0]
+    dev = means2d.device
+    tiles = torch.empty((N,), dtype=torch.int32, device=dev)
+    cum = torch.empty((N,), dtype=torch.int64, device=dev)
+    if N == 0:
+        z64 = torch.empty((0,), dtype=torch.int64, device=dev)
+        return tiles, z64, torch.empty((0,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.gspl_isect_workspace_bytes(N, 0)
+    if ws_bytes == 0:
+        raise RuntimeError("gspl_isect_workspace_bytes failed: " + lib.gspl_last_error().decode())
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    L.call("gspl_isect_count", N, mode, L.ptr(means2d), L.ptr(radii), tile_size, tile_w, tile_h,
+                                 L.ptr(tiles), L.ptr(cum), L.ptr(ws), ws_bytes, L.stream())
+    n_isects = int(cum[-1].item())        # the one host read-back of the pipeline (sizes the sort buffers)
+    isect_ids = torch.empty((n_isects,), dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty((n_isects,), dtype=torch.int32, device=dev)
+    if n_isects > 0:
+        ws_bytes = lib.gspl_isect_workspace_bytes(N, n_isects)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        L.call("gspl_isect_emit_sort", N, mode, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(cum),
+                                         tile_size, tile_w, tile_h, n_isects, L.ptr(isect_ids), L.ptr(flatten_ids),
+                                         L.ptr(ws), ws_bytes, L.stream())
+    return tiles, isect_ids, flatten_ids
+
+
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
+                sort: bool = True, packed: bool = False, n_cameras: Optional[int] = None,
+                camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None,
+                mode: int = L.GSPL_MODE_GSPLAT):
+    """gsplat-v1 signature (reference call: gsplat_v1_renderer.py:446-457).  Single camera:
+    means2d [1,N,2] or [N,2], radii [1,N] or [N], depths likewise.
+    Returns (tiles_per_gauss [1,N] i32, isect_ids [I] i64, flatten_ids [I] i32)."""
+    if packed or camera_ids is not None or gaussian_ids is not None:
+        raise NotImplementedError("packed mode is not used by the reference")
+    if n_cameras not in (None, 1) or (means2d.dim() == 3 and means2d.shape[0] != 1):
+        raise NotImplementedError("one camera per call (the reference always renders one camera per rank)")
+    if not sort:
+        raise NotImplementedError("sort=False is not used by the reference")
+    tiles, ids, flat = _isect(mode, means2d.reshape(-1, 2), radii.reshape(-1), depths.reshape(-1), tile_size, tile_width, tile_height)
+    return tiles[None], ids, flat
+
+
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    """gsplat-v1 signature (gsplat_v1_renderer.py:458) -> offsets [n_cameras, tile_height, tile_width] i32."""
+    if n_cameras != 1:
+        raise NotImplementedError("one camera per call")
+    lib = L.lib()
+    offsets = torch.empty((1, tile_height, tile_width), dtype=torch.int32, device=isect_ids.device)
+    isect_ids = isect_ids.contiguous()
+    L.call("gspl_isect_offsets", isect_ids.shape[0], L.ptr(isect_ids) if isect_ids.numel() else None,
+                                   tile_width, tile_height, L.ptr(offsets), L.stream())
+    return offsets
+
+
+# =============================================================================================
+# compositing
+# =============================================================================================
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets, flatten_ids,
+                absgrad, mode, layout):
+        lib = L.lib()
+        means2d_in = means2d
+        means2d, conics, colors, opacities = map(_f32c, (means2d, conics, colors, opacities))
+        backgrounds = _f32c(backgrounds)
+        N, D = colors.shape
+        assert D in _SUPPORTED_D
+        dev = means2d.device
+        tile_w, tile_h = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+        offsets = offsets.to(torch.int32).contiguous()
+        flatten_ids = flatten_ids.to(torch.int32).contiguous()
+        assert offsets.numel() == tile_w * tile_h
+        n_isects = flatten_ids.shape[0]
+        shape = (height, width, D) if layout == L.GSPL_LAYOUT_HWC else (D, height, width)
+        out = torch.empty(shape, dtype=torch.float32, device=dev)
+        alphas = torch.empty((height, width), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((height, width), dtype=torch.int32, device=dev)
+        L.call("gspl_composite_fwd", 
+            N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
+            width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
+            L.ptr(out), L.ptr(alphas), L.ptr(last_ids), L.stream())
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids)
+        ctx.cfg = (width, height, tile_size, tile_w, tile_h, bool(absgrad), mode, layout)
+        ctx.means2d_ref = means2d_in      # the caller's tensor object: `.absgrad` is attached to it in backward
+        return out, alphas
+
+    @staticmethod
+    def backward(ctx, v_out, v_alphas):
+        lib = L.lib()
+        means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        width, height, tile_size, tile_w, tile_h, absgrad, mode, layout = ctx.cfg
+        N, D = colors.shape
+        dev = means2d.device
+        n_isects = flatten_ids.shape[0]
+        v_means2d = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+        v_abs = torch.zeros((N, 2), dtype=torch.float32, device=dev) if absgrad else None
+        v_conics = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        v_colors = torch.zeros((N, D), dtype=torch.float32, device=dev)
+        v_opac = torch.zeros((N,), dtype=torch.float32, device=dev)
+        if n_isects > 0 and N > 0:
+            v_out = _grad_or_zeros(v_out, alphas.shape + (D,) if layout == L.GSPL_LAYOUT_HWC else (D,) + alphas.shape, dev)
+            v_alphas = _f32c(v_alphas) if v_alphas is not None else None
+            L.call("gspl_composite_bwd", 
+                N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
+                width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids),
+                L.ptr(v_out), L.ptr(v_alphas), L.ptr(v_means2d), L.ptr(v_abs), L.ptr(v_conics), L.ptr(v_colors), L.ptr(v_opac),
+                L.stream())
+        if absgrad:
+            # same side channel as gsplat: the density controller reads `viewspace_points.absgrad`
+            # (internal/density_controllers/vanilla_density_controller.py:112-113)
+            ctx.means2d_ref.absgrad = v_abs
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            T_final = 1.0 - alphas
+            vo = v_out if layout == L.GSPL_LAYOUT_HWC else v_out.permute(1, 2, 0)
+            v_bg = (vo * T_final[..., None]).sum(dim=(0, 1))
+        return v_means2d, v_conics, v_colors, v_opac.reshape(opacities.shape), v_bg, None, None, None, None, None, None, None, None
+
+
+def _composite(means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets, flatten_ids,
+               absgrad, mode, layout):
+    """Channel-count adapter: kernels are built for D in {1,2,3,4,8}; other widths are zero-padded /
+    split into groups of 8 (extra channels composite to zero and carry zero gradient)."""
+    D = colors.shape[1]
+    if D in _SUPPORTED_D:
+        return _CompositeFn.apply(means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets,
+                                  flatten_ids, absgrad, mode, layout)
+    outs, alphas = [], None
+    for s in range(0, D, 8):
+        e = min(D, s + 8)
+        c = colors[:, s:e]
+        bg = None if backgrounds is None else backgrounds[s:e]
+        w = e - s
+        pad = next(d for d in _SUPPORTED_D if d >= w) - w
+        if pad:
+            c = torch.nn.functional.pad(c, (0, pad))
+            bg = None if bg is None else torch.nn.functional.pad(bg, (0, pad))
+        o, alphas = _CompositeFn.apply(means2d, conics, c, opacities, bg, width, height, tile_size, offsets, flatten_ids,
+                                       absgrad and s == 0, mode, layout)
+        outs.append(o[..., :w] if layout == L.GSPL_LAYOUT_HWC else o[:w])
+    return torch.cat(outs, dim=-1 if layout == L.GSPL_LAYOUT_HWC else 0), alphas
+
+
+def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
+                        image_width: int, image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
+                        backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
+                        absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+    """gsplat signature as the reference calls it (gsplat_v1_renderer.py:588-601): means2d [N,2] (or [1,N,2]),
+    conics [1,N,3], colors [1,N,D], opacities [1,N], isect_offsets [1,th,tw], backgrounds [1,D].
+    Returns (colors [1,H,W,D], alphas [1,H,W,1]).  With absgrad=True, backward sets `means2d.absgrad`."""
+    if packed or masks is not None:
+        raise NotImplementedError("packed / masks are not used by the reference")
+    m2 = means2d if means2d.dim() == 2 else means2d.squeeze(0)
+    out, alphas = _composite(m2, conics.reshape(-1, 3), colors.reshape(-1, colors.shape[-1]), opacities.reshape(-1),
+                             None if backgrounds is None else backgrounds.reshape(-1), image_width, image_height, tile_size,
+                             isect_offsets.reshape(-1), flatten_ids, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_HWC)
+    if absgrad and m2 is not means2d:
+        raise ValueError("absgrad needs means2d given as [N,2] so that .absgrad lands on the caller's tensor")
+    return out[None], alphas[None, ..., None]
+
+
+def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
+                        colors: Tensor, opacity: Tensor, img_height: int, img_width: int, block_width: int,
+                        background: Optional[Tensor] = None, return_alpha: bool = False, absgrad: bool = False):
+    """gsplat-v0 signature (reference call: gsplat_renderer.py:86-99): bins + composites in one call.
+    colors [N,D], opacity [N,1] -> [H,W,D] (and alpha [H,W] when return_alpha)."""
+    if block_width != 16:
+        raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
+    tile_w, tile_h = (img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width
+    _, ids, flat = _isect(L.GSPL_MODE_GSPLAT, xys, radii, depths, block_width, tile_w, tile_h)
+    offsets = isect_offset_encode(ids, 1, tile_w, tile_h)
+    out, alphas = _composite(xys, conics, colors, opacity.reshape(-1), background, img_width, img_height, block_width,
+                             offsets.reshape(-1), flat, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_HWC)
+    return (out, alphas) if return_alpha else out
+
+
+# =============================================================================================
+# Inria API  (diff_gaussian_rasterization.GaussianRasterizer)
+# =============================================================================================
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool = False
+    debug: bool = False
+
+
+class _InriaRasterizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+        lib = L.lib()
+        s: GaussianRasterizationSettings = settings
+        dev = means3D.device
+        means3D = _f32c(means3D)
+        N = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        sh, colors_precomp, scales, rotations, cov3D_precomp = map(_f32c, (sh, colors_precomp, scales, rotations, cov3D_precomp))
+        opac = _f32c(opacities).reshape(-1)
+        viewm, projm, campos = _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos)
+        bg = _f32c(s.bg)
+        n_coeffs = sh.shape[1] if sh is not None else 0
+        radii = torch.empty((N,), dtype=torch.int32, device=dev)
+        means2d = torch.empty((N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((N,), dtype=torch.float32, device=dev)
+        conics = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev)
+        cov3d = torch.empty((N, 6), dtype=torch.float32, device=dev)
+        tile = 16
+        tile_w, tile_h = (W + tile - 1) // tile, (H + tile - 1) // tile
+        if N > 0:
+            L.call("gspl_inria_preprocess_fwd", 
+                N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
+                L.ptr(sh), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
+                float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
+                L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
+                L.stream())
+        _, ids, flat = _isect(L.GSPL_MODE_INRIA, means2d, radii, depths, tile, tile_w, tile_h)
+        offsets = isect_offset_encode(ids, 1, tile_w, tile_h).reshape(-1)
+        n_isects = flat.shape[0]
+        out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        alphas = torch.empty((H, W), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((H, W), dtype=torch.int32, device=dev)
+        L.call("gspl_composite_fwd", 
+            N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
+            L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat) if n_isects else None,
+            L.ptr(out), L.ptr(alphas), L.ptr(last_ids), L.stream())
+        ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
+                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, alphas, last_ids)
+        ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
+                   float(s.scale_modifier), colors_precomp is not None, opacities.shape)
+        ctx.mark_non_differentiable(radii)
+        return out, radii
+
+    @staticmethod
+    def backward(ctx, v_out, _v_radii):
+        lib = L.lib()
+        (means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
+         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, alphas, last_ids) = ctx.saved_tensors
+        H, W, tile, tile_w, tile_h, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, opac_shape = ctx.cfg
+        N = means3D.shape[0]
+        dev = means3D.device
+        n_isects = flat.shape[0]
+        v_out = _grad_or_zeros(v_out, (3, H, W), dev)
+        v_means2d = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+        v_conics = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        v_colors = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        v_opac = torch.zeros((N,), dtype=torch.float32, device=dev)
+        if n_isects > 0:
+            L.call("gspl_composite_bwd", 
+                N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
+                L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat), L.ptr(alphas), L.ptr(last_ids),
+                L.ptr(v_out), None, L.ptr(v_means2d), None, L.ptr(v_conics), L.ptr(v_colors), L.ptr(v_opac), L.stream())
+        v_means = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_ndc = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        use_cov = cov3D_precomp is not None
+        v_scales = None if use_cov else torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_quats = None if use_cov else torch.empty((N, 4), dtype=torch.float32, device=dev)
+        v_cov = torch.empty((N, 6), dtype=torch.float32, device=dev) if use_cov else None
+        v_sh = None if has_precomp_colors else torch.empty_like(sh)
+        v_cp = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_precomp_colors else None
+        if N > 0:
+            L.call("gspl_inria_preprocess_bwd", 
+                N, degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3d), L.ptr(sh),
+                L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tanfovx, tanfovy, scale_modifier,
+                L.ptr(radii), L.ptr(clamped), L.ptr(v_means2d), L.ptr(v_conics), L.ptr(v_colors),
+                L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_cp), L.ptr(v_ndc),
+                L.stream())
+        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """Drop-in for `diff_gaussian_rasterization.GaussianRasterizer` as the reference uses it
+    (internal/renderers/vanilla_renderer.py:79,111-120): returns (color [3,H,W], radii [N] i32);
+    `means2D.grad` receives the screen-space gradient in the Inria (NDC-scaled) units."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return _InriaRasterizeFn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                       self.raster_settings)

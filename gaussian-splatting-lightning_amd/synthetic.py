@@ -1,0 +1,47 @@
+"""Synthetic workloads of SURVEY.md §8(d) / BASELINE.md §2 (seed 42 = the reference's
+`seed_everything_default`, internal/entrypoints/gspl.py:15).  Used by bench.py and smoke().
+
+    S-1080p-1M : N = 1 000 000, 1920x1080, fx = fy = 1600   (the metric point)
+    S-800-100k : N =   100 000,  800x800,  fx = fy = 1111.1 (lego proxy, configs[0]/[1])
+"""
+from __future__ import annotations
+
+import torch
+
+WORKLOADS = {
+    "S-1080p-1M": dict(n=1_000_000, width=1920, height=1080, fx=1600.0),
+    "S-800-100k": dict(n=100_000, width=800, height=800, fx=1111.1),
+    "S-smoke": dict(n=20_000, width=320, height=208, fx=300.0),
+}
+
+
+def scene(n: int, seed: int = 42, sh_degree: int = 3):
+    """means U[-1.3,1.3]^3 (Blender init box, blender_dataparser.py:137), scales exp(N(-4.6,0.6)),
+    unit quaternions, opacity sigmoid(N(0,1)), SH [N,K,3] ~ N(0, 0.2)."""
+    g = torch.Generator().manual_seed(seed)
+    K = (sh_degree + 1) ** 2
+    means = (torch.rand(n, 3, generator=g) * 2 - 1) * 1.3
+    scales = torch.exp(torch.randn(n, 3, generator=g) * 0.6 - 4.6)
+    quats = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=-1)
+    opac = torch.sigmoid(torch.randn(n, 1, generator=g))
+    shs = torch.randn(n, K, 3, generator=g) * 0.2
+    return means, scales, quats, opac, shs
+
+
+def camera(width: int, height: int, fx: float, fy: float = None, distance: float = 4.0):
+    """Identity rotation, translation (0,0,distance); matrices in the reference's transposed storage
+    (internal/cameras/cameras.py:147-192)."""
+    fy = fx if fy is None else fy
+    w2c = torch.eye(4)
+    w2c[3, 2] = distance
+    znear, zfar = 0.01, 100.0
+    tanx, tany = 0.5 * width / fx, 0.5 * height / fy
+    P = torch.zeros(4, 4)
+    P[0, 0], P[1, 1] = 1.0 / tanx, 1.0 / tany
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    full = w2c @ P.T
+    center = torch.linalg.inv(w2c)[3, :3]
+    return {"world_to_camera": w2c, "full_projection": full, "camera_center": center, "fx": fx, "fy": fy,
+            "cx": width / 2.0, "cy": height / 2.0, "width": width, "height": height, "tanfovx": tanx, "tanfovy": tany}

@@ -1,0 +1,412 @@
+"""GPU parity tests: the HIP path (through the C-ABI / the autograd wrappers over it) against the
+oracle on identical seeded inputs, against the committed golden fixtures, and — at BASELINE size —
+through size-independent properties.
+
+Tolerances (BASELINE.json north_star): forward <= 1e-5 abs per pixel, gradients <= 1e-4 relative.
+Integer / index outputs (radii, tile counts, sort keys, offsets) are compared bit-exactly.
+Pixels / splats whose discrete skip-stop-clamp decision sits within 2e-5 relative of its threshold
+("fragile", flagged by the fp64 oracle) are excluded from the strict bound and must be rare.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gsplat_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import gspl_amd  # noqa: F401
+    from gspl_amd import _lib, ops
+    _lib.lib()       # raises if the extension is missing: no silent fallback
+    return ops
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _cuda(*ts):
+    return [t.detach().float().contiguous().to(_dev()) for t in ts]
+
+
+def _cam_tensors(cam):
+    vm = cam["world_to_camera"].T.contiguous().float().to(_dev())
+    K = torch.tensor([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1.0]], dtype=torch.float32, device=_dev())
+    return vm, K
+
+
+from hip_helpers import assert_close_scaled, hip_composite_bwd, hip_composite_fwd, t32  # noqa: E402
+
+
+# ---------------------------------------------------------------------------------------------
+# projection
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cam", [0, 1])
+def test_projection_vs_reference_golden(hip, golden_dir, cam):
+    """HIP projection against the reference Python's own outputs and gradients (fixtures)."""
+    z = np.load(os.path.join(golden_dir, "ref_projection.npz"))
+    p = f"cam{cam}_"
+    fx, fy, cx, cy, W, H = z[p + "intr"]
+    means, scales, quats = [t32(z[k]).requires_grad_(True) for k in ("means", "scales", "quats")]
+    viewmat = t32(z[p + "w2c"]).T.contiguous()
+    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(
+        means, scales, 1.0, quats, viewmat, float(fx), float(fy), float(cx), float(cy), int(H), int(W), 16)
+    r_ref = z[p + "radii"]
+    same = radii.cpu().numpy() == r_ref
+    assert same.mean() >= 0.999, "radii (ceil may flip on an fp32 rounding boundary for <0.1 %)"
+    assert np.array_equal((radii > 0).cpu().numpy(), z[p + "mask"])
+    assert np.array_equal(tiles.cpu().numpy()[same], z[p + "tiles"][same])
+    np.testing.assert_allclose(xys.detach().cpu().numpy(), z[p + "xys"], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(depths.detach().cpu().numpy(), z[p + "depths"], rtol=1e-5, atol=1e-6)
+    assert_close_scaled(conics.detach().cpu().numpy(), z[p + "conics"], 2e-4, "conics", frac_ok=0.999)
+    np.testing.assert_allclose(comp.detach().cpu().numpy(), z[p + "comp"], rtol=2e-4, atol=1e-6)
+    loss = (xys * t32(z[p + "w_xy"])).sum() + (depths * t32(z[p + "w_d"])).sum() + (conics * t32(z[p + "w_c"])).sum() \
+        + (comp * t32(z[p + "w_k"])).sum()
+    loss.backward()
+    for got, name in ((means.grad, "g_means"), (scales.grad, "g_scales"), (quats.grad, "g_quats")):
+        assert_close_scaled(got.cpu().numpy(), z[p + name], 3e-4, name, frac_ok=0.998)
+
+
+def test_projection_known_answer_vector(hip, golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_kat.npz"))
+    fx, fy, cx, cy, W, H = z["intr"]
+    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(
+        t32(z["means"]), t32(z["scales"]), 1.0, t32(z["quats"]), t32(z["w2c"]).T.contiguous(),
+        float(fx), float(fy), float(cx), float(cy), int(H), int(W), 16)
+    assert radii.tolist() == [0, 4, 0, 16783]
+    m = (radii > 0).cpu().numpy()
+    np.testing.assert_allclose(conics.cpu().numpy()[m], z["exp_conics_masked"], rtol=1e-4)
+    np.testing.assert_allclose(comp.cpu().numpy()[m], z["exp_comp_masked"], rtol=1e-5)
+    assert tiles.cpu().numpy()[m].tolist() == [4, 4346]
+    np.testing.assert_allclose(xys.cpu().numpy()[[1, 3]] - 0.5, z["exp_xys_rows13_ndc_convention"], rtol=3e-6, atol=3e-3)
+
+
+def test_projection_vs_oracle_fp64_batched_cameras(hip):
+    """v1 API, C = 3 cameras in one launch, gradients accumulated across cameras."""
+    means, scales, quats, _, _ = O.synthetic_scene(5000, seed=3)
+    scales = scales * 3
+    W, H = 400, 304
+    cams = [O.synthetic_camera(W, H, 380.0, 375.0, distance=d) for d in (3.0, 4.0, 5.5)]
+    vms = torch.stack([c["world_to_camera"].T for c in cams]).float().to(_dev())
+    Ks = torch.stack([torch.tensor([[c["fx"], 0, c["cx"]], [0, c["fy"], c["cy"]], [0, 0, 1.0]]) for c in cams]).float().to(_dev())
+    m, s, q = [t.requires_grad_(True) for t in _cuda(means, scales, quats)]
+    radii, means2d, depths, conics, comps = hip.fully_fused_projection(m, None, q, s, vms, Ks, W, H, calc_compensations=True)
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(means2d.shape, generator=g), torch.randn(depths.shape, generator=g),
+          torch.randn(conics.shape, generator=g) * 0.1, torch.randn(comps.shape, generator=g)]
+    (sum((a * w.to(_dev())).sum() for a, w in zip((means2d, depths, conics, comps), ws))).backward()
+
+    md, sd, qd = [t.double().requires_grad_(True) for t in (means, scales, quats)]
+    loss = 0
+    for ci, c in enumerate(cams):
+        xys, dep, rad, con, cmp_, tiles, _, mask, _, _ = O.project_gaussians(
+            md, sd, 1.0, qd, c["world_to_camera"].double(), c["fx"], c["fy"], c["cx"], c["cy"], H, W)
+        same = rad.numpy() == radii[ci].cpu().numpy()
+        assert same.mean() > 0.999
+        np.testing.assert_allclose(means2d[ci].detach().cpu().numpy()[same], xys.detach().numpy()[same], rtol=1e-5, atol=2e-3)
+        assert_close_scaled(conics[ci].detach().cpu().numpy()[same], con.detach().numpy()[same], 2e-4, "conics", 0.999)
+        loss = loss + (xys * ws[0][ci].double()).sum() + (dep * ws[1][ci].double()).sum() \
+            + (con * ws[2][ci].double()).sum() + (cmp_ * ws[3][ci].double()).sum()
+    loss.backward()
+    for got, ref, name in ((m.grad, md.grad, "means"), (s.grad, sd.grad, "scales"), (q.grad, qd.grad, "quats")):
+        assert_close_scaled(got.cpu().numpy(), ref.numpy(), 3e-4, name, frac_ok=0.998)
+
+
+# ---------------------------------------------------------------------------------------------
+# spherical harmonics
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("form", ["merged", "decomposed"])
+def test_sh_vs_reference_golden(hip, golden_dir, deg, form):
+    z = np.load(os.path.join(golden_dir, "ref_sh.npz"))
+    K = (deg + 1) ** 2
+    dirs = t32(z["dirs"] * 2.5).requires_grad_(True)          # un-normalised on purpose
+    w = t32(z["w"])
+    if form == "merged":
+        c = t32(z["coeffs"][:, :K]).requires_grad_(True)
+        rgb = hip.spherical_harmonics(deg, dirs, c)
+        (rgb * w).sum().backward()
+        gc = c.grad.cpu().numpy()
+    else:
+        dc = t32(z["coeffs"][:, :1]).requires_grad_(True)
+        rest = t32(z["coeffs"][:, 1:K]).requires_grad_(True)
+        rgb = hip.spherical_harmonics_decomposed(deg, dirs, dc, rest)
+        (rgb * w).sum().backward()
+        gc = np.concatenate([dc.grad.cpu().numpy(), rest.grad.cpu().numpy()], axis=1)
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), z[f"deg{deg}_rgb"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(gc, z[f"deg{deg}_g_coeffs"], rtol=2e-5, atol=2e-6)
+    if deg > 0:
+        # golden dirs gradient is w.r.t. unit dirs; ours is w.r.t. 2.5*dirs through the normalisation
+        d = torch.from_numpy(z["dirs"]).double().requires_grad_(True)
+        cc = torch.from_numpy(z["coeffs"][:, :K]).double()
+        (O.eval_sh(deg, cc, d * 2.5) * torch.from_numpy(z["w"]).double()).sum().backward()
+        assert_close_scaled(dirs.grad.cpu().numpy(), d.grad.numpy() / 2.5, 2e-4, "v_dirs")
+
+
+def test_sh_masks_partial_degree_and_fused_clamp(hip):
+    n, K = 3001, 16                       # ragged (not a multiple of the 256-row tile)
+    g = torch.Generator().manual_seed(1)
+    means = torch.randn(n, 3, generator=g)
+    center = torch.tensor([0.3, -0.2, 4.0])
+    dc = torch.randn(n, 1, 3, generator=g) * 0.5
+    rest = torch.randn(n, K - 1, 3, generator=g) * 0.5
+    mask = torch.rand(n, generator=g) > 0.3
+    w = torch.randn(n, 3, generator=g)
+    for deg in (0, 2, 3):
+        dcg, rg = [t.requires_grad_(True) for t in _cuda(dc, rest)]
+        col = hip.sh_view_colors(deg, means.to(_dev()), center.to(_dev()), dcg, rg, mask.to(_dev()))
+        (col * w.to(_dev())).sum().backward()
+        dcd, rd = dc.double().requires_grad_(True), rest.double().requires_grad_(True)
+        ref = O.sh_colors(deg, torch.cat([dcd, rd], 1), means.double(), center.double(), detach_dirs=True)
+        ref = torch.where(mask[:, None], ref, torch.zeros((), dtype=torch.float64))
+        (ref * w.double()).sum().backward()
+        np.testing.assert_allclose(col.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=3e-6)
+        np.testing.assert_allclose(dcg.grad.cpu().numpy(), dcd.grad.numpy(), rtol=2e-5, atol=3e-6)
+        np.testing.assert_allclose(rg.grad.cpu().numpy(), rd.grad.numpy(), rtol=2e-5, atol=3e-6)
+        assert torch.all(rg.grad[:, (deg + 1) ** 2 - 1:] == 0)          # above the active degree
+
+
+# ---------------------------------------------------------------------------------------------
+# binning: bit-exact
+# ---------------------------------------------------------------------------------------------
+def _projected_scene(n, W, H, fx, seed=5, scale_mul=3.0, mode=O.MODE_GSPLAT):
+    means, scales, quats, opac, shs = O.synthetic_scene(n, seed=seed)
+    cam = O.synthetic_camera(W, H, fx)
+    res = O.project_gaussians(means, scales * scale_mul, 1.0, quats, cam["world_to_camera"], cam["fx"], cam["fy"],
+                              cam["cx"], cam["cy"], H, W)
+    return res, opac, shs, cam
+
+
+@pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
+@pytest.mark.parametrize("wh", [(320, 240), (333, 211), (16, 16)])
+def test_binning_bit_exact(hip, mode, wh):
+    W, H = wh
+    res, _, _, _ = _projected_scene(4000, W, H, 300.0)
+    xys, depths, radii = res[0], res[1], res[2]
+    tiles_ref, ids_ref, flat_ref, offs_ref = O.isect_tiles(mode, xys, radii, depths, W, H)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    tiles, ids, flat = hip.isect_tiles(xys.to(_dev())[None], radii.to(_dev())[None], depths.to(_dev())[None], 16, tw, th, mode=mode)
+    offs = hip.isect_offset_encode(ids, 1, tw, th)
+    assert np.array_equal(tiles[0].cpu().numpy(), tiles_ref)
+    assert np.array_equal(ids.cpu().numpy(), ids_ref)
+    assert np.array_equal(flat.cpu().numpy(), flat_ref)          # stable: ties keep Gaussian order
+    assert np.array_equal(offs.reshape(-1).cpu().numpy(), offs_ref)
+
+
+def test_binning_empty_inputs(hip):
+    d = _dev()
+    tiles, ids, flat = hip.isect_tiles(torch.zeros(1, 7, 2, device=d), torch.zeros(1, 7, dtype=torch.int32, device=d),
+                                       torch.zeros(1, 7, device=d), 16, 4, 3)
+    assert ids.numel() == 0 and flat.numel() == 0 and int(tiles.sum()) == 0
+    offs = hip.isect_offset_encode(ids, 1, 4, 3)
+    assert offs.shape == (1, 3, 4) and int(offs.abs().sum()) == 0
+    tiles, ids, flat = hip.isect_tiles(torch.zeros(1, 0, 2, device=d), torch.zeros(1, 0, dtype=torch.int32, device=d),
+                                       torch.zeros(1, 0, device=d), 16, 4, 3)
+    assert ids.numel() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing: forward <= 1e-5 abs / pixel, backward <= 1e-4 rel
+# ---------------------------------------------------------------------------------------------
+def _composite_case(mode, D, W, H, n=6000, seed=11, big=False):
+    res, opac, shs, cam = _projected_scene(n, W, H, 260.0, seed=seed, scale_mul=(12.0 if big else 3.0))
+    xys, depths, radii, conics, comp = res[0], res[1], res[2], res[3], res[4]
+    g = torch.Generator().manual_seed(seed)
+    colors = torch.rand(n, D, generator=g)
+    op = (opac.reshape(-1) * comp).float()
+    op[:20] = 1.0                                    # exercise the clamp
+    bg = torch.rand(D, generator=g)
+    if mode == O.MODE_INRIA:
+        xys = xys - 0.5
+    tiles, ids, flat, offs = O.isect_tiles(mode, xys, radii, depths, W, H)
+    return xys.float(), conics.float(), colors, op, bg, flat, offs
+
+
+@pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
+@pytest.mark.parametrize("D,wh,big", [(3, (320, 240), False), (1, (333, 211), False), (4, (160, 96), True), (8, (97, 65), False), (2, (64, 48), True)])
+def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
+    from gspl_amd import _lib as L
+    W, H = wh
+    xys, conics, colors, op, bg, flat, offs = _composite_case(mode, D, W, H, big=big)
+    out_ref, alpha_ref, last_ref, frag = O.composite_fwd(mode, xys, conics, colors, op, bg, W, H, offs, flat)
+    c = lambda a: torch.as_tensor(a).contiguous().to(_dev())
+    dxy, dcon, dcol, dop, dbg, dflat, doffs = c(xys), c(conics), c(colors), c(op), c(bg), c(flat), c(offs)
+    out, alphas, last = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat)
+    ok = frag == 0
+    assert ok.mean() > 0.995
+    assert np.abs(out.cpu().numpy() - out_ref)[ok].max() <= 1e-5
+    assert np.abs(alphas.cpu().numpy() - alpha_ref)[ok].max() <= 1e-5
+    assert np.array_equal(last.cpu().numpy()[ok], last_ref[ok])
+
+    g = torch.Generator().manual_seed(4)
+    v_out = torch.randn(H, W, D, generator=g)
+    v_alpha = torch.randn(H, W, generator=g)
+    got = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, alphas, last, c(v_out), c(v_alpha), absgrad=True)
+    # the oracle differentiates the discrete path the GPU took (its alphas / last_ids)
+    ref = O.composite_bwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, alphas.cpu().double().numpy(),
+                          last.cpu().numpy(), v_out.double().numpy(), v_alpha.double().numpy(), fragile_px=frag, absgrad=True)
+    keep = ref["fragile_g"] == 0
+    assert keep.mean() > 0.98
+    for k in ("v_means2d", "v_means2d_abs", "v_conics", "v_colors", "v_opacities"):
+        assert_close_scaled(got[k].cpu().numpy()[keep], ref[k][keep], 1e-4, f"{k} mode={mode} D={D}", frac_ok=0.9995)
+
+
+def test_composite_layout_chw_equals_hwc(hip):
+    from gspl_amd import _lib as L
+    W, H, D = 130, 70, 3
+    xys, conics, colors, op, bg, flat, offs = _composite_case(O.MODE_INRIA, D, W, H)
+    c = lambda a: torch.as_tensor(a).contiguous().to(_dev())
+    args = (c(xys), c(conics), c(colors), c(op), c(bg), W, H, c(offs), c(flat))
+    o1, a1, l1 = hip_composite_fwd(O.MODE_INRIA, *args, layout=L.GSPL_LAYOUT_HWC)
+    o2, a2, l2 = hip_composite_fwd(O.MODE_INRIA, *args, layout=L.GSPL_LAYOUT_CHW)
+    assert torch.equal(o1.permute(2, 0, 1), o2) and torch.equal(a1, a2) and torch.equal(l1, l2)
+
+
+def test_composite_no_intersections_gives_background(hip):
+    d = _dev()
+    W, H = 50, 20
+    offs = torch.zeros(((W + 15) // 16) * ((H + 15) // 16), dtype=torch.int32, device=d)
+    bg = torch.tensor([0.1, 0.7, 0.3], device=d)
+    out, alphas, last = hip_composite_fwd(O.MODE_GSPLAT, torch.zeros(0, 2, device=d), torch.zeros(0, 3, device=d),
+                                          torch.zeros(0, 3, device=d), torch.zeros(0, device=d), bg, W, H, offs,
+                                          torch.zeros(0, dtype=torch.int32, device=d))
+    assert torch.all(out == bg) and torch.all(alphas == 0) and torch.all(last == 0)
+
+
+def test_rasterize_to_pixels_wrapper_channels_and_absgrad(hip):
+    """The reference's v1 call shape ([1,N,*]), a 7-channel feature stack (rgb+depth+normal,
+    gsplat_v1_renderer.py:226-285 -> zero-padded to 8) and the `.absgrad` side channel."""
+    W, H, D = 150, 100, 7
+    xys, conics, colors, op, bg, flat, offs = _composite_case(O.MODE_GSPLAT, D, W, H, n=3000)
+    means2d = xys.to(_dev()).requires_grad_(True)
+    col = colors.to(_dev()).requires_grad_(True)
+    opd = op.to(_dev()).requires_grad_(True)
+    out, alphas = hip.rasterize_to_pixels(means2d, conics.to(_dev())[None], col[None], opd[None], W, H, 16,
+                                          torch.as_tensor(offs).to(_dev()).reshape(1, (H + 15) // 16, (W + 15) // 16),
+                                          torch.as_tensor(flat).to(_dev()), backgrounds=bg.to(_dev())[None], absgrad=True)
+    assert out.shape == (1, H, W, D) and alphas.shape == (1, H, W, 1)
+    ref, aref, _, frag = O.composite_fwd(O.MODE_GSPLAT, xys, conics, colors, op, bg, W, H, offs, flat)
+    ok = frag == 0
+    assert np.abs(out[0].detach().cpu().numpy() - ref)[ok].max() <= 1e-5
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(H, W, D, generator=g).to(_dev())
+    (out[0] * w).sum().backward()
+    assert hasattr(means2d, "absgrad") and means2d.absgrad.shape == (xys.shape[0], 2)
+    assert torch.all(means2d.absgrad >= means2d.grad.abs() - 1e-6)
+    assert col.grad.shape == (xys.shape[0], D)
+
+
+# ---------------------------------------------------------------------------------------------
+# end-to-end pipelines through the autograd wrappers
+# ---------------------------------------------------------------------------------------------
+def _e2e_scene(n=8000, W=320, H=208, deg=3, seed=21):
+    means, scales, quats, opac, shs = O.synthetic_scene(n, seed=seed, sh_degree=deg)
+    scales = scales * 4
+    cam = O.synthetic_camera(W, H, 300.0, 295.0)
+    g = torch.Generator().manual_seed(seed)
+    wimg = torch.randn(3, H, W, generator=g)
+    bg = torch.tensor([0.25, 0.5, 0.125])
+    return means, scales, quats, opac, shs, cam, wimg, bg
+
+
+def test_end_to_end_gsplat_api(hip):
+    means, scales, quats, opac, shs, cam, wimg, bg = _e2e_scene()
+    W, H = cam["width"], cam["height"]
+    leaves = [t.requires_grad_(True) for t in _cuda(means, scales, quats, opac, shs)]
+    m, s, q, o, c = leaves
+    vm, K = _cam_tensors(cam)
+    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
+    rgbs = hip.sh_view_colors(3, m, cam["camera_center"].to(_dev()), c, None, radii > 0)
+    img = hip.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, o * comp[:, None], H, W, 16, bg.to(_dev()))
+    render = img.permute(2, 0, 1)
+    (render * wimg.to(_dev())).sum().backward()
+
+    dl = [t.double().requires_grad_(True) for t in (means, scales, quats, opac, shs)]
+    r = O.render_gsplat(*dl, 3, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W, H,
+                        bg.double(), cam["camera_center"].double())
+    (r["render"] * wimg.double()).sum().backward()
+    diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
+    assert np.mean(diff <= 1e-5) > 0.999, diff.max()       # a radius/ceil or fragile flip touches a few pixels
+    assert np.array_equal((radii > 0).cpu().numpy(), r["mask"].numpy())
+    for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
+        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995)
+
+
+def test_end_to_end_inria_api(hip):
+    means, scales, quats, opac, shs, cam, wimg, bg = _e2e_scene(seed=22)
+    W, H = cam["width"], cam["height"]
+    leaves = [t.requires_grad_(True) for t in _cuda(means, scales, quats, opac, shs)]
+    m, s, q, o, c = leaves
+    settings = hip.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg.to(_dev()), scale_modifier=1.0,
+        viewmatrix=cam["world_to_camera"].to(_dev()), projmatrix=cam["full_projection"].to(_dev()), sh_degree=3,
+        campos=cam["camera_center"].to(_dev()))
+    screen = torch.zeros_like(m, requires_grad=True)
+    render, radii = hip.GaussianRasterizer(settings)(means3D=m, means2D=screen, opacities=o, shs=c, scales=s, rotations=q)
+    (render * wimg.to(_dev())).sum().backward()
+
+    dl = [t.double().requires_grad_(True) for t in (means, scales, quats, opac, shs)]
+    r = O.render_inria(*dl, 3, cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
+                       cam["tanfovx"], cam["tanfovy"], W, H, bg.double())
+    (r["render"] * wimg.double()).sum().backward()
+    diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
+    assert np.mean(diff <= 1e-5) > 0.999, diff.max()
+    assert np.mean(radii.cpu().numpy() == r["radii"].numpy()) > 0.999
+    for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
+        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995)
+    # viewspace gradient in Inria units: pixel gradient * 0.5 * (W, H)
+    ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * W, 0.5 * H])
+    assert_close_scaled(screen.grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995)
+    assert torch.all(screen.grad[:, 2] == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE size (1920x1080, 1 M Gaussians): size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties(hip):
+    N, W, H = 1_000_000, 1920, 1080
+    means, scales, quats, opac, shs = O.synthetic_scene(N, seed=42)
+    cam = O.synthetic_camera(W, H, 1600.0)
+    m, s, q, o, c = _cuda(means, scales, quats, opac, shs)
+    vm, K = _cam_tensors(cam)
+    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(m, s, 1.0, q, vm[:3], 1600.0, 1600.0, 960.0, 540.0, H, W, 16)
+    tw, th = 120, 68
+    tiles_pg, ids, flat = hip.isect_tiles(xys[None], radii[None], depths[None], 16, tw, th)
+    offs = hip.isect_offset_encode(ids, 1, tw, th)
+    I = ids.shape[0]
+    assert I == int(tiles.sum()) and 10_000_000 < I < 20_000_000          # survey measured 13.8 M
+    assert bool(torch.all(ids[1:] >= ids[:-1]))                            # sortedness
+    o_flat = offs.reshape(-1)
+    assert bool(torch.all(o_flat[1:] >= o_flat[:-1])) and int(o_flat[0]) == 0 and int(o_flat[-1]) <= I
+    # every (tile id of key) matches the offsets partition: checksum of per-tile counts
+    counts = torch.diff(torch.cat([o_flat, torch.tensor([I], device=o_flat.device, dtype=o_flat.dtype)]))
+    assert int(counts.sum()) == I
+    assert torch.equal(torch.bincount(flat, minlength=N).to(torch.int32), tiles)   # each splat appears tiles_hit times
+
+    rgbs = hip.sh_view_colors(3, m, cam["camera_center"].to(_dev()), c, None, radii > 0)
+    op = (o.reshape(-1) * comp)
+    col2 = torch.rand_like(rgbs)
+    f = lambda colors: hip.rasterize_to_pixels(xys, conics[None], colors[None], op[None], W, H, 16, offs, flat)
+    img1, a1 = f(rgbs)
+    img2, a2 = f(col2)
+    img12, a12 = f(rgbs + col2)
+    assert float(a1.min()) >= 0 and float(a1.max()) <= 1.0
+    assert torch.equal(a1, a2)                                           # alpha does not depend on colour
+    assert float((img12 - img1 - img2).abs().max()) <= 2e-5              # linear in colour (background 0)
+    # adjoint identity: <render(colors), w> == <colors, v_colors>
+    colg = rgbs.clone().requires_grad_(True)
+    img, _ = f(colg)
+    w = torch.randn_like(img)
+    (img * w).sum().backward()
+    lhs = float((img.detach().double() * w.double()).sum())
+    rhs = float((colg.grad.double() * rgbs.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    # idempotence / determinism of the forward
+    img1b, _ = f(rgbs)
+    assert torch.equal(img1, img1b)
