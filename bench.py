@@ -113,9 +113,11 @@ def cpu_baseline(workload_name, api):
     from gspl_amd import synthetic
     from oracle import gsplat_oracle as O
     wl = synthetic.WORKLOADS[workload_name]
-    cores = os.cpu_count() or 1
+    # elementwise torch ops degrade badly when oversubscribed (28 s vs ~1 s for the projection on a
+    # 256-thread host), so the baseline uses at most 32 threads and reports that number
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
     cam = synthetic.camera(wl["width"], wl["height"], wl["fx"])
     W, H = wl["width"], wl["height"]
@@ -123,6 +125,7 @@ def cpu_baseline(workload_name, api):
     m, s, q, o, c = leaves
     lib = O._lib()
     import ctypes
+    lib.oracle_set_threads(ctypes.c_int(cores))
 
     t0 = time.perf_counter()
     xys, depths, radii, conics, comp, n_tiles, _, mask, _, _ = O.project_gaussians(

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
-    float* __restrict__ out_colors, float* __restrict__ out_alphas, int32_t* __restrict__ last_ids) {
+    float* __restrict__ out_colors, float* __restrict__ out_alphas, float* __restrict__ final_Ts,
+    int32_t* __restrict__ last_ids) {
     using TR = ModeTraits<MODE>;
     __shared__ float2 s_xy[CHUNK];
     __shared__ float4 s_co[CHUNK];      // 0.5a, b, 0.5c, opacity
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
             else out_colors[pix * D + c] = v;
         }
         out_alphas[pix] = 1.f - T;
+        final_Ts[pix] = T;     // kept exactly: 1 - (1 - T) would lose the small transmittances backward divides by
         last_ids[pix] = last;
     }
 }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
-    const float* __restrict__ out_alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
     float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
     float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities) {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     tile_range(tile, n_tiles, n_isects, offsets, start, end);
 
     const int last = inside ? last_ids[pix] : start;
-    const float T_final = inside ? (1.f - out_alphas[pix]) : 1.f;
+    const float T_final = inside ? final_Ts[pix] : 1.f;
     float T = T_final;
     float v_out[D];
     float buffer[D];
@@ -290,10 +292,10 @@ template <int D, int MODE, bool CHW>
 static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
-                      float* out_colors, float* out_alphas, int32_t* last_ids, hipStream_t s) {
+                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, hipStream_t s) {
     hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW>), dim3(n_tiles), dim3(256), 0, s,
                        n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                       offsets, flatten_ids, out_colors, out_alphas, last_ids);
+                       offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids);
     return check_launch("composite_fwd");
 }
 
@@ -301,19 +303,19 @@ template <int D, int MODE, bool CHW>
 static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
-                      const float* out_alphas, const int32_t* last_ids,
+                      const float* final_Ts, const int32_t* last_ids,
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
                       hipStream_t s) {
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                           offsets, flatten_ids, out_alphas, last_ids, v_out_colors, v_out_alphas,
+                           offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
     else
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, false>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                           offsets, flatten_ids, out_alphas, last_ids, v_out_colors, v_out_alphas,
+                           offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
     return check_launch("composite_bwd");
 }
@@ -346,16 +348,16 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
                                   const float* opacities, const float* backgrounds,
                                   int width, int height, int tile_size, int tile_w, int tile_h,
                                   const int32_t* offsets, const int32_t* flatten_ids,
-                                  float* out_colors, float* out_alphas, int32_t* last_ids, void* stream) {
+                                  float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, void* stream) {
     using namespace gspl;
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_fwd: bad argument");
     if (rc != GSPL_OK) return rc;
-    if (!offsets || !out_colors || !out_alphas || !last_ids) return fail_arg("composite_fwd: NULL required pointer");
+    if (!offsets || !out_colors || !out_alphas || !final_Ts || !last_ids) return fail_arg("composite_fwd: NULL required pointer");
     if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return fail_arg("composite_fwd: NULL required pointer");
     const int n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, last_ids, s)
+#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, s)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_FWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_FWD) }
@@ -372,7 +374,7 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
                                   const float* opacities, const float* backgrounds,
                                   int width, int height, int tile_size, int tile_w, int tile_h,
                                   const int32_t* offsets, const int32_t* flatten_ids,
-                                  const float* out_alphas, const int32_t* last_ids,
+                                  const float* final_Ts, const int32_t* last_ids,
                                   const float* v_out_colors, const float* v_out_alphas,
                                   float* v_means2d, float* v_means2d_abs,
                                   float* v_conics, float* v_colors, float* v_opacities, void* stream) {
@@ -380,14 +382,14 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_bwd: bad argument");
     if (rc != GSPL_OK) return rc;
     if (n_isects == 0 || N == 0) return GSPL_OK;
-    if (!means2d || !conics || !colors || !opacities || !offsets || !flatten_ids || !out_alphas || !last_ids ||
+    if (!means2d || !conics || !colors || !opacities || !offsets || !flatten_ids || !final_Ts || !last_ids ||
         !v_out_colors || !v_means2d || !v_conics || !v_colors || !v_opacities)
         return fail_arg("composite_bwd: NULL required pointer");
     const int n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream;
     const bool absgrad = v_means2d_abs != nullptr;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWD(kD, M, C) rc = launch_bwd<kD, M, C>(absgrad, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_alphas, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, s)
+#define CALL_BWD(kD, M, C) rc = launch_bwd<kD, M, C>(absgrad, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, s)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWD) }

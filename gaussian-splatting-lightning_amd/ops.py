@@ -306,12 +306,13 @@ class _CompositeFn(torch.autograd.Function):
         shape = (height, width, D) if layout == L.GSPL_LAYOUT_HWC else (D, height, width)
         out = torch.empty(shape, dtype=torch.float32, device=dev)
         alphas = torch.empty((height, width), dtype=torch.float32, device=dev)
+        final_Ts = torch.empty((height, width), dtype=torch.float32, device=dev)
         last_ids = torch.empty((height, width), dtype=torch.int32, device=dev)
         L.call("gspl_composite_fwd", 
             N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
             width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
-            L.ptr(out), L.ptr(alphas), L.ptr(last_ids), L.stream())
-        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids)
+            L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.stream())
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids)
         ctx.cfg = (width, height, tile_size, tile_w, tile_h, bool(absgrad), mode, layout)
         ctx.means2d_ref = means2d_in      # the caller's tensor object: `.absgrad` is attached to it in backward
         return out, alphas
@@ -319,7 +320,7 @@ class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_out, v_alphas):
         lib = L.lib()
-        means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids = ctx.saved_tensors
         width, height, tile_size, tile_w, tile_h, absgrad, mode, layout = ctx.cfg
         N, D = colors.shape
         dev = means2d.device
@@ -330,11 +331,11 @@ class _CompositeFn(torch.autograd.Function):
         v_colors = torch.zeros((N, D), dtype=torch.float32, device=dev)
         v_opac = torch.zeros((N,), dtype=torch.float32, device=dev)
         if n_isects > 0 and N > 0:
-            v_out = _grad_or_zeros(v_out, alphas.shape + (D,) if layout == L.GSPL_LAYOUT_HWC else (D,) + alphas.shape, dev)
+            v_out = _grad_or_zeros(v_out, final_Ts.shape + (D,) if layout == L.GSPL_LAYOUT_HWC else (D,) + final_Ts.shape, dev)
             v_alphas = _f32c(v_alphas) if v_alphas is not None else None
             L.call("gspl_composite_bwd", 
                 N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
-                width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids), L.ptr(alphas), L.ptr(last_ids),
+                width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids), L.ptr(final_Ts), L.ptr(last_ids),
                 L.ptr(v_out), L.ptr(v_alphas), L.ptr(v_means2d), L.ptr(v_abs), L.ptr(v_conics), L.ptr(v_colors), L.ptr(v_opac),
                 L.stream())
         if absgrad:
@@ -343,7 +344,7 @@ class _CompositeFn(torch.autograd.Function):
             ctx.means2d_ref.absgrad = v_abs
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[4]:
-            T_final = 1.0 - alphas
+            T_final = final_Ts
             vo = v_out if layout == L.GSPL_LAYOUT_HWC else v_out.permute(1, 2, 0)
             v_bg = (vo * T_final[..., None]).sum(dim=(0, 1))
         return v_means2d, v_conics, v_colors, v_opac.reshape(opacities.shape), v_bg, None, None, None, None, None, None, None, None
@@ -459,13 +460,14 @@ class _InriaRasterizeFn(torch.autograd.Function):
         n_isects = flat.shape[0]
         out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         alphas = torch.empty((H, W), dtype=torch.float32, device=dev)
+        final_Ts = torch.empty((H, W), dtype=torch.float32, device=dev)
         last_ids = torch.empty((H, W), dtype=torch.int32, device=dev)
         L.call("gspl_composite_fwd", 
             N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
             L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat) if n_isects else None,
-            L.ptr(out), L.ptr(alphas), L.ptr(last_ids), L.stream())
+            L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.stream())
         ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
-                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, alphas, last_ids)
+                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids)
         ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
                    float(s.scale_modifier), colors_precomp is not None, opacities.shape)
         ctx.mark_non_differentiable(radii)
@@ -475,7 +477,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
     def backward(ctx, v_out, _v_radii):
         lib = L.lib()
         (means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
-         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, alphas, last_ids) = ctx.saved_tensors
+         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids) = ctx.saved_tensors
         H, W, tile, tile_w, tile_h, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, opac_shape = ctx.cfg
         N = means3D.shape[0]
         dev = means3D.device
@@ -488,7 +490,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
         if n_isects > 0:
             L.call("gspl_composite_bwd", 
                 N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
-                L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat), L.ptr(alphas), L.ptr(last_ids),
+                L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat), L.ptr(final_Ts), L.ptr(last_ids),
                 L.ptr(v_out), None, L.ptr(v_means2d), None, L.ptr(v_conics), L.ptr(v_colors), L.ptr(v_opac), L.stream())
         v_means = torch.empty((N, 3), dtype=torch.float32, device=dev)
         v_ndc = torch.empty((N, 3), dtype=torch.float32, device=dev)

@@ -162,14 +162,17 @@ int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids,
  *      colors [N,D], D in {1,2,3,4,8}; backgrounds [D] nullable (treated as 0)
  *      offsets [tile_h*tile_w] i32, flatten_ids [n_isects] i32
  *    Outputs: out_colors ([H,W,D] or [D,H,W] by `layout`), out_alphas [H,W] (= 1 - T_final),
- *             last_ids [H,W] i32 (index into flatten_ids of the last contributor + 1 ... see DESIGN).
+ *             final_Ts [H,W] (the final transmittance itself: backward divides by it, and
+ *             1 - (1 - T) in fp32 would lose up to 6e-4 relative at T ~ 1e-4),
+ *             last_ids [H,W] i32 (one past the index into flatten_ids of the last contributor;
+ *             the tile's range start when the pixel has none).
  * ---------------------------------------------------------------------------------------- */
 int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int layout,
                        const float* means2d, const float* conics, const float* colors,
                        const float* opacities, const float* backgrounds /*nullable*/,
                        int width, int height, int tile_size, int tile_w, int tile_h,
                        const int32_t* offsets, const int32_t* flatten_ids,
-                       float* out_colors, float* out_alphas, int32_t* last_ids,
+                       float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids,
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -185,7 +188,7 @@ int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int layout,
                        const float* opacities, const float* backgrounds /*nullable*/,
                        int width, int height, int tile_size, int tile_w, int tile_h,
                        const int32_t* offsets, const int32_t* flatten_ids,
-                       const float* out_alphas, const int32_t* last_ids,
+                       const float* final_Ts, const int32_t* last_ids,
                        const float* v_out_colors, const float* v_out_alphas /*nullable*/,
                        float* v_means2d, float* v_means2d_abs /*nullable*/,
                        float* v_conics, float* v_colors, float* v_opacities,

@@ -315,4 +315,11 @@ void oracle_composite_bwd_f32(int mode, int N, int64_t n_isects, int D,
     }
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+#endif
+
 int oracle_version(void) { return 1; }

@@ -237,19 +237,20 @@ def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
     out_ref, alpha_ref, last_ref, frag = O.composite_fwd(mode, xys, conics, colors, op, bg, W, H, offs, flat)
     c = lambda a: torch.as_tensor(a).contiguous().to(_dev())
     dxy, dcon, dcol, dop, dbg, dflat, doffs = c(xys), c(conics), c(colors), c(op), c(bg), c(flat), c(offs)
-    out, alphas, last = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat)
+    out, alphas, final_T, last = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat)
     ok = frag == 0
     assert ok.mean() > 0.995
     assert np.abs(out.cpu().numpy() - out_ref)[ok].max() <= 1e-5
     assert np.abs(alphas.cpu().numpy() - alpha_ref)[ok].max() <= 1e-5
+    assert np.abs(final_T.cpu().numpy() - (1.0 - alpha_ref))[ok].max() <= 1e-5
     assert np.array_equal(last.cpu().numpy()[ok], last_ref[ok])
 
     g = torch.Generator().manual_seed(4)
     v_out = torch.randn(H, W, D, generator=g)
     v_alpha = torch.randn(H, W, generator=g)
-    got = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, alphas, last, c(v_out), c(v_alpha), absgrad=True)
+    got = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, final_T, last, c(v_out), c(v_alpha), absgrad=True)
     # the oracle differentiates the discrete path the GPU took (its alphas / last_ids)
-    ref = O.composite_bwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, alphas.cpu().double().numpy(),
+    ref = O.composite_bwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, 1.0 - final_T.cpu().double().numpy(),
                           last.cpu().numpy(), v_out.double().numpy(), v_alpha.double().numpy(), fragile_px=frag, absgrad=True)
     keep = ref["fragile_g"] == 0
     assert keep.mean() > 0.98
@@ -263,8 +264,8 @@ def test_composite_layout_chw_equals_hwc(hip):
     xys, conics, colors, op, bg, flat, offs = _composite_case(O.MODE_INRIA, D, W, H)
     c = lambda a: torch.as_tensor(a).contiguous().to(_dev())
     args = (c(xys), c(conics), c(colors), c(op), c(bg), W, H, c(offs), c(flat))
-    o1, a1, l1 = hip_composite_fwd(O.MODE_INRIA, *args, layout=L.GSPL_LAYOUT_HWC)
-    o2, a2, l2 = hip_composite_fwd(O.MODE_INRIA, *args, layout=L.GSPL_LAYOUT_CHW)
+    o1, a1, _, l1 = hip_composite_fwd(O.MODE_INRIA, *args, layout=L.GSPL_LAYOUT_HWC)
+    o2, a2, _, l2 = hip_composite_fwd(O.MODE_INRIA, *args, layout=L.GSPL_LAYOUT_CHW)
     assert torch.equal(o1.permute(2, 0, 1), o2) and torch.equal(a1, a2) and torch.equal(l1, l2)
 
 
@@ -273,7 +274,7 @@ def test_composite_no_intersections_gives_background(hip):
     W, H = 50, 20
     offs = torch.zeros(((W + 15) // 16) * ((H + 15) // 16), dtype=torch.int32, device=d)
     bg = torch.tensor([0.1, 0.7, 0.3], device=d)
-    out, alphas, last = hip_composite_fwd(O.MODE_GSPLAT, torch.zeros(0, 2, device=d), torch.zeros(0, 3, device=d),
+    out, alphas, _, last = hip_composite_fwd(O.MODE_GSPLAT, torch.zeros(0, 2, device=d), torch.zeros(0, 3, device=d),
                                           torch.zeros(0, 3, device=d), torch.zeros(0, device=d), bg, W, H, offs,
                                           torch.zeros(0, dtype=torch.int32, device=d))
     assert torch.all(out == bg) and torch.all(alphas == 0) and torch.all(last == 0)
