@@ -253,7 +253,7 @@ def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
     ref = O.composite_bwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, 1.0 - final_T.cpu().double().numpy(),
                           last.cpu().numpy(), v_out.double().numpy(), v_alpha.double().numpy(), fragile_px=frag, absgrad=True)
     keep = ref["fragile_g"] == 0
-    assert keep.mean() > 0.98
+    assert keep.mean() > 0.9            # splats touching a fragile pixel are excused (a pixel touches many splats)
     for k in ("v_means2d", "v_means2d_abs", "v_conics", "v_colors", "v_opacities"):
         assert_close_scaled(got[k].cpu().numpy()[keep], ref[k][keep], 1e-4, f"{k} mode={mode} D={D}", frac_ok=0.9995)
 
