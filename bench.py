@@ -247,10 +247,16 @@ def main():
         I = I_gsplat
         alg_bytes = 76.0 * I + 20.0 * P
         roofline = None
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f).get(f"{args.workload}/{args.api}", {}).get("composite_bwd_kernel", {}).get("traffic_bytes")
+        except OSError:
+            pass
         if bwd_ms:
             achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes": alg_bytes, "avg_ms": round(bwd_ms, 4), "intersections": I,
                         "valu_frac_upper": round((256.0 * I * 70.0) / (bwd_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12), 5)}
         line = {
