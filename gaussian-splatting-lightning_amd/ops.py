@@ -392,18 +392,29 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     return out[None], alphas[None, ..., None]
 
 
+def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, img_width: int, block_width: int = 16,
+                  mode: int = L.GSPL_MODE_GSPLAT):
+    """Binning half of `rasterize_gaussians`, exposed so that several compositing passes over the same
+    projection (rgb + depth variants, gsplat_renderer.py:101-185) share one sort.
+    Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
+    if block_width != 16:
+        raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
+    tile_w, tile_h = (img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width
+    _, ids, flat = _isect(mode, xys, radii, depths, block_width, tile_w, tile_h)
+    return flat, isect_offset_encode(ids, 1, tile_w, tile_h).reshape(-1)
+
+
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
                         colors: Tensor, opacity: Tensor, img_height: int, img_width: int, block_width: int,
-                        background: Optional[Tensor] = None, return_alpha: bool = False, absgrad: bool = False):
+                        background: Optional[Tensor] = None, return_alpha: bool = False, absgrad: bool = False,
+                        isects=None):
     """gsplat-v0 signature (reference call: gsplat_renderer.py:86-99): bins + composites in one call.
     colors [N,D], opacity [N,1] -> [H,W,D] (and alpha [H,W] when return_alpha)."""
     if block_width != 16:
         raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
-    tile_w, tile_h = (img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width
-    _, ids, flat = _isect(L.GSPL_MODE_GSPLAT, xys, radii, depths, block_width, tile_w, tile_h)
-    offsets = isect_offset_encode(ids, 1, tile_w, tile_h)
+    flat, offsets = isects if isects is not None else bin_gaussians(xys, depths, radii, img_height, img_width, block_width)
     out, alphas = _composite(xys, conics, colors, opacity.reshape(-1), background, img_width, img_height, block_width,
-                             offsets.reshape(-1), flat, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_HWC)
+                             offsets, flat, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_HWC)
     return (out, alphas) if return_alpha else out
 
 

@@ -1,0 +1,103 @@
+"""HipVanillaRenderer — drop-in for the reference's default `VanillaRenderer`
+(internal/renderers/vanilla_renderer.py:17-213), backed by the HIP `GaussianRasterizer` of ops.py
+instead of `diff_gaussian_rasterization`.
+
+Select with   --model.renderer gspl_amd.renderers.HipVanillaRenderer   (INTEGRATION.md).
+Output contract (vanilla_renderer.py:122-129): `render` [3,H,W], `viewspace_points` (zeros [N,3] whose
+`.grad[:, :2]` receives the NDC-scaled screen-space gradient), `visibility_filter`, `radii`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw
+
+
+def _tan_half(fov):
+    return math.tan(float(fov) * 0.5)
+
+
+class HipVanillaRenderer(Renderer):
+    def __init__(self, compute_cov3D_python: bool = False, convert_SHs_python: bool = False):
+        super().__init__()
+        self.compute_cov3D_python = compute_cov3D_python
+        self.convert_SHs_python = convert_SHs_python
+
+    @staticmethod
+    def _settings(viewpoint_camera, bg_color, scaling_modifier, sh_degree):
+        W, H = camera_hw(viewpoint_camera)
+        return ops.GaussianRasterizationSettings(
+            image_height=H, image_width=W,
+            tanfovx=_tan_half(viewpoint_camera.fov_x), tanfovy=_tan_half(viewpoint_camera.fov_y),
+            bg=bg_color, scale_modifier=scaling_modifier,
+            viewmatrix=viewpoint_camera.world_to_camera, projmatrix=viewpoint_camera.full_projection,
+            sh_degree=int(sh_degree), campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+
+    def forward(self, viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+                render_types: list = None, **kwargs):
+        if render_types is None:
+            render_types = ["rgb"]
+        assert len(render_types) == 1, "Only single type is allowed currently"
+
+        rendered_image_key = "render"
+        if "depth" in render_types:
+            rendered_image_key = "depth"
+            w2c = viewpoint_camera.world_to_camera
+            depth = (torch.matmul(pc.get_xyz, w2c[:3, :3]) + w2c[3, :3])[:, 2:]
+            bg_color = torch.zeros_like(bg_color)
+            override_color = depth.repeat(1, 3)
+
+        means3D = pc.get_xyz
+        screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=bg_color.device) + 0
+        settings = self._settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree)
+        rasterizer = ops.GaussianRasterizer(raster_settings=settings)
+
+        scales = rotations = cov3D_precomp = None
+        if self.compute_cov3D_python:
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
+
+        shs = colors_precomp = None
+        if override_color is None:
+            if self.convert_SHs_python:
+                # the "python" colour path of the reference, served by the fused HIP SH kernel
+                colors_precomp = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center,
+                                                    pc.get_features, None, detach_means=False)
+            else:
+                shs = pc.get_features
+        else:
+            colors_precomp = override_color
+
+        rendered_image, radii = rasterizer(
+            means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+            opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        return {
+            rendered_image_key: rendered_image,
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii,
+        }
+
+    @staticmethod
+    def render(means3D, opacity, scales, rotations, features, active_sh_degree: int, viewpoint_camera, bg_color,
+               scaling_modifier=1.0, colors_precomp: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None):
+        """Static helper with the reference's signature (vanilla_renderer.py:131-207)."""
+        if colors_precomp is not None:
+            assert features is None
+        if cov3D_precomp is not None:
+            assert scales is None and rotations is None
+        screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=means3D.device)
+        settings = HipVanillaRenderer._settings(viewpoint_camera, bg_color, scaling_modifier, active_sh_degree)
+        rendered_image, radii = ops.GaussianRasterizer(raster_settings=settings)(
+            means3D=means3D, means2D=screenspace_points, shs=features, colors_precomp=colors_precomp,
+            opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        return {"render": rendered_image, "depth": None, "viewspace_points": screenspace_points,
+                "visibility_filter": radii > 0, "radii": radii}
+
+    def get_available_outputs(self) -> Dict:
+        return {"rgb": RendererOutputInfo("render"), "depth": RendererOutputInfo("depth", RendererOutputTypes.GRAY)}

@@ -1,0 +1,84 @@
+"""Renderer plugin base.
+
+Inside the reference repository (yzslab/gaussian-splatting-lightning on PYTHONPATH) the classes are the
+reference's own (`internal/renderers/renderer.py:43-117`), so `isinstance(renderer, Renderer)` checks in
+`internal/gaussian_splatting.py:75-77` hold.  Stand-alone (tests, bench, this container, where
+`lightning` is not installed) an interface-identical stub is used.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, Dict
+
+import torch
+
+try:  # pragma: no cover - only inside the reference repo
+    from internal.renderers.renderer import (  # type: ignore
+        Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes)
+    INSIDE_REFERENCE = True
+except Exception:  # ImportError, or lightning missing
+    INSIDE_REFERENCE = False
+
+    class RendererOutputTypes:
+        RGB: int = 1
+        GRAY: int = 2
+        NORMAL_MAP: int = 3
+        FEATURE_MAP: int = 4
+        OTHER: int = 65535
+
+    @dataclass
+    class RendererOutputInfo:
+        key: str
+        type: int = RendererOutputTypes.RGB
+        visualizer: Callable = None
+
+        def __post_init__(self):
+            if self.type == RendererOutputTypes.OTHER and self.visualizer is None:
+                raise ValueError("Visualizer must be provided when `type` is `OTHER`")
+
+    class Renderer(torch.nn.Module):
+        """Same surface as the reference's `Renderer` (renderer.py:43-111)."""
+
+        def forward(self, viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, render_types: list = None, **kwargs):
+            pass
+
+        def training_forward(self, step: int, module, viewpoint_camera, pc, bg_color: torch.Tensor, render_types: list = None, **kwargs):
+            return self(viewpoint_camera=viewpoint_camera, pc=pc, bg_color=bg_color, render_types=render_types, **kwargs)
+
+        def before_training_step(self, step: int, module):
+            return
+
+        def after_training_step(self, step: int, module):
+            return
+
+        def setup(self, stage: str, *args: Any, **kwargs: Any) -> Any:
+            pass
+
+        def training_setup(self, module):
+            return None, None
+
+        def on_load_checkpoint(self, module, checkpoint):
+            pass
+
+        def setup_web_viewer_tabs(self, viewer, server, tabs):
+            pass
+
+        def get_available_outputs(self) -> Dict[str, RendererOutputInfo]:
+            return {"rgb": RendererOutputInfo("render")}
+
+    @dataclass
+    class RendererConfig:
+        def instantiate(self, *args, **kwargs) -> Renderer:
+            raise NotImplementedError()
+
+
+def camera_hw(viewpoint_camera):
+    """(width, height) as python ints with ONE device read-back (the reference does `.item()` per field:
+    gsplat_renderer.py:61-62,71-74)."""
+    w, h = viewpoint_camera.width, viewpoint_camera.height
+    if isinstance(w, torch.Tensor):
+        if w.is_cuda:
+            w, h = torch.stack([w.reshape(()), h.reshape(())]).tolist()
+        else:
+            w, h = w.item(), h.item()
+    return int(w), int(h)

@@ -1,0 +1,48 @@
+"""Duck-typed stand-ins for the reference's Camera (internal/cameras/cameras.py:13-43) and
+VanillaGaussianModel getters (internal/models/gaussian.py:122-323) — enough surface for the renderers."""
+import math
+
+import torch
+
+
+class FakeCamera:
+    def __init__(self, cam: dict, device):
+        t = lambda v, dt=torch.float32: torch.tensor(v, dtype=dt, device=device)
+        self.world_to_camera = cam["world_to_camera"].to(device)
+        self.full_projection = cam["full_projection"].to(device)
+        self.camera_center = cam["camera_center"].to(device)
+        self.fx, self.fy, self.cx, self.cy = t(cam["fx"]), t(cam["fy"]), t(cam["cx"]), t(cam["cy"])
+        self.width, self.height = t(cam["width"], torch.int32), t(cam["height"], torch.int32)
+        self.fov_x = t(2 * math.atan(cam["tanfovx"]))
+        self.fov_y = t(2 * math.atan(cam["tanfovy"]))
+        self.idx = t(0, torch.int32)
+        self.device = device
+
+
+class FakeGaussianModel(torch.nn.Module):
+    """Stores activated values directly (like `pre_activate_all_properties`), with shs split dc/rest."""
+
+    def __init__(self, means, scales, quats, opac, shs, active_sh_degree=3):
+        super().__init__()
+        P = torch.nn.Parameter
+        self.means, self.scales_, self.rotations_, self.opacities_ = P(means), P(scales), P(quats), P(opac)
+        self.shs_dc, self.shs_rest = P(shs[:, :1].contiguous()), P(shs[:, 1:].contiguous())
+        self.active_sh_degree = active_sh_degree
+        self.max_sh_degree = int(math.isqrt(shs.shape[1])) - 1
+        self.is_pre_activated = False
+
+    # vanilla getters
+    get_xyz = property(lambda s: s.means)
+    get_scaling = property(lambda s: s.scales_)
+    get_rotation = property(lambda s: s.rotations_)
+    get_opacity = property(lambda s: s.opacities_)
+    get_features = property(lambda s: torch.cat((s.shs_dc, s.shs_rest), dim=1))
+
+    # v1-style getters
+    def get_means(self): return self.means
+    def get_scales(self): return self.scales_
+    def get_rotations(self): return self.rotations_
+    def get_opacities(self): return self.opacities_
+    def get_shs_dc(self): return self.shs_dc
+    def get_shs_rest(self): return self.shs_rest
+    def leaves(self): return [self.means, self.scales_, self.rotations_, self.opacities_, self.shs_dc, self.shs_rest]

@@ -1,0 +1,120 @@
+"""Renderer plugins (the drop-in boundary) on the GPU: output-dict contract of each
+reference renderer they replace, parity of `render` and of the parameter gradients with the oracle,
+and the consumer contract of the density controller (`viewspace_points.grad`, `.absgrad`, grad scale)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gsplat_oracle as O
+from fakes import FakeCamera, FakeGaussianModel
+from hip_helpers import assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _scene(seed=31, n=6000, W=272, H=176):
+    means, scales, quats, opac, shs = O.synthetic_scene(n, seed=seed)
+    scales = scales * 4
+    cam = O.synthetic_camera(W, H, 250.0, 247.0)
+    g = torch.Generator().manual_seed(seed)
+    wimg = torch.randn(3, H, W, generator=g)
+    bg = torch.tensor([0.1, 0.3, 0.6])
+    return (means, scales, quats, opac, shs), cam, wimg, bg
+
+
+def _oracle_grads(api, params, cam, wimg, bg):
+    W, H = cam["width"], cam["height"]
+    dl = [t.double().requires_grad_(True) for t in params]
+    if api == "inria":
+        r = O.render_inria(*dl, 3, cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
+                           cam["tanfovx"], cam["tanfovy"], W, H, bg.double())
+    else:
+        r = O.render_gsplat(*dl, 3, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W, H, bg.double(),
+                            cam["camera_center"].double())
+    (r["render"] * wimg.double()).sum().backward()
+    return r, dl
+
+
+def _check(model, dl, render, r):
+    diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
+    assert np.mean(diff <= 1e-5) > 0.999, diff.max()
+    shs_grad = torch.cat([model.shs_dc.grad, model.shs_rest.grad], dim=1)
+    for got, ref, name in zip([model.means.grad, model.scales_.grad, model.rotations_.grad, model.opacities_.grad, shs_grad], dl,
+                              ("means", "scales", "quats", "opacities", "shs")):
+        assert_close_scaled(got.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995)
+
+
+def test_hip_vanilla_renderer_contract_and_parity():
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipVanillaRenderer
+    params, cam, wimg, bg = _scene()
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    camera = FakeCamera(cam, DEV)
+    renderer = HipVanillaRenderer()
+    out = renderer(camera, model, bg.to(DEV))
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
+    N = params[0].shape[0]
+    assert out["render"].shape == (3, cam["height"], cam["width"]) and out["viewspace_points"].shape == (N, 3)
+    assert out["visibility_filter"].dtype == torch.bool and out["radii"].shape == (N,)
+    out["viewspace_points"].retain_grad()          # what VanillaDensityControllerImpl.before_backward does
+    (out["render"] * wimg.to(DEV)).sum().backward()
+    r, dl = _oracle_grads("inria", params, cam, wimg, bg)
+    _check(model, dl, out["render"], r)
+    ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * cam["width"], 0.5 * cam["height"]])
+    assert_close_scaled(out["viewspace_points"].grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace grad", 0.995)
+    # depth render type (override colour path)
+    d = renderer(camera, model, bg.to(DEV), render_types=["depth"])
+    assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].max()) > 0
+
+
+@pytest.mark.parametrize("which", ["v0", "v1"])
+def test_hip_gsplat_renderers_contract_and_parity(which):
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatRenderer, HipGSplatV1Renderer
+    params, cam, wimg, bg = _scene(seed=32)
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    camera = FakeCamera(cam, DEV)
+    renderer = HipGSplatRenderer(absgrad=True) if which == "v0" else HipGSplatV1Renderer().instantiate()
+    out = renderer(camera, model, bg.to(DEV))
+    for k in ("render", "viewspace_points", "viewspace_points_grad_scale", "visibility_filter", "radii"):
+        assert k in out
+    N, W, H = params[0].shape[0], cam["width"], cam["height"]
+    assert out["viewspace_points"].shape == (N, 2)
+    assert torch.allclose(out["viewspace_points_grad_scale"].cpu(), 0.5 * torch.tensor([[W, H]], dtype=torch.float32))
+    out["viewspace_points"].retain_grad()
+    (out["render"] * wimg.to(DEV)).sum().backward()
+    r, dl = _oracle_grads("gsplat", params, cam, wimg, bg)
+    _check(model, dl, out["render"], r)
+    vp = out["viewspace_points"]
+    assert_close_scaled(vp.grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", 0.995)
+    assert hasattr(vp, "absgrad") and torch.all(vp.absgrad >= vp.grad.abs() - 1e-6)
+
+
+def test_hip_gsplat_renderer_depth_types():
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatRenderer, HipGSplatV1Renderer
+    params, cam, wimg, bg = _scene(seed=33, n=3000)
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    camera = FakeCamera(cam, DEV)
+    H, W = cam["height"], cam["width"]
+    types = ["rgb", "alpha", "acc_depth", "acc_depth_inverted", "exp_depth", "exp_depth_inverted", "inverse_depth", "hard_depth",
+             "hard_inverse_depth"]
+    for renderer in (HipGSplatRenderer(), HipGSplatV1Renderer().instantiate()):
+        with torch.no_grad():
+            out = renderer(camera, model, bg.to(DEV), render_types=types)
+        assert out["render"].shape == (3, H, W)
+        for k in ("alpha", "acc_depth", "acc_depth_inverted", "exp_depth", "exp_depth_inverted", "inverse_depth", "hard_depth",
+                  "hard_inverse_depth"):
+            assert out[k].shape == (1, H, W), k
+            assert torch.isfinite(out[k]).all(), k
+        a = out["alpha"]
+        assert float(a.min()) >= 0 and float(a.max()) <= 1
+        covered = a[0] > 0.5
+        # expected depth = acc_depth / alpha lies inside the scene's depth range where coverage is high
+        ed = out["exp_depth"][0][covered]
+        assert float(ed.min()) > 2.0 and float(ed.max()) < 6.0
+    v1 = HipGSplatV1Renderer().instantiate()
+    with torch.no_grad():
+        o = v1(camera, model, bg.to(DEV), render_types=["rgb", "normal", "acc_depth"])       # 7 feature channels in one pass
+    assert o["normal"].shape == (3, H, W) and o["acc_depth"].shape == (1, H, W)
