@@ -36,13 +36,18 @@ def _oracle_grads(api, params, cam, wimg, bg):
     return r, dl
 
 
-def _check(model, dl, render, r):
+def _check(model, dl, render, r, quats_normalised_by_renderer=False):
     diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
     assert np.mean(diff <= 1e-5) > 0.999, diff.max()
     shs_grad = torch.cat([model.shs_dc.grad, model.shs_rest.grad], dim=1)
     for got, ref, name in zip([model.means.grad, model.scales_.grad, model.rotations_.grad, model.opacities_.grad, shs_grad], dl,
                               ("means", "scales", "quats", "opacities", "shs")):
-        assert_close_scaled(got.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995)
+        ref_g = ref.grad
+        if name == "quats" and quats_normalised_by_renderer:
+            # GSPlatRenderer divides the rotations by their norm (gsplat_renderer.py:68): the radial part vanishes
+            q = ref.detach()
+            ref_g = (ref_g - q * (q * ref_g).sum(-1, keepdim=True)) / q.norm(dim=-1, keepdim=True)
+        assert_close_scaled(got.cpu().numpy(), ref_g.numpy(), 1e-4, name, frac_ok=0.995)
 
 
 def test_hip_vanilla_renderer_contract_and_parity():
@@ -65,7 +70,7 @@ def test_hip_vanilla_renderer_contract_and_parity():
     assert_close_scaled(out["viewspace_points"].grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace grad", 0.995)
     # depth render type (override colour path)
     d = renderer(camera, model, bg.to(DEV), render_types=["depth"])
-    assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].max()) > 0
+    assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].detach().max()) > 0
 
 
 @pytest.mark.parametrize("which", ["v0", "v1"])
@@ -85,7 +90,7 @@ def test_hip_gsplat_renderers_contract_and_parity(which):
     out["viewspace_points"].retain_grad()
     (out["render"] * wimg.to(DEV)).sum().backward()
     r, dl = _oracle_grads("gsplat", params, cam, wimg, bg)
-    _check(model, dl, out["render"], r)
+    _check(model, dl, out["render"], r, quats_normalised_by_renderer=(which == "v0"))
     vp = out["viewspace_points"]
     assert_close_scaled(vp.grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", 0.995)
     assert hasattr(vp, "absgrad") and torch.all(vp.absgrad >= vp.grad.abs() - 1e-6)
