@@ -37,6 +37,20 @@ __device__ __forceinline__ float eval_sigma(float half_a, float b, float half_c,
     return fmaf(half_a * dx, dx, fmaf(half_c * dy, dy, (b * dx) * dy));
 }
 
+// Half-widths (hx, hy) of the axis-aligned box around the region where this splat can reach
+// alpha >= 1/255:  o * exp(-sigma) >= 1/255  <=>  sigma <= tau = ln(255 o), and the ellipse
+// { d : 1/2 d^T Q d <= tau } (Q = conic) has the bounding box |dx| <= sqrt(2 tau Q^-1_xx), Q^-1_xx = c / det.
+// Inflated by a small margin so that fp32 rounding of exp/log can never cull a pair the exact test would
+// keep; candidates still go through the exact per-pixel test.  (-1,-1): can never contribute.
+__device__ __forceinline__ float2 splat_extent(float a, float b, float c, float opacity) {
+    const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
+    if (!(tau > 0.f)) return make_float2(-1.f, -1.f);
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return make_float2(INFINITY, INFINITY);   // not an ellipse: never cull
+    const float k = 2.f * tau / det;
+    return make_float2(sqrtf(k * c) * 1.0002f + 1e-3f, sqrtf(k * a) * 1.0002f + 1e-3f);
+}
+
 __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isects,
                                            const int32_t* __restrict__ offsets, int& start, int& end) {
     start = offsets[tile];
@@ -54,6 +68,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     using TR = ModeTraits<MODE>;
     __shared__ float2 s_xy[CHUNK];
     __shared__ float4 s_co[CHUNK];      // 0.5a, b, 0.5c, opacity
+    __shared__ float2 s_ext[CHUNK];     // conservative half-extent of the alpha >= 1/255 region
     __shared__ float s_col[CHUNK * D];
     __shared__ int s_wdone[4];
 
@@ -63,6 +78,9 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
     const bool inside = (px < width) && (py < height);
     const float pxf = (float)px + TR::kPixelCentre, pyf = (float)py + TR::kPixelCentre;
+    // pixel-centre bounds of this wave's 8x8 quadrant (wave-uniform)
+    const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
+    const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
 
     int start, end;
     tile_range(tile, n_tiles, n_isects, offsets, start, end);
@@ -82,34 +100,49 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
         const int i = base + t;
         if (i < end) {
             const int g = flatten_ids[i];
+            const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
             s_xy[t] = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
-            s_co[t] = make_float4(0.5f * conics[g * 3 + 0], conics[g * 3 + 1], 0.5f * conics[g * 3 + 2], opacities[g]);
+            s_co[t] = make_float4(0.5f * ca, cb, 0.5f * cc, op);
+            s_ext[t] = splat_extent(ca, cb, cc, op);
 #pragma unroll
             for (int c = 0; c < D; ++c) s_col[t * D + c] = colors[(int64_t)g * D + c];
         }
         __syncthreads();
         if (!wave_done) {
             const int cnt = min(CHUNK, end - base);
-            for (int j = 0; j < cnt; ++j) {
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
-                const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float sigma = eval_sigma(co.x, co.y, co.z, dx, dy);
-                const float alpha = fminf(TR::kAlphaMax, co.w * __expf(-sigma));
-                bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
-                if (!__any(valid)) continue;
-                const float next_T = T * (1.f - alpha);
-                const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
-                done = done || stop;
-                valid = valid && !stop;
-                if (valid) {
-                    const float wgt = alpha * T;
+            // wave-level culling: each LANE tests one splat of the chunk against the quadrant's box, the
+            // ballot is the candidate list; only candidates run the per-pixel loop (4 x 64 splats per chunk)
+#pragma unroll 1
+            for (int k = 0; k < CHUNK / 64 && !wave_done; ++k) {
+                const int idx = k * 64 + l;
+                const float2 cxy = s_xy[idx];
+                const float2 ext = s_ext[idx];
+                const bool cand = (idx < cnt) && (cxy.x + ext.x >= qx0) && (cxy.x - ext.x <= qx1) &&
+                                  (cxy.y + ext.y >= qy0) && (cxy.y - ext.y <= qy1);
+                unsigned long long mask = __ballot(cand);
+                while (mask) {
+                    const int j = k * 64 + (int)__builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float2 xy = s_xy[j];
+                    const float4 co = s_co[j];
+                    const float dx = xy.x - pxf, dy = xy.y - pyf;
+                    const float sigma = eval_sigma(co.x, co.y, co.z, dx, dy);
+                    const float alpha = fminf(TR::kAlphaMax, co.w * __expf(-sigma));
+                    bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
+                    if (!__any(valid)) continue;
+                    const float next_T = T * (1.f - alpha);
+                    const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
+                    done = done || stop;
+                    valid = valid && !stop;
+                    if (valid) {
+                        const float wgt = alpha * T;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) acc[c] += s_col[j * D + c] * wgt;
-                    T = next_T;
-                    last = base + j + 1;
+                        for (int c = 0; c < D; ++c) acc[c] += s_col[j * D + c] * wgt;
+                        T = next_T;
+                        last = base + j + 1;
+                    }
+                    if (__all(done)) { wave_done = true; break; }
                 }
-                if (__all(done)) break;
             }
             wave_done = __all(done);
         }
@@ -130,6 +163,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
 }
 
+static_assert(true, "");
 // number of per-splat gradient values reduced per (wave, splat): xy(2) conic(3) opacity(1) colour(D) [+abs xy(2)]
 template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (ABS ? 2 : 0); };
 
@@ -148,6 +182,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     __shared__ int s_id[CHUNK];
     __shared__ float2 s_xy[CHUNK];
     __shared__ float4 s_co[CHUNK];       // a, b, c, opacity (unscaled: needed for the gradients)
+    __shared__ float2 s_ext[CHUNK];
     __shared__ float s_col[CHUNK * D];
     __shared__ float s_acc[CHUNK * NV];
     __shared__ int s_last;
@@ -158,7 +193,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
     const bool inside = (px < width) && (py < height);
     const float pxf = (float)px + TR::kPixelCentre, pyf = (float)py + TR::kPixelCentre;
+    const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
+    const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
     const int64_t pix = (int64_t)py * width + px;
+    const int row_pos = l & 15;          // position inside the 16-lane DPP row
 
     int start, end;
     tile_range(tile, n_tiles, n_isects, offsets, start, end);
@@ -199,16 +237,28 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         if (t < cnt) {
             const int g = flatten_ids[hi - 1 - t];
             s_id[t] = g;
+            const float4 co = make_float4(conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
             s_xy[t] = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
-            s_co[t] = make_float4(conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
+            s_co[t] = co;
+            s_ext[t] = splat_extent(co.x, co.y, co.z, co.w);
 #pragma unroll
             for (int c = 0; c < D; ++c) s_col[t * D + c] = colors[(int64_t)g * D + c];
         }
         __syncthreads();
         if (wave_last > lo) {
-            for (int j = 0; j < cnt; ++j) {
+#pragma unroll 1
+            for (int kk = 0; kk < CHUNK / 64; ++kk) {
+              const int slot = kk * 64 + l;
+              const float2 cxy = s_xy[slot];
+              const float2 ext = s_ext[slot];
+              // candidate: staged, reached by some pixel of this quadrant, and its alpha >= 1/255 box touches the quadrant
+              const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && (cxy.x + ext.x >= qx0) && (cxy.x - ext.x <= qx1) &&
+                                (cxy.y + ext.y >= qy0) && (cxy.y - ext.y <= qy1);
+              unsigned long long mask = __ballot(cand);
+              while (mask) {
+                const int j = kk * 64 + (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
                 const int idx = hi - 1 - j;
-                if (idx >= wave_last) continue;          // wave-uniform: nobody in this quadrant got that far
                 const float2 xy = s_xy[j];
                 const float4 co = s_co[j];
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
@@ -249,12 +299,16 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
                         }
                     }
                 }
+                // reduce each value over the 16 lanes of its DPP row (4 fused v_add_f32_dpp), then let lane p of
+                // every row add value p into the tile accumulator: ONE ds_add_f32 with 4*NV active lanes
+                // (per-lane addresses, so the compiler's uniform-address atomic expansion does not kick in)
 #pragma unroll
-                for (int k = 0; k < NV; ++k) vals[k] = wave_sum_to_lane63(vals[k]);
-                if (l == 63) {
+                for (int k = 0; k < NV; ++k) vals[k] = row_sum(vals[k]);
+                float mine = vals[0];
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[j * NV + k], vals[k]);
-                }
+                for (int k = 1; k < NV; ++k) mine = (row_pos == k) ? vals[k] : mine;
+                if (row_pos < NV) atomicAdd(&s_acc[j * NV + row_pos], mine);
+              }
             }
         }
         __syncthreads();

@@ -194,6 +194,14 @@ __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
     return v + __int_as_float(moved);
 }
+// Sum over the 16 lanes of each DPP row; every lane ends up holding its row's sum.
+__device__ __forceinline__ float row_sum(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);   // row_mirror
+    return v;
+}
 // Sum over the 64 lanes of the wave; the total is valid in lane 63 (row 3).
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
