@@ -400,8 +400,31 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, i
     if block_width != 16:
         raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
     tile_w, tile_h = (img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width
-    _, ids, flat = _isect(mode, xys, radii, depths, block_width, tile_w, tile_h)
-    return flat, isect_offset_encode(ids, 1, tile_w, tile_h).reshape(-1)
+    lib = L.lib()
+    means2d, depths = _f32c(xys.detach()), _f32c(depths.detach())
+    radii = radii.to(torch.int32).contiguous()
+    N = means2d.shape[0]
+    dev = means2d.device
+    offsets = torch.empty((tile_w * tile_h,), dtype=torch.int32, device=dev)
+    n_isects = 0
+    order = cum = None
+    if N > 0:
+        order = torch.empty((N,), dtype=torch.int32, device=dev)
+        cum = torch.empty((N,), dtype=torch.int64, device=dev)
+        ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
+        if ws_bytes == 0:
+            raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        L.call("gspl_bin_count", N, mode, L.ptr(means2d), L.ptr(radii), L.ptr(depths), block_width, tile_w, tile_h,
+               L.ptr(order), L.ptr(cum), L.ptr(ws), ws_bytes, L.stream())
+        n_isects = int(cum[-1].item())      # the one host read-back of the pipeline (sizes the sort buffers)
+    flat = torch.empty((n_isects,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.gspl_bin_workspace_bytes(max(N, 1), n_isects) if n_isects > 0 else 0
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+    L.call("gspl_bin_emit_sort", N, mode, L.ptr(means2d) if N else None, L.ptr(radii) if N else None,
+           L.ptr(order), L.ptr(cum), block_width, tile_w, tile_h, n_isects,
+           L.ptr(flat) if n_isects else None, L.ptr(offsets), L.ptr(ws), ws_bytes, L.stream())
+    return flat, offsets
 
 
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
@@ -466,8 +489,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                 float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
                 L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
                 L.stream())
-        _, ids, flat = _isect(L.GSPL_MODE_INRIA, means2d, radii, depths, tile, tile_w, tile_h)
-        offsets = isect_offset_encode(ids, 1, tile_w, tile_h).reshape(-1)
+        flat, offsets = bin_gaussians(means2d, depths, radii, H, W, tile, mode=L.GSPL_MODE_INRIA)
         n_isects = flat.shape[0]
         out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         alphas = torch.empty((H, W), dtype=torch.float32, device=dev)

@@ -153,6 +153,27 @@ int gspl_isect_emit_sort(int N, int mode,
 int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids,
                        int tile_w, int tile_h, int32_t* offsets, void* stream);
 
+/*    3b. The same binning for callers that only need the per-tile lists (flatten_ids + offsets), not
+ *    the 64-bit keys: the fused Inria rasterizer (vanilla_renderer.py:111-120) and gsplat-v0
+ *    `rasterize_gaussians` (gsplat_renderer.py:86-99) never see isect_ids.  Two-level, "depth first":
+ *    sort the N splats by depth (32-bit keys), emit tile hits in that order, stable-sort by tile id
+ *    only.  Produces exactly the flatten_ids / offsets of steps a-c above at a third of the traffic.
+ *      order [N] i32 (splat ids by depth, tile-less splats last), cum_tiles [N] i64 (inclusive prefix
+ *      sum of tile counts in that order; host reads cum_tiles[N-1]).
+ * ---------------------------------------------------------------------------------------- */
+size_t gspl_bin_workspace_bytes(int N, int64_t n_isects);
+int gspl_bin_count(int N, int mode,
+                   const float* means2d, const int32_t* radii, const float* depths,
+                   int tile_size, int tile_w, int tile_h,
+                   int32_t* order, int64_t* cum_tiles,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int gspl_bin_emit_sort(int N, int mode,
+                       const float* means2d, const int32_t* radii,
+                       const int32_t* order, const int64_t* cum_tiles,
+                       int tile_size, int tile_w, int tile_h, int64_t n_isects,
+                       int32_t* flatten_ids, int32_t* offsets,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 4. Tile compositing, forward.
  *    Replaces gsplat `rasterize_to_pixels` (gsplat_v1_renderer.py:588-601), v0

@@ -197,6 +197,27 @@ def test_binning_bit_exact(hip, mode, wh):
     assert np.array_equal(ids.cpu().numpy(), ids_ref)
     assert np.array_equal(flat.cpu().numpy(), flat_ref)          # stable: ties keep Gaussian order
     assert np.array_equal(offs.reshape(-1).cpu().numpy(), offs_ref)
+    # the two-level "depth first" path used by the fused rasterizers must give the very same lists
+    flat2, offs2 = hip.bin_gaussians(xys.to(_dev()), depths.to(_dev()), radii.to(_dev()), H, W, 16, mode=mode)
+    assert np.array_equal(flat2.cpu().numpy(), flat_ref)
+    assert np.array_equal(offs2.cpu().numpy(), offs_ref)
+
+
+def test_binning_two_level_ties_and_empty(hip):
+    """Equal depths (ties must stay in Gaussian-id order), all-culled and N == 0 inputs."""
+    d = _dev()
+    n, W, H = 3000, 200, 120
+    g = torch.Generator().manual_seed(2)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([W, H])
+    radii = torch.randint(0, 30, (n,), generator=g, dtype=torch.int32)
+    depths = torch.randint(1, 6, (n,), generator=g).float()          # only 5 distinct depths
+    _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, xy, radii, depths, W, H)
+    flat, offs = hip.bin_gaussians(xy.to(d), depths.to(d), radii.to(d), H, W, 16)
+    assert np.array_equal(flat.cpu().numpy(), flat_ref) and np.array_equal(offs.cpu().numpy(), offs_ref)
+    flat, offs = hip.bin_gaussians(xy.to(d), depths.to(d), torch.zeros_like(radii).to(d), H, W, 16)
+    assert flat.numel() == 0 and int(offs.abs().sum()) == 0
+    flat, offs = hip.bin_gaussians(torch.zeros(0, 2, device=d), torch.zeros(0, device=d), torch.zeros(0, dtype=torch.int32, device=d), H, W, 16)
+    assert flat.numel() == 0 and offs.numel() == ((W + 15) // 16) * ((H + 15) // 16) and int(offs.abs().sum()) == 0
 
 
 def test_binning_empty_inputs(hip):
