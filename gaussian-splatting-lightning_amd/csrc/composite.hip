@@ -163,10 +163,32 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     }
 }
 
-static_assert(true, "");
-// number of per-splat gradient values reduced per (wave, splat): xy(2) conic(3) opacity(1) colour(D) [+abs xy(2)]
+// number of per-splat gradient values accumulated per (tile, splat): xy(2) conic(3) opacity(1) colour(D) [+abs xy(2)]
 template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (ABS ? 2 : 0); };
 
+static constexpr int BATCH = 8;         // splats per phase-2 batch (one per 8-lane group)
+static constexpr int PAIR_STRIDE = 72;  // float2 per batch slot: 64 lanes + pad -> conflict-free ds_read_b64 in phase 2
+
+// Sum over each aligned group of 8 lanes (three fused v_add_f32_dpp); every lane of the group gets the sum.
+__device__ __forceinline__ float group8_sum(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    return v;
+}
+
+// Backward, two phases per wave (no extra workgroup barriers):
+//   phase 1 (lane = pixel of the 8x8 quadrant): walk the candidate splats back-to-front, rebuild alpha and
+//            T, and emit just TWO numbers per (pixel, splat): fac = alpha*T (colour weight) and
+//            sp = dL/dsigma; they go to a wave-private LDS slab [slot][lane].
+//   phase 2 (lane = (splat slot s, pixel column q), after 8 active splats): each lane walks the 8 pixels of
+//            its column for ITS splat and accumulates the 9..16 gradient moments with plain FMAs (dx is
+//            constant down a column, so only sum(sp), sum(sp*dy), sum(sp*dy^2) and the colour sums are
+//            per-pixel work); a 3-step DPP reduction over the 8 columns finishes the quadrant.
+//   The per-(tile, splat) totals of the four waves meet in LDS (one ds_add_f32 per lane) and leave as ONE
+//   fp32 L2 atomic per value per (tile, splat).
+// VALU work per (pixel, splat) pair drops to ~33 (phase 1) + ~9 (phase 2) instructions, against ~110 for a
+// per-splat 64-lane reduction of every gradient component.
 template <int D, int MODE, bool CHW, bool ABS>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
@@ -181,10 +203,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     constexpr int NV = BwdVals<D, ABS>::N;
     __shared__ int s_id[CHUNK];
     __shared__ float2 s_xy[CHUNK];
-    __shared__ float4 s_co[CHUNK];       // a, b, c, opacity (unscaled: needed for the gradients)
+    __shared__ float4 s_co[CHUNK];       // a, b, c, opacity
     __shared__ float2 s_ext[CHUNK];
     __shared__ float s_col[CHUNK * D];
     __shared__ float s_acc[CHUNK * NV];
+    __shared__ float2 s_pair[4 * BATCH * PAIR_STRIDE];
+    __shared__ float s_vo[4 * 64 * D];
     __shared__ int s_last;
 
     const int tile = xcd_remap(blockIdx.x, n_tiles);
@@ -196,7 +220,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
     const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
     const int64_t pix = (int64_t)py * width + px;
-    const int row_pos = l & 15;          // position inside the 16-lane DPP row
+    const int ps = l >> 3, pq = l & 7;   // phase-2 role: splat slot, pixel column
+    float2* pair_w = s_pair + w * BATCH * PAIR_STRIDE;
 
     int start, end;
     tile_range(tile, n_tiles, n_isects, offsets, start, end);
@@ -213,6 +238,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         v_out[c] = 0.f;
         if (inside) v_out[c] = CHW ? v_out_colors[(int64_t)c * width * height + pix] : v_out_colors[pix * D + c];
         if (backgrounds) bgdot += backgrounds[c] * v_out[c];
+        s_vo[(w * 64 + l) * D + c] = v_out[c];
     }
     const float v_out_a = (inside && v_out_alphas) ? v_out_alphas[pix] : 0.f;
     // d(out)/d(alpha_i) carries  T_final/(1-alpha_i) * (v_out_alpha - bg . v_out)
@@ -221,6 +247,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     if (t == 0) s_last = start;
     for (int k = t; k < CHUNK * NV; k += 256) s_acc[k] = 0.f;
     __syncthreads();
+    // phase-2 view of dL/d(out): the 8 pixels of column pq (rows 0..7 of this wave's quadrant)
+    float vo2[8][D];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < D; ++c) vo2[i][c] = s_vo[(w * 64 + i * 8 + pq) * D + c];
     // wave-max of `last`, then one LDS atomic per wave
     int wl = last;
 #pragma unroll
@@ -229,6 +261,74 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     __syncthreads();
     const int block_last = s_last;
     const int wave_last = wl;
+
+    int nb = 0;          // splats waiting in the phase-2 batch (wave-uniform)
+    int batch_j = 0;     // lane b holds the staged slot index j of batch entry b
+
+    auto phase2 = [&](int count) {
+        float vals[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vals[k] = 0.f;
+        const int j = __builtin_amdgcn_ds_bpermute(ps << 2, batch_j);
+        const bool live = ps < count;
+        float4 co = make_float4(0.f, 0.f, 0.f, 1.f);
+        if (live) {
+            const float2 xy = s_xy[j];
+            co = s_co[j];
+            const float dx = xy.x - (qx0 + (float)pq);
+            const float dy0 = xy.y - qy0;
+            float S0 = 0.f, Sy = 0.f, Syy = 0.f, ax = 0.f, ay = 0.f;
+            float rgb[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) rgb[c] = 0.f;
+            const float2* col = pair_w + ps * PAIR_STRIDE + pq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float2 fs = col[i * 8];                 // (fac, sp) of pixel (column pq, row i)
+                const float dy = dy0 - (float)i;
+#pragma unroll
+                for (int c = 0; c < D; ++c) rgb[c] = fmaf(fs.x, vo2[i][c], rgb[c]);
+                S0 += fs.y;
+                const float tq = fs.y * dy;
+                Sy += tq;
+                Syy = fmaf(tq, dy, Syy);
+                if constexpr (ABS) {
+                    ax += fabsf(fs.y * (co.x * dx + co.y * dy));
+                    ay += fabsf(fs.y * (co.y * dx + co.z * dy));
+                }
+            }
+            const float Sx = S0 * dx;
+            vals[0] = Sx;            // -> sum sp*dx
+            vals[1] = Sy;            // -> sum sp*dy
+            vals[2] = Sx * dx;       // -> sum sp*dx^2
+            vals[3] = Sy * dx;       // -> sum sp*dx*dy
+            vals[4] = Syy;           // -> sum sp*dy^2
+            vals[5] = S0;            // -> sum sp
+#pragma unroll
+            for (int c = 0; c < D; ++c) vals[6 + c] = rgb[c];
+            if constexpr (ABS) { vals[6 + D] = ax; vals[7 + D] = ay; }
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vals[k] = group8_sum(vals[k]);
+        // moments -> gradients (every lane of the group holds the group totals)
+        const float Sx = vals[0], Sy = vals[1];
+        vals[0] = co.x * Sx + co.y * Sy;                     // dL/dx
+        vals[1] = co.y * Sx + co.z * Sy;                     // dL/dy
+        vals[2] = 0.5f * vals[2];                            // dL/da
+        vals[4] = 0.5f * vals[4];                            // dL/dc      (vals[3] = dL/db as is)
+        vals[5] = (co.w != 0.f) ? -vals[5] / co.w : 0.f;     // dL/dopacity = sum(vis * v_alpha) = -sum(sp) / o
+        // lane q of the group adds value q (and q+8): two ds_add_f32 per batch, per-lane addresses
+        float mine = vals[0];
+#pragma unroll
+        for (int k = 1; k < 8 && k < NV; ++k) mine = (pq == k) ? vals[k] : mine;
+        if (live && pq < NV) atomicAdd(&s_acc[j * NV + pq], mine);
+        if constexpr (NV > 8) {
+            float mine2 = vals[8];
+#pragma unroll
+            for (int k = 9; k < NV; ++k) mine2 = (pq == k - 8) ? vals[k] : mine2;
+            if (live && pq + 8 < NV) atomicAdd(&s_acc[j * NV + 8 + pq], mine2);
+        }
+    };
 
     for (int hi = block_last; hi > start; hi -= CHUNK) {
         const int lo = max(start, hi - CHUNK);
@@ -248,68 +348,45 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         if (wave_last > lo) {
 #pragma unroll 1
             for (int kk = 0; kk < CHUNK / 64; ++kk) {
-              const int slot = kk * 64 + l;
-              const float2 cxy = s_xy[slot];
-              const float2 ext = s_ext[slot];
-              // candidate: staged, reached by some pixel of this quadrant, and its alpha >= 1/255 box touches the quadrant
-              const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && (cxy.x + ext.x >= qx0) && (cxy.x - ext.x <= qx1) &&
-                                (cxy.y + ext.y >= qy0) && (cxy.y - ext.y <= qy1);
-              unsigned long long mask = __ballot(cand);
-              while (mask) {
-                const int j = kk * 64 + (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int idx = hi - 1 - j;
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
-                const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float sigma = eval_sigma(0.5f * co.x, co.y, 0.5f * co.z, dx, dy);
-                const float vis = __expf(-sigma);
-                const float alpha = fminf(TR::kAlphaMax, co.w * vis);
-                const bool valid = (idx < last) && (sigma >= 0.f) && (alpha >= kAlphaMin);
-                if (!__any(valid)) continue;
-
-                float vals[NV];
+                const int slot = kk * 64 + l;
+                const float2 cxy = s_xy[slot];
+                const float2 ext = s_ext[slot];
+                // candidate: staged, reached by some pixel of this quadrant, and its alpha >= 1/255 box touches the quadrant
+                const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && (cxy.x + ext.x >= qx0) && (cxy.x - ext.x <= qx1) &&
+                                  (cxy.y + ext.y >= qy0) && (cxy.y - ext.y <= qy1);
+                unsigned long long mask = __ballot(cand);
+                while (mask) {
+                    const int j = kk * 64 + (int)__builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int idx = hi - 1 - j;
+                    const float2 xy = s_xy[j];
+                    const float4 co = s_co[j];
+                    const float dx = xy.x - pxf, dy = xy.y - pyf;
+                    const float sigma = eval_sigma(0.5f * co.x, co.y, 0.5f * co.z, dx, dy);
+                    const float vis = __expf(-sigma);
+                    const float alpha = fminf(TR::kAlphaMax, co.w * vis);
+                    const bool valid = (idx < last) && (sigma >= 0.f) && (alpha >= kAlphaMin);
+                    if (!__any(valid)) continue;
+                    float fac = 0.f, sp = 0.f;
+                    if (valid) {
+                        const float ra = 1.f / (1.f - alpha);
+                        T *= ra;                               // transmittance in front of this splat
+                        fac = alpha * T;
+                        float v_alpha = tail * ra;
 #pragma unroll
-                for (int k = 0; k < NV; ++k) vals[k] = 0.f;
-                if (valid) {
-                    const float ra = 1.f / (1.f - alpha);
-                    T *= ra;                               // transmittance in front of this splat
-                    const float fac = alpha * T;
-                    float v_alpha = tail * ra;
-#pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        const float col = s_col[j * D + c];
-                        vals[6 + c] = fac * v_out[c];
-                        v_alpha += (col * T - buffer[c] * ra) * v_out[c];
-                        buffer[c] += col * fac;
-                    }
-                    if (!TR::kClampKillsGrad || (co.w * vis <= TR::kAlphaMax)) {
-                        const float v_sigma = -co.w * vis * v_alpha;
-                        const float gx = v_sigma * (co.x * dx + co.y * dy);
-                        const float gy = v_sigma * (co.y * dx + co.z * dy);
-                        vals[0] = gx;
-                        vals[1] = gy;
-                        vals[2] = 0.5f * v_sigma * dx * dx;
-                        vals[3] = v_sigma * dx * dy;
-                        vals[4] = 0.5f * v_sigma * dy * dy;
-                        vals[5] = vis * v_alpha;
-                        if constexpr (ABS) {
-                            vals[6 + D] = fabsf(gx);
-                            vals[7 + D] = fabsf(gy);
+                        for (int c = 0; c < D; ++c) {
+                            const float col = s_col[j * D + c];
+                            v_alpha += (col * T - buffer[c] * ra) * v_out[c];
+                            buffer[c] += col * fac;
                         }
+                        if (!TR::kClampKillsGrad || (co.w * vis <= TR::kAlphaMax)) sp = -co.w * vis * v_alpha;
                     }
+                    pair_w[nb * PAIR_STRIDE + l] = make_float2(fac, sp);
+                    batch_j = (l == nb) ? j : batch_j;
+                    if (++nb == BATCH) { phase2(BATCH); nb = 0; }
                 }
-                // reduce each value over the 16 lanes of its DPP row (4 fused v_add_f32_dpp), then let lane p of
-                // every row add value p into the tile accumulator: ONE ds_add_f32 with 4*NV active lanes
-                // (per-lane addresses, so the compiler's uniform-address atomic expansion does not kick in)
-#pragma unroll
-                for (int k = 0; k < NV; ++k) vals[k] = row_sum(vals[k]);
-                float mine = vals[0];
-#pragma unroll
-                for (int k = 1; k < NV; ++k) mine = (row_pos == k) ? vals[k] : mine;
-                if (row_pos < NV) atomicAdd(&s_acc[j * NV + row_pos], mine);
-              }
             }
+            if (nb) { phase2(nb); nb = 0; }
         }
         __syncthreads();
         // flush: one lane per splat of the chunk, one L2 atomic per non-zero value
