@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
 // number of per-splat gradient values accumulated per (tile, splat): xy(2) conic(3) opacity(1) colour(D) [+abs xy(2)]
 template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (ABS ? 2 : 0); };
 
+static constexpr int BCHUNK = 128;     // splats staged per round in the backward kernel (LDS footprint -> occupancy)
 static constexpr int BATCH = 8;         // splats per phase-2 batch (one per 8-lane group)
 static constexpr int PAIR_STRIDE = 72;  // float2 per batch slot: 64 lanes + pad -> conflict-free ds_read_b64 in phase 2
 
@@ -201,14 +202,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
-    __shared__ int s_id[CHUNK];
-    __shared__ float2 s_xy[CHUNK];
-    __shared__ float4 s_co[CHUNK];       // a, b, c, opacity
-    __shared__ float2 s_ext[CHUNK];
-    __shared__ float s_col[CHUNK * D];
-    __shared__ float s_acc[CHUNK * NV];
+    __shared__ int s_id[BCHUNK];
+    __shared__ float2 s_xy[BCHUNK];
+    __shared__ float4 s_co[BCHUNK];       // a, b, c, opacity
+    __shared__ float2 s_ext[BCHUNK];
+    __shared__ float s_col[BCHUNK * D];
+    __shared__ float s_acc[BCHUNK * NV];
     __shared__ float2 s_pair[4 * BATCH * PAIR_STRIDE];
-    __shared__ float s_vo[4 * 64 * D];
+    float* s_vo = reinterpret_cast<float*>(s_pair);      // only used before the main loop (4*64*D floats <= slab size)
+    static_assert(4 * 64 * D <= 2 * 4 * BATCH * PAIR_STRIDE, "s_vo alias too small");
     __shared__ int s_last;
 
     const int tile = xcd_remap(blockIdx.x, n_tiles);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float tail = T_final * (v_out_a - bgdot);
 
     if (t == 0) s_last = start;
-    for (int k = t; k < CHUNK * NV; k += 256) s_acc[k] = 0.f;
+    for (int k = t; k < BCHUNK * NV; k += 256) s_acc[k] = 0.f;
     __syncthreads();
     // phase-2 view of dL/d(out): the 8 pixels of column pq (rows 0..7 of this wave's quadrant)
     float vo2[8][D];
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         }
     };
 
-    for (int hi = block_last; hi > start; hi -= CHUNK) {
-        const int lo = max(start, hi - CHUNK);
+    for (int hi = block_last; hi > start; hi -= BCHUNK) {
+        const int lo = max(start, hi - BCHUNK);
         const int cnt = hi - lo;
         // stage [lo, hi) in reverse: slot j holds index hi-1-j
         if (t < cnt) {
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         __syncthreads();
         if (wave_last > lo) {
 #pragma unroll 1
-            for (int kk = 0; kk < CHUNK / 64; ++kk) {
+            for (int kk = 0; kk < BCHUNK / 64; ++kk) {
                 const int slot = kk * 64 + l;
                 const float2 cxy = s_xy[slot];
                 const float2 ext = s_ext[slot];
