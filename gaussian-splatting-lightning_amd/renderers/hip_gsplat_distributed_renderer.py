@@ -1,0 +1,190 @@
+"""HipGSplatDistributedRenderer — the reference's Gaussian-sharded multi-GPU renderer
+(internal/renderers/gsplat_distributed_renderer.py:16-516, `configs/distributed.yaml`) on the HIP ops.
+
+Per step, on each of W ranks (one process per GPU, MPStrategy = RCCL on ROCm):
+  1. all_gather the W camera ids                                   (reference :319-323)
+  2. project THIS rank's shard for all W cameras in ONE batched launch (`fully_fused_projection`, C = W) and
+     evaluate SH colours per camera for the visible splats           (reference :252-311)
+  3. ONE packed 48-B-record all-to-all (`distributed.exchange_visible_splats`; the reference sends a float and
+     an int message, :195-202), autograd-aware: backward is the reverse all-to-all
+  4. bin + composite the received splats for the local camera        (reference :356-389)
+Outputs follow the reference (:407-414): `render`, `cameras`, `projection_results_list`, `visible_mask_list`,
+`xys_grad_scale_required` — what `DistributedVanillaDensityControllerImpl` consumes.
+Random redistribution (:432-510) uses one all_to_all_single per tensor (`distributed.redistribute_rows`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import distributed as D
+from .. import ops
+from .hip_gsplat_v1_renderer import GSplatV1
+from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw
+
+
+@dataclass
+class HipGSplatDistributedRenderer(RendererConfig):
+    block_size: int = 16
+    anti_aliased: bool = True
+    filter_2d_kernel_size: float = 0.3
+    tile_based_culling: bool = False
+    redistribute_interval: int = 1000
+    redistribute_until: int = 15_000
+    redistribute_threshold: float = 1.1
+
+    def instantiate(self, *args, **kwargs) -> Renderer:
+        if self.tile_based_culling:
+            raise NotImplementedError("tile_based_culling is not built yet")
+        return HipGSplatDistributedRendererImpl(self)
+
+
+class HipGSplatDistributedRendererImpl(Renderer):
+    def __init__(self, config: HipGSplatDistributedRenderer) -> None:
+        super().__init__()
+        self.config = config
+        self.world_size = 1
+        self.global_rank = 0
+        self.camera_lookup: Optional[Callable[[int, bool], object]] = None   # (camera idx, training) -> Camera
+        self.on_density_changed = lambda: None
+
+    # ---- setup: shard the Gaussians (reference :63-118) -------------------------------------------------
+    def training_setup(self, module):
+        self.world_size = module.trainer.world_size
+        self.global_rank = module.trainer.global_rank
+        lo, hi = D.shard_bounds(module.gaussian_model.n_gaussians, self.world_size, self.global_rank)
+        from internal.density_controllers.density_controller import Utils as DensityControllerUtils  # reference helper
+        new_tensors = {k: v[lo:hi] for k, v in module.gaussian_model.properties.items()}
+        module.gaussian_model.properties = DensityControllerUtils.replace_tensors_to_properties(new_tensors, module.gaussian_optimizers)
+        self.on_density_changed = module.density_updated_by_renderer
+        self.on_density_changed()
+
+        def lookup(idx: int, training: bool):
+            loader = module.trainer.train_dataloader if training else module.trainer.val_dataloaders
+            return loader.dataset.image_cameras[idx]
+
+        self.camera_lookup = lookup
+        return None, None
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def gather_cameras(self, viewpoint_camera):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if world == 1:
+            return [viewpoint_camera]
+        ids = torch.empty(world, dtype=torch.int, device=viewpoint_camera.device)
+        dist.all_gather_into_tensor(ids, viewpoint_camera.idx.to(torch.int).reshape(1))
+        cams = []
+        for i in ids.tolist():
+            cam = self.camera_lookup(int(i), self.training)
+            if cam.device != viewpoint_camera.device:
+                cam.to_device(viewpoint_camera.device)
+            cams.append(cam)
+        return cams
+
+    def batch_project(self, cameras, pc, scales, scaling_modifier):
+        """One launch for all W cameras (the kernel is per (camera, splat); reference :252-283)."""
+        viewmats = torch.stack([c.world_to_camera.T for c in cameras])
+        Ks = torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, scales.device) for c in cameras])
+        W, H = camera_hw(cameras[0])
+        if scaling_modifier != 1.:
+            scales = scales * scaling_modifier
+        radii, means2d, depths, conics, comps = ops.fully_fused_projection(
+            pc.get_means(), None, pc.get_rotations(), scales, viewmats=viewmats, Ks=Ks, width=W, height=H,
+            eps2d=self.config.filter_2d_kernel_size, calc_compensations=True, packed=False)
+        results, rgbs = [], []
+        for i, cam in enumerate(cameras):
+            vis = radii[i] > 0
+            results.append((radii[i], means2d[i], depths[i], conics[i], comps[i], vis))
+            rgbs.append(self.get_rgbs(pc, cam, vis))
+        return results, rgbs
+
+    def get_rgbs(self, pc, camera, visibility):
+        return ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, camera.camera_center, pc.get_shs_dc(), pc.get_shs_rest(), visibility)
+
+    def forward(self, viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, render_types: list = None, **kwargs):
+        if render_types is None:
+            render_types = ["rgb"]
+        cameras = self.gather_cameras(viewpoint_camera)
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        scales, opacities = pc.get_scales(), pc.get_opacities()
+        projection_results_list, rgb_list = self.batch_project(cameras, pc, scales, scaling_modifier)
+        for r in projection_results_list:
+            if r[1].requires_grad:
+                r[1].retain_grad()              # per-camera xys: what the distributed density controller reads
+
+        records = [D.pack_visible(r[0], r[1], r[2], r[3], r[4], opacities, rgb, r[5]) for r, rgb in zip(projection_results_list, rgb_list)]
+        if len(cameras) > 1:
+            received, _ = D.exchange_visible_splats(records)
+        else:
+            received = records[0]
+        radii, means2d, depths, conics, comps, opac, rgbs = D.unpack_records(received)
+        if self.config.anti_aliased:
+            opac = opac * comps.unsqueeze(-1)
+        opac = opac.squeeze(-1).unsqueeze(0)
+
+        local = cameras[rank]
+        W, H = camera_hw(local)
+        pre = (None, None, (W, H))
+        projections = (radii.unsqueeze(0), means2d, depths.unsqueeze(0), conics.unsqueeze(0), None)
+        isects = GSplatV1.isect_encode(pre, (projections[0], means2d.unsqueeze(0), projections[2], projections[3], None),
+                                       tile_size=self.config.block_size)
+        rgb, _ = GSplatV1.rasterize(pre, projections, isects, opac, colors=rgbs, background=bg_color, tile_size=self.config.block_size,
+                                    absgrad=False)
+        rgb = rgb.permute(2, 0, 1)
+        hard_inverse_depth_im = None
+        if "hard_inverse_depth" in render_types:
+            inverse_depth = 1. / (depths.clamp_min(0.) + 1e-8).unsqueeze(-1)
+            hard_inverse_depth_im, _ = GSplatV1.rasterize(pre, projections, isects, opac + (1 - opac.detach()), colors=inverse_depth,
+                                                          background=torch.zeros((1,), dtype=torch.float, device=bg_color.device),
+                                                          tile_size=self.config.block_size, absgrad=False)
+            hard_inverse_depth_im = hard_inverse_depth_im.permute(2, 0, 1)
+        return {
+            "render": rgb,
+            "hard_inverse_depth": hard_inverse_depth_im,
+            "cameras": cameras,
+            "projection_results_list": projection_results_list,
+            "visible_mask_list": [r[5] for r in projection_results_list],
+            "xys_grad_scale_required": True,
+        }
+
+    # ---- periodic rebalancing (reference :423-510) -------------------------------------------------------
+    def after_training_step(self, step: int, module):
+        c = self.config
+        if c.redistribute_interval < 0 or step >= c.redistribute_until or step % c.redistribute_interval != 0:
+            return
+        with torch.no_grad():
+            counts = [0 for _ in range(self.world_size)]
+            dist.all_gather_object(counts, module.gaussian_model.get_xyz.shape[0])
+            if min(counts) * c.redistribute_threshold >= max(counts):
+                return
+            self.random_redistribute(module)
+
+    def random_redistribute(self, module):
+        n = module.gaussian_model.get_xyz.shape[0]
+        destination = torch.randint(0, self.world_size, (n,), device=module.device)
+        move = lambda t: D.redistribute_rows(t, destination)
+        new_tensors = {}
+        for opt in module.gaussian_optimizers:
+            for group in opt.param_groups:
+                assert len(group["params"]) == 1
+                state = opt.state.get(group["params"][0], None)
+                if state is not None:
+                    state["exp_avg"], state["exp_avg_sq"] = move(state["exp_avg"]), move(state["exp_avg_sq"])
+                    del opt.state[group["params"][0]]
+                    group["params"][0] = torch.nn.Parameter(move(group["params"][0]).requires_grad_(True))
+                    opt.state[group["params"][0]] = state
+                else:
+                    group["params"][0] = torch.nn.Parameter(move(group["params"][0]).requires_grad_(True))
+                new_tensors[group["name"]] = group["params"][0]
+        for name in module.gaussian_model.get_property_names():
+            if name not in new_tensors:
+                new_tensors[name] = move(module.gaussian_model.get_property(name))
+        module.gaussian_model.properties = new_tensors
+        self.on_density_changed()
+
+    def get_available_outputs(self) -> Dict:
+        return {"rgb": RendererOutputInfo("render"),
+                "hard_inverse_depth": RendererOutputInfo("hard_inverse_depth", type=RendererOutputTypes.GRAY)}

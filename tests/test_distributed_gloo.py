@@ -1,0 +1,92 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes exercise the packed all-to-all (forward contents,
+split bookkeeping, autograd reverse route), shard bounds, row redistribution and the stats all-reduce."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _records(rank, n_by_dest, seed):
+    g = torch.Generator().manual_seed(seed + 17 * rank)
+    out = []
+    for j, n in enumerate(n_by_dest):
+        radii = torch.randint(1, 50, (n,), generator=g, dtype=torch.int32)
+        parts = dict(means2d=torch.randn(n, 2, generator=g), depths=torch.rand(n, generator=g) + 1, conics=torch.randn(n, 3, generator=g),
+                     compensations=torch.rand(n, generator=g), opacities=torch.rand(n, 1, generator=g), rgbs=torch.rand(n, 3, generator=g))
+        out.append((radii, parts))
+    return out
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gspl_amd  # noqa: F401
+        from gspl_amd import distributed as D
+        counts = [[3, 5], [0, 4]]                      # counts[src][dst]; rank 1 sends nothing to rank 0's camera
+        mine = _records(rank, counts[rank], seed=5)
+        leaves, packed = [], []
+        for radii, p in mine:
+            p = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            leaves.append(p)
+            vis = torch.ones(radii.shape[0], dtype=torch.bool)
+            packed.append(D.pack_visible(radii, p["means2d"], p["depths"], p["conics"], p["compensations"], p["opacities"], p["rgbs"], vis))
+        recv, recv_counts = D.exchange_visible_splats(packed)
+        assert recv_counts == [counts[src][rank] for src in range(world)]
+        radii, means2d, depths, conics, comp, opac, rgbs = D.unpack_records(recv)
+        # forward contents: what each source packed for this rank, in rank order
+        exp_radii, exp_xy = [], []
+        for src in range(world):
+            r, p = _records(src, counts[src], seed=5)[rank]
+            exp_radii.append(r)
+            exp_xy.append(p["means2d"])
+        assert torch.equal(radii, torch.cat(exp_radii)) and torch.equal(means2d, torch.cat(exp_xy))
+        assert recv.shape == (sum(recv_counts), D.RECORD_FLOATS)
+        # backward: gradient of a rank-dependent loss must come home to the owner of each record
+        ((means2d * (rank + 1)).sum() + (rgbs * 10 * (rank + 1)).sum() + (opac * 100).sum()).backward()
+        for dst in range(world):
+            n = counts[rank][dst]
+            if n == 0:
+                continue
+            assert torch.allclose(leaves[dst]["means2d"].grad, torch.full((n, 2), float(dst + 1)))
+            assert torch.allclose(leaves[dst]["rgbs"].grad, torch.full((n, 3), 10.0 * (dst + 1)))
+            assert torch.allclose(leaves[dst]["opacities"].grad, torch.full((n, 1), 100.0))
+            assert torch.all(leaves[dst]["conics"].grad == 0)
+
+        # shard bounds partition [0, N)
+        bounds = [D.shard_bounds(1001, world, r) for r in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == 1001 and all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
+
+        # row redistribution: rows tagged with (owner, index) arrive where `destination` says
+        n_local = 6 + rank
+        rows = torch.stack([torch.full((n_local,), float(rank)), torch.arange(n_local, dtype=torch.float32)], dim=1)
+        g = torch.Generator().manual_seed(100 + rank)
+        dest = torch.randint(0, world, (n_local,), generator=g)
+        got = D.redistribute_rows(rows, dest)
+        exp = []
+        for src in range(world):
+            ns = 6 + src
+            d = torch.randint(0, world, (ns,), generator=torch.Generator().manual_seed(100 + src))
+            r = torch.stack([torch.full((ns,), float(src)), torch.arange(ns, dtype=torch.float32)], dim=1)
+            exp.append(r[d == rank])
+        assert torch.equal(got, torch.cat(exp))
+
+        # replicated mode: densification statistics agree on every rank afterwards
+        accum = torch.tensor([1.0, 2.0, 3.0]) * (rank + 1)
+        denom = torch.tensor([1.0, 0.0, 1.0])
+        maxr = torch.tensor([5.0, 1.0, 0.0]) if rank == 0 else torch.tensor([2.0, 7.0, 0.0])
+        D.reduce_densification_stats(accum, denom, maxr)
+        assert torch.equal(accum, torch.tensor([3.0, 6.0, 9.0])) and torch.equal(denom, torch.tensor([2.0, 0.0, 2.0]))
+        assert torch.equal(maxr, torch.tensor([5.0, 7.0, 0.0]))
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo(tmp_path):
+    port = 29600 + (os.getpid() % 300)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
