@@ -15,7 +15,7 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libgspl_hip.so")
+LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
 ABI_VERSION = 3
 
 GSPL_MODE_GSPLAT = 0

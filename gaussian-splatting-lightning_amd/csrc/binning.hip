@@ -203,6 +203,36 @@ __global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, cons
         for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
 }
 
+// rocPRIM tuning (swept on MI355X, S-1080p-1M: 8 variants, tools/bench_stages.sh).  The library default switches to a
+// merge sort below 2^20 items (20 small merge launches for the 1 M-splat depth sort, 0.15 ms): both sorts are forced
+// onto the onesweep radix path, with 1024-thread blocks of few items per thread (more blocks in flight) and 7-bit
+// digits for the 13-bit tile sort.  bin_count 0.20 -> 0.14 ms, bin_emit_sort 0.37 -> 0.31 ms.
+#ifndef GSPL_TS_BITS
+#define GSPL_TS_BITS 7
+#endif
+#ifndef GSPL_TS_SB
+#define GSPL_TS_SB 1024
+#endif
+#ifndef GSPL_TS_SI
+#define GSPL_TS_SI 8
+#endif
+#ifndef GSPL_DS_SB
+#define GSPL_DS_SB 1024
+#endif
+#ifndef GSPL_DS_SI
+#define GSPL_DS_SI 4
+#endif
+using DepthSortCfg = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 8>, rocprim::kernel_config<GSPL_DS_SB, GSPL_DS_SI>, 8,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    32 * 1024>;
+using TileSortCfg = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 32>, rocprim::kernel_config<GSPL_TS_SB, GSPL_TS_SI>, GSPL_TS_BITS,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    32 * 1024>;
+
 struct BinWorkspace {
     size_t keys_off, ids_off, keys2_off, counts_off, counts64_off, scan_tmp_off, scan_tmp_bytes, sort1_tmp_off, sort1_tmp_bytes;
     size_t tkeys_off, tvals_off, tkeys2_off, sort2_tmp_off, sort2_tmp_bytes;
@@ -214,9 +244,9 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     size_t scan_tmp = 0, s1 = 0, s2 = 0;
     hipError_t e = rocprim::inclusive_scan(nullptr, scan_tmp, (const int64_t*)nullptr, (int64_t*)nullptr, n, rocprim::plus<int64_t>(), (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: scan size query");
-    e = rocprim::radix_sort_pairs(nullptr, s1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+    e = rocprim::radix_sort_pairs<DepthSortCfg>(nullptr, s1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort1 size query");
-    e = rocprim::radix_sort_pairs(nullptr, s2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 32, (hipStream_t)0);
+    e = rocprim::radix_sort_pairs<TileSortCfg>(nullptr, s2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 32, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort2 size query");
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -266,7 +296,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     rc = check_launch("bin_keys");
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort1_tmp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
+    hipError_t e = rocprim::radix_sort_pairs<DepthSortCfg>(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
     if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
     hipLaunchKernelGGL(bin_gather_counts_kernel, dim3(grid), dim3(256), 0, s, N, (const uint32_t*)order, counts, counts64);
     rc = check_launch("bin_gather_counts");
@@ -309,7 +339,7 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort2_tmp_bytes;
     const int bits = key_bits(n_tiles) - 32;
-    hipError_t e = rocprim::radix_sort_pairs(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, tvals, (uint32_t*)flatten_ids, (size_t)n_isects, 0,
+    hipError_t e = rocprim::radix_sort_pairs<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, tvals, (uint32_t*)flatten_ids, (size_t)n_isects, 0,
                                              bits > 0 ? bits : 1, s);
     if (e != hipSuccess) return check_hip(e, "bin_emit_sort: tile sort");
     const int64_t g2 = (n_isects + 255) / 256;

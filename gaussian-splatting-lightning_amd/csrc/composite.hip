@@ -190,8 +190,11 @@ __device__ __forceinline__ float group8_sum(float v) {
 //   fp32 L2 atomic per value per (tile, splat).
 // VALU work per (pixel, splat) pair drops to ~33 (phase 1) + ~9 (phase 2) instructions, against ~110 for a
 // per-splat 64-lane reduction of every gradient component.
+#ifndef GSPL_BWD_WAVES
+#define GSPL_BWD_WAVES 5     // <= 96 VGPRs: 5 waves/SIMD (with the 29 KB LDS footprint: 5 blocks/CU); 6 spills
+#endif
 template <int D, int MODE, bool CHW, bool ABS>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(
+__global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
