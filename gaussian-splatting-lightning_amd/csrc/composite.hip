@@ -57,8 +57,18 @@ __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isec
     end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
 }
 
+// Forward: ONE WAVE PER WORKGROUP.  A workgroup is a single wave64 that owns one 8x8 quadrant of a tile and walks
+// the tile's list on its own: no workgroup barrier anywhere, a quadrant that saturates (T <= 1e-4 everywhere) or has
+// few candidates retires immediately and frees its slot, and up to 32 such waves per CU hide each other's LDS and
+// gather latency.  The price is that the four quadrants of a tile each gather the tile's records (L1/L2 hits: the
+// four workgroups are adjacent in dispatch order and XCD-remapped together).
+// Per round of 64 splats: lane l gathers splat base+l, tests ITS splat's alpha >= 1/255 box against the quadrant
+// (the ballot is the candidate list) and parks the record in LDS; the wave then walks the candidates with
+// broadcast LDS reads.  The id of the next round's splat is prefetched.
+static constexpr int FCHUNK = 64;
+
 template <int D, int MODE, bool CHW>
-__global__ __launch_bounds__(256) void composite_fwd_kernel(
+__global__ __launch_bounds__(64) void composite_fwd_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
@@ -66,14 +76,12 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     float* __restrict__ out_colors, float* __restrict__ out_alphas, float* __restrict__ final_Ts,
     int32_t* __restrict__ last_ids) {
     using TR = ModeTraits<MODE>;
-    __shared__ float2 s_xy[CHUNK];
-    __shared__ float4 s_co[CHUNK];      // 0.5a, b, 0.5c, opacity
-    __shared__ float2 s_ext[CHUNK];     // conservative half-extent of the alpha >= 1/255 region
-    __shared__ float s_col[CHUNK * D];
-    __shared__ int s_wdone[4];
+    __shared__ float2 s_xy[FCHUNK];
+    __shared__ float4 s_co[FCHUNK];      // 0.5a, b, 0.5c, opacity
+    __shared__ float s_col[FCHUNK * D];
 
-    const int tile = xcd_remap(blockIdx.x, n_tiles);
-    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int unit = xcd_remap(blockIdx.x, 4 * n_tiles);     // (tile, quadrant), contiguous per XCD
+    const int tile = unit >> 2, w = unit & 3, l = threadIdx.x;
     const int px = (tile % tile_w) * TILE + (w & 1) * 8 + (l & 7);
     const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
     const bool inside = (px < width) && (py < height);
@@ -91,60 +99,52 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(
     for (int c = 0; c < D; ++c) acc[c] = 0.f;
     int last = start;            // one past the last contributing index
     bool done = !inside;
-    bool wave_done = __all(done);
 
-    for (int base = start; base < end; base += CHUNK) {
-        if (l == 0) s_wdone[w] = wave_done ? 1 : 0;
-        __syncthreads();
-        if (s_wdone[0] & s_wdone[1] & s_wdone[2] & s_wdone[3]) break;
-        const int i = base + t;
-        if (i < end) {
-            const int g = flatten_ids[i];
-            const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
-            s_xy[t] = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
-            s_co[t] = make_float4(0.5f * ca, cb, 0.5f * cc, op);
-            s_ext[t] = splat_extent(ca, cb, cc, op);
+    if (!__all(done)) {
+        int g_next = (start + l < end) ? flatten_ids[start + l] : 0;
+        for (int base = start; base < end; base += FCHUNK) {
+            const int i = base + l;
+            const int g = g_next;
+            if (base + FCHUNK + l < end) g_next = flatten_ids[base + FCHUNK + l];     // prefetch next round's id
+            bool cand = false;
+            if (i < end) {
+                const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
+                const float2 xy = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
+                const float2 ext = splat_extent(ca, cb, cc, op);
+                cand = (xy.x + ext.x >= qx0) && (xy.x - ext.x <= qx1) && (xy.y + ext.y >= qy0) && (xy.y - ext.y <= qy1);
+                if (cand) {
+                    s_xy[l] = xy;
+                    s_co[l] = make_float4(0.5f * ca, cb, 0.5f * cc, op);
 #pragma unroll
-            for (int c = 0; c < D; ++c) s_col[t * D + c] = colors[(int64_t)g * D + c];
-        }
-        __syncthreads();
-        if (!wave_done) {
-            const int cnt = min(CHUNK, end - base);
-            // wave-level culling: each LANE tests one splat of the chunk against the quadrant's box, the
-            // ballot is the candidate list; only candidates run the per-pixel loop (4 x 64 splats per chunk)
-#pragma unroll 1
-            for (int k = 0; k < CHUNK / 64 && !wave_done; ++k) {
-                const int idx = k * 64 + l;
-                const float2 cxy = s_xy[idx];
-                const float2 ext = s_ext[idx];
-                const bool cand = (idx < cnt) && (cxy.x + ext.x >= qx0) && (cxy.x - ext.x <= qx1) &&
-                                  (cxy.y + ext.y >= qy0) && (cxy.y - ext.y <= qy1);
-                unsigned long long mask = __ballot(cand);
-                while (mask) {
-                    const int j = k * 64 + (int)__builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const float2 xy = s_xy[j];
-                    const float4 co = s_co[j];
-                    const float dx = xy.x - pxf, dy = xy.y - pyf;
-                    const float sigma = eval_sigma(co.x, co.y, co.z, dx, dy);
-                    const float alpha = fminf(TR::kAlphaMax, co.w * __expf(-sigma));
-                    bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
-                    if (!__any(valid)) continue;
-                    const float next_T = T * (1.f - alpha);
-                    const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
-                    done = done || stop;
-                    valid = valid && !stop;
-                    if (valid) {
-                        const float wgt = alpha * T;
-#pragma unroll
-                        for (int c = 0; c < D; ++c) acc[c] += s_col[j * D + c] * wgt;
-                        T = next_T;
-                        last = base + j + 1;
-                    }
-                    if (__all(done)) { wave_done = true; break; }
+                    for (int c = 0; c < D; ++c) s_col[l * D + c] = colors[(int64_t)g * D + c];
                 }
             }
-            wave_done = __all(done);
+            unsigned long long mask = __ballot(cand);
+            bool all_done = false;
+            while (mask) {
+                const int j = (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float2 xy = s_xy[j];
+                const float4 co = s_co[j];
+                const float dx = xy.x - pxf, dy = xy.y - pyf;
+                const float sigma = eval_sigma(co.x, co.y, co.z, dx, dy);
+                const float alpha = fminf(TR::kAlphaMax, co.w * __expf(-sigma));
+                bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
+                if (!__any(valid)) continue;
+                const float next_T = T * (1.f - alpha);
+                const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
+                done = done || stop;
+                valid = valid && !stop;
+                if (valid) {
+                    const float wgt = alpha * T;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc[c] += s_col[j * D + c] * wgt;
+                    T = next_T;
+                    last = base + j + 1;
+                }
+                if (__all(done)) { all_done = true; break; }
+            }
+            if (all_done) break;
         }
     }
 
@@ -429,7 +429,7 @@ static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
                       float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, hipStream_t s) {
-    hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW>), dim3(n_tiles), dim3(256), 0, s,
+    hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW>), dim3(4 * n_tiles), dim3(64), 0, s,
                        n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                        offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids);
     return check_launch("composite_fwd");
