@@ -143,9 +143,71 @@ static int plan_workspace(int N, int64_t n_isects, IsectWorkspace& w) {
 // sort — both are stable, ties end in Gaussian-id order — but the traffic per intersection drops
 // from 12 B x 2 x 6 passes to 8 B x 2 x 2 passes (+ 8 B x 2 x 4 passes per *splat*).
 // =================================================================================================
+// Exact "which tiles of this tile ROW can the splat reach with alpha >= 1/255" test.
+// The region alpha >= 1/255 is the ellipse  1/2 d^T Q d <= tau  (d = p - mu, Q = conic, tau = ln(255 opacity)).
+// For a horizontal band dy in [lo, hi] (the pixel centres of one tile row) the ellipse's chord at height dy is
+//     dx in [(-b dy - sqrt(D))/a, (-b dy + sqrt(D))/a],  D = 2 tau a - det dy^2,
+// the right end is concave in dy with its maximum hx = sqrt(2 tau c / det) at dy = -dys, the left end convex with its
+// minimum -hx at dy = +dys  (dys = b sqrt(2 tau / (det c))).  The ellipse-band intersection is convex, so a tile of the
+// row is reachable iff its pixel-centre span meets the x-projection [xl, xr] of that intersection: the test is exact
+// and costs two square roots per tile ROW instead of a test per tile.  tau and the span are inflated by small margins so
+// that fp32 rounding can never drop a pair the compositing kernels' per-pixel test would keep: images and gradients
+// are unchanged by the culling.
+struct SplatCull {
+    float mx, my, a, b, det, two_tau_a, inv_a, hx, hy, dys;
+    int kind;    // 0: never contributes, 1: ellipse test, 2: never cull (degenerate conic)
+};
+__device__ __forceinline__ SplatCull make_cull(float mx, float my, float a, float b, float c, float opacity) {
+    SplatCull s;
+    s.mx = mx; s.my = my; s.a = a; s.b = b;
+    const float tau = __logf(255.f * opacity);
+    s.det = a * c - b * b;
+    if (!(tau > 0.f)) { s.kind = 0; return s; }
+    if (!(s.det > 0.f) || !(a > 0.f) || !(c > 0.f)) { s.kind = 2; return s; }
+    s.kind = 1;
+    const float two_tau = 2.f * (tau * 1.001f + 1e-3f);
+    s.two_tau_a = two_tau * a;
+    s.inv_a = 1.f / a;
+    s.hx = sqrtf(two_tau * c / s.det);
+    s.hy = sqrtf(two_tau * a / s.det);
+    s.dys = b * sqrtf(two_tau / (s.det * c));
+    return s;
+}
+// x-span (absolute pixel coordinates) reachable inside the band y in [y0, y1]; returns false when empty.
+__device__ __forceinline__ bool row_span(const SplatCull& s, float y0, float y1, float& xl, float& xr) {
+    float lo = y0 - s.my, hi = y1 - s.my;
+    if (hi < -s.hy || lo > s.hy) return false;
+    lo = fmaxf(lo, -s.hy); hi = fminf(hi, s.hy);
+    const float rlo = sqrtf(fmaxf(0.f, s.two_tau_a - s.det * lo * lo));
+    const float rhi = sqrtf(fmaxf(0.f, s.two_tau_a - s.det * hi * hi));
+    const float right = (-s.dys >= lo && -s.dys <= hi) ? s.hx : fmaxf((-s.b * lo + rlo) * s.inv_a, (-s.b * hi + rhi) * s.inv_a);
+    const float left = (s.dys >= lo && s.dys <= hi) ? -s.hx : fminf((-s.b * lo - rlo) * s.inv_a, (-s.b * hi - rhi) * s.inv_a);
+    const float eps = 1e-3f + 1e-4f * s.hx;
+    xl = s.mx + left - eps;
+    xr = s.mx + right + eps;
+    return true;
+}
+// reachable tile columns [c0, c1) of tile row ty inside the rect columns [minx, maxx)
+template <int MODE>
+__device__ __forceinline__ void row_columns(const SplatCull& s, int ty, int tile_size, int minx, int maxx, int& c0, int& c1) {
+    if (s.kind == 2) { c0 = minx; c1 = maxx; return; }
+    c0 = c1 = minx;
+    if (s.kind == 0) return;
+    const float off = MODE == GSPL_MODE_GSPLAT ? 0.5f : 0.f;
+    const float ts = (float)tile_size, span = (float)(tile_size - 1);
+    const float y0 = (float)(ty * tile_size) + off;
+    float xl, xr;
+    if (!row_span(s, y0, y0 + span, xl, xr)) return;
+    // tile tx covers pixel centres [tx*ts + off, tx*ts + off + span]
+    c0 = max(minx, (int)ceilf((xl - off - span) / ts));
+    c1 = min(maxx, (int)floorf((xr - off) / ts) + 1);
+    if (c1 < c0) c1 = c0;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bin_keys_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+    const float* __restrict__ conics, const float* __restrict__ opacities,
     int tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, int32_t* __restrict__ counts) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
@@ -153,8 +215,18 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
     const int radius = radii[g];
     if (radius > 0) {
         int minx, miny, maxx, maxy;
-        tile_rect<MODE>(means2d[g * 2 + 0], means2d[g * 2 + 1], radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
-        n = max(maxx - minx, 0) * max(maxy - miny, 0);
+        const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+        tile_rect<MODE>(mx, my, radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+        if (conics) {
+            const SplatCull sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
+            for (int ty = miny; ty < maxy; ++ty) {
+                int c0, c1;
+                row_columns<MODE>(sc, ty, tile_size, minx, maxx, c0, c1);
+                n += c1 - c0;
+            }
+        } else {
+            n = max(maxx - minx, 0) * max(maxy - miny, 0);
+        }
     }
     counts[g] = n;
     ids[g] = (uint32_t)g;
@@ -170,6 +242,7 @@ __global__ __launch_bounds__(256) void bin_gather_counts_kernel(int N, const uin
 template <int MODE>
 __global__ __launch_bounds__(256) void bin_emit_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
+    const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, int tile_size, int tile_w, int tile_h,
     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,14 +251,21 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(
     const int radius = radii[g];
     if (radius <= 0) return;
     int minx, miny, maxx, maxy;
-    tile_rect<MODE>(means2d[g * 2 + 0], means2d[g * 2 + 1], radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+    const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+    tile_rect<MODE>(mx, my, radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
     int64_t off = (i == 0) ? 0 : cum_sorted[i - 1];
-    for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) {
+    SplatCull sc;
+    sc.kind = 2;
+    if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
+    for (int ty = miny; ty < maxy; ++ty) {
+        int c0, c1;
+        row_columns<MODE>(sc, ty, tile_size, minx, maxx, c0, c1);
+        for (int tx = c0; tx < c1; ++tx) {
             tile_keys[off] = (uint32_t)(ty * tile_w + tx);
             vals[off] = (uint32_t)g;
             ++off;
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ keys, int n_tiles,
@@ -270,6 +350,7 @@ extern "C" size_t gspl_bin_workspace_bytes(int N, int64_t n_isects) {
 }
 
 extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
+                              const float* conics, const float* opacities,
                               int tile_size, int tile_w, int tile_h,
                               int32_t* order, int64_t* cum_tiles, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gspl;
@@ -277,6 +358,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_count: bad mode");
     if (N == 0) return GSPL_OK;
     if (!means2d || !radii || !depths || !order || !cum_tiles || !workspace) return fail_arg("bin_count: NULL required pointer");
+    if ((conics == nullptr) != (opacities == nullptr)) return fail_arg("bin_count: conics and opacities go together");
     BinWorkspace w;
     int rc = plan_bin(N, 0, w);
     if (rc != GSPL_OK) return rc;
@@ -290,9 +372,9 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, tile_size, tile_w, tile_h, keys, ids, counts);
+        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts);
     else
-        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, tile_size, tile_w, tile_h, keys, ids, counts);
+        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts);
     rc = check_launch("bin_keys");
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort1_tmp_bytes;
@@ -307,6 +389,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
 }
 
 extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const int32_t* radii,
+                                  const float* conics, const float* opacities,
                                   const int32_t* order, const int64_t* cum_tiles,
                                   int tile_size, int tile_w, int tile_h, int64_t n_isects,
                                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
@@ -332,9 +415,9 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
     uint32_t* tkeys2 = (uint32_t*)(ws + w.tkeys2_off);
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
     else
-        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
     rc = check_launch("bin_emit");
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort2_tmp_bytes;

@@ -405,6 +405,9 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
                 s_acc[t * NV + k] = 0.f;
                 any_nz = any_nz || (v[k] != 0.f);
             }
+#ifdef GSPL_EXPERIMENT_NO_FLUSH
+            any_nz = any_nz && (g < 0);
+#endif
             if (any_nz) {
                 atomicAdd(&v_means2d[g * 2 + 0], v[0]);
                 atomicAdd(&v_means2d[g * 2 + 1], v[1]);

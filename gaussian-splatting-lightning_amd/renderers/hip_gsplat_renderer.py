@@ -87,12 +87,14 @@ class HipGSplatRenderer(Renderer):
             opacities = opacities * comp[:, None]
         zero1 = torch.zeros((1,), dtype=torch.float, device=bg_color.device)
 
-        isects = ops.bin_gaussians(xys, depths, radii, H, W, self.block_size)     # sorted once, shared by every pass below
+        # sorted once, shared by every pass that composites with `opacities`; tile hits that cannot reach alpha >= 1/255
+        # are not listed.  Passes with other opacities ("hard" depth) bin for themselves inside rasterize_gaussians.
+        isects = ops.bin_gaussians(xys, depths, radii, H, W, self.block_size, conics=conics, opacities=opacities)
 
         def rasterize(feats, background, return_alpha=False, opac=opacities, absgrad=False):
             return ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, feats, opac, img_height=H, img_width=W,
                                            block_width=self.block_size, background=background, return_alpha=return_alpha,
-                                           absgrad=absgrad, isects=isects)
+                                           absgrad=absgrad, isects=isects if opac is opacities else None)
 
         rgb = None
         if self.is_type_required(bits, self._RGB_REQUIRED):

@@ -160,15 +160,22 @@ int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids,
  *    only.  Produces exactly the flatten_ids / offsets of steps a-c above at a third of the traffic.
  *      order [N] i32 (splat ids by depth, tile-less splats last), cum_tiles [N] i64 (inclusive prefix
  *      sum of tile counts in that order; host reads cum_tiles[N-1]).
+ *    conics [N,3] + opacities [N] (both nullable, together): when given, a (tile, splat) pair is listed
+ *    only if the splat can reach alpha >= 1/255 somewhere in the tile (exact ellipse-vs-tile test with a
+ *    conservative margin).  The dropped pairs contribute nothing to any pixel, so composited images and
+ *    gradients are unchanged, while the lists shrink by ~40 % (the 3-sigma square of the reference's
+ *    rect is loose, the more so for low opacities).  Pass the SAME opacities the compositing call uses.
  * ---------------------------------------------------------------------------------------- */
 size_t gspl_bin_workspace_bytes(int N, int64_t n_isects);
 int gspl_bin_count(int N, int mode,
                    const float* means2d, const int32_t* radii, const float* depths,
+                   const float* conics /*nullable*/, const float* opacities /*nullable*/,
                    int tile_size, int tile_w, int tile_h,
                    int32_t* order, int64_t* cum_tiles,
                    void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_emit_sort(int N, int mode,
                        const float* means2d, const int32_t* radii,
+                       const float* conics /*nullable*/, const float* opacities /*nullable*/,
                        const int32_t* order, const int64_t* cum_tiles,
                        int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int32_t* flatten_ids, int32_t* offsets,

@@ -220,6 +220,43 @@ def test_binning_two_level_ties_and_empty(hip):
     assert flat.numel() == 0 and offs.numel() == ((W + 15) // 16) * ((H + 15) // 16) and int(offs.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
+def test_tile_culling_is_lossless(hip, mode):
+    """Exact ellipse-vs-tile culling in the list-only binning path: shorter lists, every tile's list an
+    order-preserving subsequence of the un-culled one, bit-identical image, same gradients."""
+    from gspl_amd import _lib as L
+    W, H, D = 333, 211, 3
+    xys, conics, colors, op, bg, flat_ref, offs_ref = _composite_case(mode, D, W, H, n=8000, seed=17)
+    res, _, _, _ = _projected_scene(8000, W, H, 260.0, seed=17)
+    depths, radii = res[1], res[2]
+    d = _dev()
+    c = lambda a: torch.as_tensor(a).contiguous().to(d)
+    dxy, dcon, dcol, dop, dbg = c(xys), c(conics), c(colors), c(op), c(bg)
+    flat0, offs0 = hip.bin_gaussians(dxy, c(depths), c(radii), H, W, 16, mode=mode)
+    flat1, offs1 = hip.bin_gaussians(dxy, c(depths), c(radii), H, W, 16, mode=mode, conics=dcon, opacities=dop)
+    assert np.array_equal(flat0.cpu().numpy(), flat_ref)
+    assert 0.3 * flat0.numel() < flat1.numel() < 0.9 * flat0.numel()
+    f0, f1, o0, o1 = flat0.cpu().numpy(), flat1.cpu().numpy(), offs0.cpu().numpy(), offs1.cpu().numpy()
+    n_tiles = o0.shape[0]
+    for t in range(0, n_tiles, 7):
+        a = f0[o0[t]:(o0[t + 1] if t + 1 < n_tiles else len(f0))]
+        b = f1[o1[t]:(o1[t + 1] if t + 1 < n_tiles else len(f1))]
+        it = iter(a.tolist())
+        assert all(any(x == y for y in it) for x in b.tolist()), "culled list is not a subsequence"
+    out0, a0, T0, l0 = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, offs0, flat0)
+    out1, a1, T1, l1 = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, offs1, flat1)
+    assert torch.equal(out0, out1) and torch.equal(T0, T1)
+    g = torch.Generator().manual_seed(3)
+    v_out = c(torch.randn(H, W, D, generator=g))
+    g0 = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, offs0, flat0, T0, l0, v_out)
+    g1 = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, offs1, flat1, T1, l1, v_out)
+    for k in ("v_means2d", "v_conics", "v_colors", "v_opacities"):
+        assert_close_scaled(g1[k].cpu().numpy(), g0[k].cpu().numpy(), 1e-5, k)
+    # and against the oracle on the culled lists
+    out_ref, _, _, frag = O.composite_fwd(mode, xys, conics, colors, op, bg, W, H, offs_ref, flat_ref)
+    assert np.abs(out1.cpu().numpy() - out_ref)[frag == 0].max() <= 1e-5
+
+
 def test_binning_empty_inputs(hip):
     d = _dev()
     tiles, ids, flat = hip.isect_tiles(torch.zeros(1, 7, 2, device=d), torch.zeros(1, 7, dtype=torch.int32, device=d),
