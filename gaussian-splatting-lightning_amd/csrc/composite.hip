@@ -51,6 +51,12 @@ __device__ __forceinline__ float2 splat_extent(float a, float b, float c, float 
     return make_float2(sqrtf(k * c) * 1.0002f + 1e-3f, sqrtf(k * a) * 1.0002f + 1e-3f);
 }
 
+// Two splats at once with packed fp32 math; each component is bit-identical to eval_sigma.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t eval_sigma2(v2f_t half_a, v2f_t b, v2f_t half_c, v2f_t dx, v2f_t dy) {
+    return __builtin_elementwise_fma(half_a * dx, dx, __builtin_elementwise_fma(half_c * dy, dy, (b * dx) * dy));
+}
+
 __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isects,
                                            const int32_t* __restrict__ offsets, int& start, int& end) {
     start = offsets[tile];
@@ -60,12 +66,21 @@ __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isec
 // Forward: ONE WAVE PER WORKGROUP.  A workgroup is a single wave64 that owns one 8x8 quadrant of a tile and walks
 // the tile's list on its own: no workgroup barrier anywhere, a quadrant that saturates (T <= 1e-4 everywhere) or has
 // few candidates retires immediately and frees its slot, and up to 32 such waves per CU hide each other's LDS and
-// gather latency.  The price is that the four quadrants of a tile each gather the tile's records (L1/L2 hits: the
-// four workgroups are adjacent in dispatch order and XCD-remapped together).
-// Per round of 64 splats: lane l gathers splat base+l, tests ITS splat's alpha >= 1/255 box against the quadrant
-// (the ballot is the candidate list) and parks the record in LDS; the wave then walks the candidates with
-// broadcast LDS reads.  The id of the next round's splat is prefetched.
+// gather latency.  The four quadrants of a tile each gather the tile's records (L1/L2 hits: the four workgroups are
+// adjacent in dispatch order and XCD-remapped together).
+//
+// Per round of 64 splats:
+//   1. lane l gathers splat base+l and tests ITS splat's alpha >= 1/255 box against the quadrant;
+//   2. ballot + prefix count (v_mbcnt) COMPACT the candidates into a structure-of-arrays list in LDS
+//      (x[], y[], ha[], b[], hc[], opacity[], colour[][D]);
+//   3. the wave walks the list TWO candidates at a time: one ds_read_b64 per array yields the pair as a
+//      64-bit register pair, so sigma / exp argument / alpha are evaluated with packed fp32 math
+//      (v_pk_add/mul/fma_f32 — the only way CDNA reaches its fp32 rate; plain wave64 VALU ops issue at half of it),
+//      and the short sequential transmittance update is branch-free (predicated) to keep scalar-unit work low:
+//      the first version of this loop was bound by SALU mask bookkeeping (136 M scalar vs 118 M vector instructions).
+typedef float v2f __attribute__((ext_vector_type(2)));
 static constexpr int FCHUNK = 64;
+static constexpr int FLIST = FCHUNK + 2;      // room for the odd-count padding entry
 
 template <int D, int MODE, bool CHW>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
@@ -76,9 +91,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     float* __restrict__ out_colors, float* __restrict__ out_alphas, float* __restrict__ final_Ts,
     int32_t* __restrict__ last_ids) {
     using TR = ModeTraits<MODE>;
-    __shared__ float2 s_xy[FCHUNK];
-    __shared__ float4 s_co[FCHUNK];      // 0.5a, b, 0.5c, opacity
-    __shared__ float s_col[FCHUNK * D];
+    __shared__ __attribute__((aligned(16))) float s_x[FLIST];
+    __shared__ __attribute__((aligned(16))) float s_y[FLIST];
+    __shared__ __attribute__((aligned(16))) float s_ha[FLIST];
+    __shared__ __attribute__((aligned(16))) float s_b[FLIST];
+    __shared__ __attribute__((aligned(16))) float s_hc[FLIST];
+    __shared__ __attribute__((aligned(16))) float s_op[FLIST];
+    __shared__ __attribute__((aligned(16))) int s_pos[FLIST];      // list index (base + lane) of each candidate
+    __shared__ __attribute__((aligned(16))) float s_col[FLIST * D];
 
     const int unit = xcd_remap(blockIdx.x, 4 * n_tiles);     // (tile, quadrant), contiguous per XCD
     const int tile = unit >> 2, w = unit & 3, l = threadIdx.x;
@@ -86,6 +106,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
     const bool inside = (px < width) && (py < height);
     const float pxf = (float)px + TR::kPixelCentre, pyf = (float)py + TR::kPixelCentre;
+    const v2f pxf2 = {pxf, pxf}, pyf2 = {pyf, pyf};
     // pixel-centre bounds of this wave's 8x8 quadrant (wave-uniform)
     const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
     const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
@@ -107,40 +128,61 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             const int g = g_next;
             if (base + FCHUNK + l < end) g_next = flatten_ids[base + FCHUNK + l];     // prefetch next round's id
             bool cand = false;
+            float2 xy = make_float2(0.f, 0.f);
+            float ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
             if (i < end) {
-                const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
-                const float2 xy = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
+                ca = conics[g * 3 + 0]; cb = conics[g * 3 + 1]; cc = conics[g * 3 + 2]; op = opacities[g];
+                xy = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
                 const float2 ext = splat_extent(ca, cb, cc, op);
                 cand = (xy.x + ext.x >= qx0) && (xy.x - ext.x <= qx1) && (xy.y + ext.y >= qy0) && (xy.y - ext.y <= qy1);
-                if (cand) {
-                    s_xy[l] = xy;
-                    s_co[l] = make_float4(0.5f * ca, cb, 0.5f * cc, op);
-#pragma unroll
-                    for (int c = 0; c < D; ++c) s_col[l * D + c] = colors[(int64_t)g * D + c];
-                }
             }
-            unsigned long long mask = __ballot(cand);
-            bool all_done = false;
-            while (mask) {
-                const int j = (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float2 xy = s_xy[j];
-                const float4 co = s_co[j];
-                const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float sigma = eval_sigma(co.x, co.y, co.z, dx, dy);
-                const float alpha = fminf(TR::kAlphaMax, co.w * __expf(-sigma));
-                bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
-                if (!__any(valid)) continue;
-                const float next_T = T * (1.f - alpha);
-                const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
-                done = done || stop;
-                valid = valid && !stop;
-                if (valid) {
-                    const float wgt = alpha * T;
+            const unsigned long long mask = __ballot(cand);
+            const int ncand = __builtin_popcountll(mask);
+            if (ncand == 0) continue;
+            // compaction: candidate k of the round goes to slot k (k = number of candidates in lower lanes)
+            const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (cand) {
+                s_x[slot] = xy.x; s_y[slot] = xy.y;
+                s_ha[slot] = 0.5f * ca; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op;
+                s_pos[slot] = i + 1;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) acc[c] += s_col[j * D + c] * wgt;
-                    T = next_T;
-                    last = base + j + 1;
+                for (int c = 0; c < D; ++c) s_col[slot * D + c] = colors[(int64_t)g * D + c];
+            }
+            if (l == 0) {        // padding entry for an odd count: opacity 0 -> alpha 0 -> never valid
+                s_x[ncand] = 0.f; s_y[ncand] = 0.f; s_ha[ncand] = 0.f; s_b[ncand] = 0.f; s_hc[ncand] = 0.f; s_op[ncand] = 0.f;
+                s_pos[ncand] = 0;
+#pragma unroll
+                for (int c = 0; c < D; ++c) s_col[ncand * D + c] = 0.f;
+            }
+            bool all_done = false;
+            for (int k = 0; k < ncand; k += 2) {
+                const v2f x2 = *reinterpret_cast<const v2f*>(&s_x[k]);
+                const v2f y2 = *reinterpret_cast<const v2f*>(&s_y[k]);
+                const v2f ha2 = *reinterpret_cast<const v2f*>(&s_ha[k]);
+                const v2f b2 = *reinterpret_cast<const v2f*>(&s_b[k]);
+                const v2f hc2 = *reinterpret_cast<const v2f*>(&s_hc[k]);
+                const v2f op2 = *reinterpret_cast<const v2f*>(&s_op[k]);
+                const int2 pos2 = *reinterpret_cast<const int2*>(&s_pos[k]);
+                const v2f dx2 = x2 - pxf2, dy2 = y2 - pyf2;
+                const v2f sigma2 = eval_sigma2(ha2, b2, hc2, dx2, dy2);
+                const v2f arg2 = sigma2 * (v2f){-1.4426950408889634f, -1.4426950408889634f};
+                const v2f e2 = {__builtin_amdgcn_exp2f(arg2.x), __builtin_amdgcn_exp2f(arg2.y)};
+                const v2f raw2 = op2 * e2;
+                const float alpha[2] = {fminf(TR::kAlphaMax, raw2.x), fminf(TR::kAlphaMax, raw2.y)};
+                const float sig[2] = {sigma2.x, sigma2.y};
+                const int pos[2] = {pos2.x, pos2.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool valid = !done && (sig[e] >= 0.f) && (alpha[e] >= kAlphaMin);
+                    const float next_T = T * (1.f - alpha[e]);
+                    const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
+                    const bool contrib = valid && !stop;
+                    const float wgt = contrib ? alpha[e] * T : 0.f;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc[c] = fmaf(s_col[(k + e) * D + c], wgt, acc[c]);
+                    T = contrib ? next_T : T;
+                    last = contrib ? pos[e] : last;
+                    done = done || stop;
                 }
                 if (__all(done)) { all_done = true; break; }
             }
