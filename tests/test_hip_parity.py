@@ -469,3 +469,92 @@ def test_full_size_properties(hip):
     # idempotence / determinism of the forward
     img1b, _ = f(rgbs)
     assert torch.equal(img1, img1b)
+
+
+# ---------------------------------------------------------------------------------------------
+# Inria API: optional inputs of the reference's GaussianRasterizer call (vanilla_renderer.py:81-120)
+# ---------------------------------------------------------------------------------------------
+def _inria_settings(hip, cam, bg, W, H, scale_modifier=1.0, deg=3):
+    return hip.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg.to(_dev()), scale_modifier=scale_modifier,
+        viewmatrix=cam["world_to_camera"].to(_dev()), projmatrix=cam["full_projection"].to(_dev()), sh_degree=deg,
+        campos=cam["camera_center"].to(_dev()))
+
+
+def test_inria_api_precomputed_cov3d_and_colors_and_scale_modifier(hip):
+    means, scales, quats, opac, shs, cam, wimg, bg = _e2e_scene(n=4000, seed=23)
+    W, H = cam["width"], cam["height"]
+    mod = 1.7
+    # (a) cov3D_precomp == scales/rotations path with the same modifier; gradients reach cov3D
+    m, s, q, o, c = [t.requires_grad_(True) for t in _cuda(means, scales, quats, opac, shs)]
+    r1, rad1 = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, W, H, mod))(
+        means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, shs=c, scales=s, rotations=q)
+    cov = O.cov3d_from_scale_rot(scales.double(), mod, quats.double())
+    cov6 = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], -1).float().to(_dev()).requires_grad_(True)
+    m2, o2, c2 = [t.requires_grad_(True) for t in _cuda(means, opac, shs)]
+    r2, rad2 = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, W, H, mod))(
+        means3D=m2, means2D=torch.zeros_like(m2, requires_grad=True), opacities=o2, shs=c2, cov3D_precomp=cov6)
+    assert torch.equal(rad1, rad2) or (rad1 == rad2).float().mean() > 0.999
+    assert float((r1 - r2).abs().max()) <= 2e-5
+    (r2 * wimg.to(_dev())).sum().backward()
+    (r1 * wimg.to(_dev())).sum().backward()
+    assert cov6.grad is not None and torch.isfinite(cov6.grad).all() and float(cov6.grad.abs().sum()) > 0
+    # chain rule check: dL/dscales through cov6 equals the direct path
+    sd, qd = scales.double().requires_grad_(True), quats.double().requires_grad_(True)
+    cv = O.cov3d_from_scale_rot(sd, mod, qd)
+    cv6 = torch.stack([cv[:, 0, 0], cv[:, 0, 1], cv[:, 0, 2], cv[:, 1, 1], cv[:, 1, 2], cv[:, 2, 2]], -1)
+    (cv6 * cov6.grad.cpu().double()).sum().backward()
+    assert_close_scaled(sd.grad.numpy(), s.grad.cpu().numpy(), 2e-4, "scales via cov3D_precomp", frac_ok=0.995)
+    assert_close_scaled(qd.grad.numpy(), q.grad.cpu().numpy(), 2e-4, "quats via cov3D_precomp", frac_ok=0.995)
+
+    # (b) colors_precomp == SH evaluated outside; gradient flows to the colours
+    rgbs = O.sh_colors(3, shs.double(), means.double(), cam["camera_center"].double(), detach_dirs=True).float()
+    col = rgbs.to(_dev()).requires_grad_(True)
+    m3, s3, q3, o3 = [t.requires_grad_(True) for t in _cuda(means, scales, quats, opac)]
+    r3, _ = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, W, H, mod))(
+        means3D=m3, means2D=torch.zeros_like(m3, requires_grad=True), opacities=o3, colors_precomp=col, scales=s3, rotations=q3)
+    assert float((r3 - r1.detach()).abs().max()) <= 2e-5
+    (r3 * wimg.to(_dev())).sum().backward()
+    assert col.grad is not None and float(col.grad.abs().sum()) > 0
+    with pytest.raises(Exception):
+        hip.GaussianRasterizer(_inria_settings(hip, cam, bg, W, H))(means3D=m3, means2D=None, opacities=o3, shs=c, colors_precomp=col,
+                                                                    scales=s3, rotations=q3)
+
+
+def test_degenerate_inputs(hip):
+    """Everything behind the camera, a single huge splat covering the whole image, image smaller than a tile."""
+    d = _dev()
+    cam = O.synthetic_camera(40, 24, 30.0)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    # all splats behind the camera -> pure background, zero gradients, radii 0
+    means = torch.tensor([[0.0, 0.0, -10.0], [0.5, 0.1, -8.0]])
+    scales = torch.full((2, 3), 0.1)
+    quats = torch.tensor([[1.0, 0, 0, 0]] * 2)
+    opac = torch.full((2, 1), 0.5)
+    shs = torch.zeros(2, 16, 3)
+    m = means.to(d).requires_grad_(True)
+    r, radii = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, 40, 24))(
+        means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=opac.to(d), shs=shs.to(d), scales=scales.to(d),
+        rotations=quats.to(d))
+    assert int(radii.sum()) == 0 and torch.allclose(r, bg.to(d)[:, None, None].expand_as(r))
+    r.sum().backward()
+    assert float(m.grad.abs().sum()) == 0
+    # one huge opaque splat in front: every pixel saturates to its colour (dc = (c - 0.5)/C0)
+    means = torch.tensor([[0.0, 0.0, 0.0]])
+    scales = torch.full((1, 3), 50.0)
+    shs = torch.zeros(1, 16, 3)
+    shs[0, 0] = (torch.tensor([0.9, 0.1, 0.5]) - 0.5) / 0.28209479177387814
+    r, radii = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, 40, 24))(
+        means3D=means.to(d), means2D=torch.zeros(1, 3, device=d), opacities=torch.ones(1, 1, device=d), shs=shs.to(d),
+        scales=scales.to(d), rotations=quats[:1].to(d))
+    ref = O.render_inria(means.double(), scales.double(), quats[:1].double(), torch.ones(1, 1).double(), shs.double(), 3,
+                         cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
+                         cam["tanfovx"], cam["tanfovy"], 40, 24, bg.double())
+    assert int(radii[0]) > 0 and float((r.cpu() - ref["render"].float()).abs().max()) <= 1e-5
+    # image smaller than one tile, gsplat API
+    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(
+        torch.tensor([[0.0, 0.0, 0.0]], device=d), torch.full((1, 3), 0.3, device=d), 1.0, quats[:1].to(d),
+        torch.eye(4, device=d)[:3] + torch.tensor([[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 4.0]], device=d), 20.0, 20.0, 5.0, 3.5, 7, 10, 16)
+    img = hip.rasterize_gaussians(xys, depths, radii, conics, tiles, torch.ones(1, 3, device=d), torch.ones(1, 1, device=d), 7, 10, 16,
+                                  torch.zeros(3, device=d))
+    assert img.shape == (7, 10, 3) and float(img.max()) > 0.5
