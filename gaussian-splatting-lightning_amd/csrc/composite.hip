@@ -47,8 +47,9 @@ __device__ __forceinline__ float2 splat_extent(float a, float b, float c, float 
     if (!(tau > 0.f)) return make_float2(-1.f, -1.f);
     const float det = a * c - b * b;
     if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return make_float2(INFINITY, INFINITY);   // not an ellipse: never cull
-    const float k = 2.f * tau / det;
-    return make_float2(sqrtf(k * c) * 1.0002f + 1e-3f, sqrtf(k * a) * 1.0002f + 1e-3f);
+    // hardware rcp / sqrt (1 ulp) instead of the IEEE expansions (~10 instructions each): the margins absorb it
+    const float k = 2.f * tau * __builtin_amdgcn_rcpf(det);
+    return make_float2(__builtin_amdgcn_sqrtf(k * c) * 1.0004f + 1e-3f, __builtin_amdgcn_sqrtf(k * a) * 1.0004f + 1e-3f);
 }
 
 // Two splats at once with packed fp32 math; each component is bit-identical to eval_sigma.
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
         vals[1] = co.y * Sx + co.z * Sy;                     // dL/dy
         vals[2] = 0.5f * vals[2];                            // dL/da
         vals[4] = 0.5f * vals[4];                            // dL/dc      (vals[3] = dL/db as is)
-        vals[5] = (co.w != 0.f) ? -vals[5] / co.w : 0.f;     // dL/dopacity = sum(vis * v_alpha) = -sum(sp) / o
+        vals[5] = (co.w != 0.f) ? -vals[5] * __builtin_amdgcn_rcpf(co.w) : 0.f;     // dL/dopacity = sum(vis * v_alpha) = -sum(sp) / o
         // lane q of the group adds value q (and q+8): two ds_add_f32 per batch, per-lane addresses
         float mine = vals[0];
 #pragma unroll
@@ -416,7 +417,8 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
                     if (!__any(valid)) continue;
                     float fac = 0.f, sp = 0.f;
                     if (valid) {
-                        const float ra = 1.f / (1.f - alpha);
+                        // v_rcp_f32 (1 ulp): an IEEE division here expands to ~10 VALU instructions per (pixel, splat) pair
+                        const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
                         T *= ra;                               // transmittance in front of this splat
                         fac = alpha * T;
                         float v_alpha = tail * ra;
