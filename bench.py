@@ -241,7 +241,7 @@ def main():
                                                                 wl["height"], wl["width"], 16)
             I_gsplat = int(tiles.sum().item())
         P = wl["width"] * wl["height"]
-        bwd_ms = mean("gspl_composite_bwd")
+        bwd_ms = mean("gspl_composite_bwd_packed") or mean("gspl_composite_bwd")
         fwd_ms = mean("gspl_composite_fwd")
         # vanilla rect convention gives a slightly different I; measure it from the sort call count instead
         I = I_gsplat

@@ -236,7 +236,7 @@ __device__ __forceinline__ float group8_sum(float v) {
 #ifndef GSPL_BWD_WAVES
 #define GSPL_BWD_WAVES 5     // <= 96 VGPRs: 5 waves/SIMD (with the 29 KB LDS footprint: 5 blocks/CU); 6 spills
 #endif
-template <int D, int MODE, bool CHW, bool ABS>
+template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
 __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
@@ -438,8 +438,19 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
             if (nb) { phase2(nb); nb = 0; }
         }
         __syncthreads();
-        // flush: one lane per splat of the chunk, one L2 atomic per non-zero value
-        if (t < cnt) {
+        // flush to global memory, one fp32 L2 atomic per non-zero value per (tile, splat)
+        if constexpr (PACKED) {
+            // packed rows [N][NV] (x, y, a, b, c, opacity, colour[D], abs x, abs y): thread e handles element e of the
+            // round's [cnt][NV] block, so the 64 lanes of one atomic instruction cover ~64/NV splat rows with contiguous
+            // components (a handful of cache lines per instruction instead of 64 scattered dwords)
+            float* __restrict__ v_packed = v_means2d;
+            for (int e = t; e < cnt * NV; e += 256) {
+                const float v = s_acc[e];
+                s_acc[e] = 0.f;
+                const int row = e / NV;
+                if (v != 0.f) atomicAdd(&v_packed[(int64_t)s_id[row] * NV + (e - row * NV)], v);
+            }
+        } else if (t < cnt) {
             const int g = s_id[t];
             float v[NV];
             bool any_nz = false;
@@ -449,9 +460,6 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
                 s_acc[t * NV + k] = 0.f;
                 any_nz = any_nz || (v[k] != 0.f);
             }
-#ifdef GSPL_EXPERIMENT_NO_FLUSH
-            any_nz = any_nz && (g < 0);
-#endif
             if (any_nz) {
                 atomicAdd(&v_means2d[g * 2 + 0], v[0]);
                 atomicAdd(&v_means2d[g * 2 + 1], v[1]);
@@ -482,7 +490,7 @@ static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_
     return check_launch("composite_fwd");
 }
 
-template <int D, int MODE, bool CHW>
+template <int D, int MODE, bool CHW, bool PACKED = false>
 static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
@@ -491,12 +499,12 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
                       hipStream_t s) {
     if (absgrad)
-        hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true>), dim3(n_tiles), dim3(256), 0, s,
+        hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
     else
-        hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, false>), dim3(n_tiles), dim3(256), 0, s,
+        hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
@@ -581,5 +589,40 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
         else { GSPL_DISPATCH_D(D, GSPL_MODE_INRIA, true, CALL_BWD) }
     }
 #undef CALL_BWD
+    return rc;
+}
+
+// Same backward, gradients delivered as ONE packed row per splat: v_packed [N, 6 + D (+2 with absgrad)] =
+// (dL/dx, dL/dy, dL/da, dL/db, dL/dc, dL/dopacity, dL/dcolour[D], [sum|dL/dx|, sum|dL/dy|]); must be zero-initialised.
+// The flush then issues atomics whose 64 lanes cover contiguous components of a few rows instead of 64 scattered
+// dwords per instruction (see kernel).  Consumers read the columns with a row stride (gspl_inria_preprocess_bwd's
+// grad_stride, or strided views on the host side).
+extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layout,
+                                         const float* means2d, const float* conics, const float* colors,
+                                         const float* opacities, const float* backgrounds,
+                                         int width, int height, int tile_size, int tile_w, int tile_h,
+                                         const int32_t* offsets, const int32_t* flatten_ids,
+                                         const float* final_Ts, const int32_t* last_ids,
+                                         const float* v_out_colors, const float* v_out_alphas,
+                                         float* v_packed, int absgrad, void* stream) {
+    using namespace gspl;
+    int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_bwd_packed: bad argument");
+    if (rc != GSPL_OK) return rc;
+    if (n_isects == 0 || N == 0) return GSPL_OK;
+    if (!means2d || !conics || !colors || !opacities || !offsets || !flatten_ids || !final_Ts || !last_ids || !v_out_colors || !v_packed)
+        return fail_arg("composite_bwd_packed: NULL required pointer");
+    const int n_tiles = tile_w * tile_h;
+    hipStream_t s = (hipStream_t)stream;
+    const bool ag = absgrad != 0;
+    rc = GSPL_ERR_UNSUPPORTED;
+#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s)
+    if (mode == GSPL_MODE_GSPLAT) {
+        if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWDP) }
+        else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWDP) }
+    } else {
+        if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_INRIA, false, CALL_BWDP) }
+        else { GSPL_DISPATCH_D(D, GSPL_MODE_INRIA, true, CALL_BWDP) }
+    }
+#undef CALL_BWDP
     return rc;
 }

@@ -43,5 +43,5 @@ int sh_fwd_launch(int N, int degree, const float* dirs, const float* origin,
 int sh_bwd_launch(int N, int degree, int n_coeffs, const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
-                  const float* v_colors, float* v_dc, float* v_rest, float* v_dirs, void* stream);
+                  const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream);
 }  // namespace gspl

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int width, int height, float tanfovx, float tanfovy, float scale_modifier,
     const int32_t* __restrict__ radii,
-    const float* __restrict__ v_means2d, const float* __restrict__ v_conics,
+    const float* __restrict__ v_means2d, const float* __restrict__ v_conics, int gs2, int gs3,
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
     float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
         inria_geom(cam, p, S6, width, height, tanfovx, tanfovy, G);
 
         // 2D mean (pixels) -> clip space
-        ndc[0] = v_means2d[g * 2 + 0] * 0.5f * (float)width;
-        ndc[1] = v_means2d[g * 2 + 1] * 0.5f * (float)height;
+        ndc[0] = v_means2d[(int64_t)g * gs2 + 0] * 0.5f * (float)width;
+        ndc[1] = v_means2d[(int64_t)g * gs2 + 1] * 0.5f * (float)height;
         const float mw = 1.f / (G.hom[3] + 1e-7f);
         const float vh0 = ndc[0] * mw, vh1 = ndc[1] * mw;
         const float vh3 = -(ndc[0] * G.hom[0] + ndc[1] * G.hom[1]) * mw * mw;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
 
         // conic -> cov2D -> (view-space mean, cov3D)
         float va, vb, vc;
-        conic_bwd(G.a, G.b, G.c, v_conics[g * 3 + 0], v_conics[g * 3 + 1], v_conics[g * 3 + 2], va, vb, vc);
+        conic_bwd(G.a, G.b, G.c, v_conics[(int64_t)g * gs3 + 0], v_conics[(int64_t)g * gs3 + 1], v_conics[(int64_t)g * gs3 + 2], va, vb, vc);
         float vpv[3] = {0.f, 0.f, 0.f};
         ewa_bwd<false>(G.pv, S6, G.Wstd, G.fx, G.fy, G.ctx, va, vb, vc, vpv, G6);
 #pragma unroll
@@ -194,14 +194,14 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
 }
 
 __global__ __launch_bounds__(256) void masked_copy3_kernel(int N, const int32_t* __restrict__ radii,
-                                                           const float* __restrict__ src, float* __restrict__ dst,
+                                                           const float* __restrict__ src, int src_stride, float* __restrict__ dst,
                                                            uint8_t* __restrict__ clamped) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     const bool live = radii[g] > 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        dst[g * 3 + c] = live ? src[g * 3 + c] : 0.f;
+        dst[g * 3 + c] = live ? src[(int64_t)g * src_stride + c] : 0.f;
         if (clamped) clamped[g * 3 + c] = 0;
     }
 }
@@ -233,7 +233,7 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
     int rc = check_launch("inria_preprocess_fwd");
     if (rc != GSPL_OK) return rc;
     if (colors_precomp) {
-        hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, colors_precomp, colors, clamped);
+        hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, colors_precomp, 3, colors, clamped);
         return check_launch("inria_preprocess_fwd(colors_precomp)");
     }
     const int stride = 3 * n_coeffs;
@@ -247,7 +247,7 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                                          const float* viewmatrix, const float* projmatrix, const float* campos,
                                          int width, int height, float tanfovx, float tanfovy, float scale_modifier,
                                          const int32_t* radii, const uint8_t* clamped,
-                                         const float* v_means2d, const float* v_conics, const float* v_colors,
+                                         const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
                                          float* v_means, float* v_scales, float* v_quats,
                                          float* v_cov3d_precomp, float* v_shs, float* v_colors_precomp,
                                          float* v_means2d_ndc, void* stream) {
@@ -260,6 +260,9 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
     if (v_scales && (!scales || !quats)) return fail_arg("inria_preprocess_bwd: scales/quats missing");
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
+    // grad_stride == 0: three dense arrays ([N,2], [N,3], [N,3]); otherwise all three are columns of one packed
+    // [N, grad_stride] buffer (gspl_composite_bwd_packed) and share its row stride
+    const int gs2 = grad_stride > 0 ? grad_stride : 2, gs3 = grad_stride > 0 ? grad_stride : 3;
     bool accum = false;
     if (v_shs) {
         if (!shs || !campos || !clamped) return fail_arg("inria_preprocess_bwd: shs/campos/clamped missing");
@@ -267,22 +270,22 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
         const int stride = 3 * n_coeffs;
         // dL/d(dir) lands in v_means; the geometry kernel accumulates on top
         int rc = sh_bwd_launch(N, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
-                               GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, v_shs, v_shs + 3, v_means, stream);
+                               GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream);
         if (rc != GSPL_OK) return rc;
         accum = true;
     }
     if (v_colors_precomp) {
-        hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, v_colors, v_colors_precomp, (uint8_t*)nullptr);
+        hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, v_colors, gs3, v_colors_precomp, (uint8_t*)nullptr);
         int rc = check_launch("inria_preprocess_bwd(colors_precomp)");
         if (rc != GSPL_OK) return rc;
     }
     if (accum)
         hipLaunchKernelGGL(inria_preprocess_bwd_kernel<true>, dim3(grid), dim3(256), 0, s,
                            N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
-                           radii, v_means2d, v_conics, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
+                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
     else
         hipLaunchKernelGGL(inria_preprocess_bwd_kernel<false>, dim3(grid), dim3(256), 0, s,
                            N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
-                           radii, v_means2d, v_conics, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
+                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
     return check_launch("inria_preprocess_bwd");
 }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
     const float* __restrict__ dirs, const float* __restrict__ origin,
     const float* __restrict__ dc, int dc_stride, const float* __restrict__ rest,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ mask32, int flags, const uint8_t* __restrict__ clamped,
-    const float* __restrict__ v_colors, ShTile tile, int vec_ok_in, int vec_ok_out,
+    const float* __restrict__ v_colors, int vc_stride, ShTile tile, int vec_ok_in, int vec_ok_out,
     float* __restrict__ v_dc, float* __restrict__ v_rest, float* __restrict__ v_dirs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * SH_BLOCK;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
         if (live) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                vc[c] = v_colors[n * 3 + c];
+                vc[c] = v_colors[(int64_t)n * vc_stride + c];
                 if ((flags & GSPL_SH_ADD_HALF_CLAMP) && clamped && clamped[n * 3 + c]) vc[c] = 0.f;
             }
             dx = dirs[n * 3 + 0]; dy = dirs[n * 3 + 1]; dz = dirs[n * 3 + 2];
@@ -361,7 +361,7 @@ int sh_bwd_launch(int N, int degree, int n_coeffs,
                   const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
-                  const float* v_colors,
+                  const float* v_colors, int vc_stride,
                   float* v_dc, float* v_rest, float* v_dirs, void* stream) {
     if (N < 0 || degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("sh_bwd: bad N/degree/n_coeffs");
     if (N == 0) return GSPL_OK;
@@ -393,7 +393,7 @@ int sh_bwd_launch(int N, int degree, int n_coeffs,
             if (e != hipSuccess) return check_hip(e, "sh_bwd: hipFuncSetAttribute");                                  \
         }                                                                                                             \
         hipLaunchKernelGGL((sh_bwd_kernel<DEG, WD>), dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N,   \
-                           n_coeffs, dirs, origin, dc, dc_stride, rest, mask, mask32, flags, clamped, v_colors, tile, vec_in, \
+                           n_coeffs, dirs, origin, dc, dc_stride, rest, mask, mask32, flags, clamped, v_colors, vc_stride, tile, vec_in, \
                            vec_out, v_dc, v_rest, v_dirs);                                                            \
     }
 #define GSPL_SH_BWD_CASE(DEG) \
@@ -412,5 +412,5 @@ extern "C" int gspl_sh_bwd(int N, int degree, int n_coeffs,
                            const uint8_t* mask, int flags, const uint8_t* clamped,
                            const float* v_colors,
                            float* v_dc, float* v_rest, float* v_dirs, void* stream) {
-    return gspl::sh_bwd_launch(N, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors, v_dc, v_rest, v_dirs, stream);
+    return gspl::sh_bwd_launch(N, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors, 3, v_dc, v_rest, v_dirs, stream);
 }

@@ -222,6 +222,20 @@ int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int layout,
                        float* v_conics, float* v_colors, float* v_opacities,
                        void* stream);
 
+/*    5b. Same backward with the gradients delivered as ONE packed row per splat:
+ *      v_packed [N, 6 + D (+2 when absgrad != 0)] =
+ *        (dL/dx, dL/dy, dL/dconic a, b, c, dL/dopacity, dL/dcolour[0..D), [sum|dL/dx|, sum|dL/dy|]),
+ *    zero-initialised by the caller.  One atomic instruction then covers contiguous components of a few
+ *    splat rows instead of 64 scattered dwords. */
+int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layout,
+                              const float* means2d, const float* conics, const float* colors,
+                              const float* opacities, const float* backgrounds /*nullable*/,
+                              int width, int height, int tile_size, int tile_w, int tile_h,
+                              const int32_t* offsets, const int32_t* flatten_ids,
+                              const float* final_Ts, const int32_t* last_ids,
+                              const float* v_out_colors, const float* v_out_alphas /*nullable*/,
+                              float* v_packed, int absgrad, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 6. Inria-convention preprocess (the front half of the fused `GaussianRasterizer`).
  *    Replaces `diff_gaussian_rasterization.GaussianRasterizer.forward` up to the sort
@@ -257,6 +271,7 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               float tanfovx, float tanfovy, float scale_modifier,
                               const int32_t* radii, const uint8_t* clamped,
                               const float* v_means2d, const float* v_conics, const float* v_colors,
+                              int grad_stride /* 0: dense [N,2],[N,3],[N,3]; k: columns of one packed [N,k] buffer */,
                               float* v_means, float* v_scales /*nullable*/, float* v_quats /*nullable*/,
                               float* v_cov3d_precomp /*nullable*/, float* v_shs /*nullable*/,
                               float* v_colors_precomp /*nullable*/, float* v_means2d_ndc,
