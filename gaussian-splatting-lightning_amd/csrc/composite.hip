@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
     float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
-    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
     __shared__ int s_id[BCHUNK];
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
                 const float v = s_acc[e];
                 s_acc[e] = 0.f;
                 const int row = e / NV;
-                if (v != 0.f) atomicAdd(&v_packed[(int64_t)s_id[row] * NV + (e - row * NV)], v);
+                if (v != 0.f) atomicAdd(&v_packed[(int64_t)s_id[row] * packed_stride + (e - row * NV)], v);
             }
         } else if (t < cnt) {
             const int g = s_id[t];
@@ -497,17 +497,17 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* final_Ts, const int32_t* last_ids,
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
-                      hipStream_t s) {
+                      hipStream_t s, int packed_stride = 0) {
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
-                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
     else
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
-                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities);
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
     return check_launch("composite_bwd");
 }
 
@@ -592,7 +592,7 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
     return rc;
 }
 
-// Same backward, gradients delivered as ONE packed row per splat: v_packed [N, 6 + D (+2 with absgrad)] =
+// Same backward, gradients delivered as ONE packed row per splat: v_packed [N, packed_stride >= 6 + D (+2 with absgrad)] =
 // (dL/dx, dL/dy, dL/da, dL/db, dL/dc, dL/dopacity, dL/dcolour[D], [sum|dL/dx|, sum|dL/dy|]); must be zero-initialised.
 // The flush then issues atomics whose 64 lanes cover contiguous components of a few rows instead of 64 scattered
 // dwords per instruction (see kernel).  Consumers read the columns with a row stride (gspl_inria_preprocess_bwd's
@@ -604,10 +604,11 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
                                          const int32_t* offsets, const int32_t* flatten_ids,
                                          const float* final_Ts, const int32_t* last_ids,
                                          const float* v_out_colors, const float* v_out_alphas,
-                                         float* v_packed, int absgrad, void* stream) {
+                                         float* v_packed, int packed_stride, int absgrad, void* stream) {
     using namespace gspl;
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_bwd_packed: bad argument");
     if (rc != GSPL_OK) return rc;
+    if (packed_stride < 6 + D + (absgrad ? 2 : 0)) return fail_arg("composite_bwd_packed: packed_stride smaller than the row");
     if (n_isects == 0 || N == 0) return GSPL_OK;
     if (!means2d || !conics || !colors || !opacities || !offsets || !flatten_ids || !final_Ts || !last_ids || !v_out_colors || !v_packed)
         return fail_arg("composite_bwd_packed: NULL required pointer");
@@ -615,7 +616,7 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
     hipStream_t s = (hipStream_t)stream;
     const bool ag = absgrad != 0;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s)
+#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWDP) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWDP) }

@@ -24,6 +24,12 @@ from torch import Tensor
 from . import _lib as L
 
 _SUPPORTED_D = (1, 2, 3, 4, 8)
+_PACKED_ROW_STRIDE = int(__import__("os").environ.get("GSPL_PACKED_STRIDE", "0"))
+
+
+def _packed_row_stride(nv: int) -> int:
+    """Floats per packed gradient row of the compositing backward."""
+    return max(nv, _PACKED_ROW_STRIDE)
 
 
 def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -326,14 +332,15 @@ class _CompositeFn(torch.autograd.Function):
         dev = means2d.device
         n_isects = flatten_ids.shape[0]
         NV = 6 + D + (2 if absgrad else 0)
-        packed = torch.zeros((N, NV), dtype=torch.float32, device=dev)      # one memset, one row per splat
+        RS = _packed_row_stride(NV)
+        packed = torch.zeros((N, RS), dtype=torch.float32, device=dev)      # one memset, one row per splat
         if n_isects > 0 and N > 0:
             v_out = _grad_or_zeros(v_out, final_Ts.shape + (D,) if layout == L.GSPL_LAYOUT_HWC else (D,) + final_Ts.shape, dev)
             v_alphas = _f32c(v_alphas) if v_alphas is not None else None
             L.call("gspl_composite_bwd_packed",
                 N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
                 width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids), L.ptr(final_Ts), L.ptr(last_ids),
-                L.ptr(v_out), L.ptr(v_alphas), L.ptr(packed), 1 if absgrad else 0, L.stream())
+                L.ptr(v_out), L.ptr(v_alphas), L.ptr(packed), RS, 1 if absgrad else 0, L.stream())
         v_means2d, v_conics, v_opac, v_colors = packed[:, 0:2], packed[:, 2:5], packed[:, 5], packed[:, 6:6 + D]
         v_abs = packed[:, 6 + D:8 + D] if absgrad else None
         if absgrad:
@@ -521,12 +528,13 @@ class _InriaRasterizeFn(torch.autograd.Function):
         dev = means3D.device
         n_isects = flat.shape[0]
         v_out = _grad_or_zeros(v_out, (3, H, W), dev)
-        packed = torch.zeros((N, 9), dtype=torch.float32, device=dev)        # x y | a b c | opacity | r g b
+        RS = _packed_row_stride(9)
+        packed = torch.zeros((N, RS), dtype=torch.float32, device=dev)       # x y | a b c | opacity | r g b | pad
         if n_isects > 0:
             L.call("gspl_composite_bwd_packed",
                 N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
                 L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat), L.ptr(final_Ts), L.ptr(last_ids),
-                L.ptr(v_out), None, L.ptr(packed), 0, L.stream())
+                L.ptr(v_out), None, L.ptr(packed), RS, 0, L.stream())
         v_opac = packed[:, 5]
         v_means = torch.empty((N, 3), dtype=torch.float32, device=dev)
         v_ndc = torch.empty((N, 3), dtype=torch.float32, device=dev)
@@ -540,7 +548,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
             L.call("gspl_inria_preprocess_bwd", 
                 N, degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3d), L.ptr(sh),
                 L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tanfovx, tanfovy, scale_modifier,
-                L.ptr(radii), L.ptr(clamped), L.ptr(packed), L.ptr(packed, offset_bytes=8), L.ptr(packed, offset_bytes=24), 9,
+                L.ptr(radii), L.ptr(clamped), L.ptr(packed), L.ptr(packed, offset_bytes=8), L.ptr(packed, offset_bytes=24), RS,
                 L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_cp), L.ptr(v_ndc),
                 L.stream())
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings

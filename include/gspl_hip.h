@@ -223,7 +223,7 @@ int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int layout,
                        void* stream);
 
 /*    5b. Same backward with the gradients delivered as ONE packed row per splat:
- *      v_packed [N, 6 + D (+2 when absgrad != 0)] =
+ *      v_packed [N, packed_stride], packed_stride >= 6 + D (+2 when absgrad != 0); 16 makes every row one 64-B line:
  *        (dL/dx, dL/dy, dL/dconic a, b, c, dL/dopacity, dL/dcolour[0..D), [sum|dL/dx|, sum|dL/dy|]),
  *    zero-initialised by the caller.  One atomic instruction then covers contiguous components of a few
  *    splat rows instead of 64 scattered dwords. */
@@ -234,7 +234,8 @@ int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layo
                               const int32_t* offsets, const int32_t* flatten_ids,
                               const float* final_Ts, const int32_t* last_ids,
                               const float* v_out_colors, const float* v_out_alphas /*nullable*/,
-                              float* v_packed, int absgrad, void* stream);
+                              float* v_packed, int packed_stride /* floats per row, >= 6+D(+2) */, int absgrad,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 6. Inria-convention preprocess (the front half of the fused `GaussianRasterizer`).
