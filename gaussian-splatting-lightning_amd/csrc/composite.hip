@@ -58,6 +58,36 @@ __device__ __forceinline__ v2f_t eval_sigma2(v2f_t half_a, v2f_t b, v2f_t half_c
     return __builtin_elementwise_fma(half_a * dx, dx, __builtin_elementwise_fma(half_c * dy, dy, (b * dx) * dy));
 }
 
+// Exact test "can this splat reach alpha >= 1/255 at some pixel centre of the box [x0,x1] x [y0,y1]" (continuous box,
+// conservative margins): the x-span of (ellipse 1/2 d^T Q d <= tau) intersected with the band dy in [y0-my, y1-my] is
+// [left, right] with right = hx if the ellipse's rightmost point lies in the band, else the larger chord end at the band
+// edges (see binning.hip, row_span); the box is reachable iff that span meets [x0, x1].  About 21 % of the candidates
+// that pass the bounding-box test fail this one (measured), and with the predicated inner loop of the forward kernel
+// every candidate costs the same whether or not a pixel is touched.
+__device__ __forceinline__ bool box_reachable(float mx, float my, float a, float b, float c, float opacity,
+                                              float x0, float x1, float y0, float y1) {
+    const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
+    if (!(tau > 0.f)) return false;
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return true;     // not an ellipse: never cull
+    const float two_tau = 2.f * tau;
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    const float hy = __builtin_amdgcn_sqrtf(two_tau * a * rdet) * 1.0004f + 1e-3f;
+    float lo = y0 - my, hi = y1 - my;
+    if (hi < -hy || lo > hy) return false;
+    lo = fmaxf(lo, -hy); hi = fminf(hi, hy);
+    const float tta = two_tau * a;
+    const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * lo * lo));
+    const float rhi = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * hi * hi));
+    const float hx = __builtin_amdgcn_sqrtf(two_tau * c * rdet);
+    const float dys = b * __builtin_amdgcn_sqrtf(two_tau * rdet * __builtin_amdgcn_rcpf(c));
+    const float inv_a = __builtin_amdgcn_rcpf(a);
+    const float right = (-dys >= lo && -dys <= hi) ? hx : fmaxf((-b * lo + rlo) * inv_a, (-b * hi + rhi) * inv_a);
+    const float left = (dys >= lo && dys <= hi) ? -hx : fminf((-b * lo - rlo) * inv_a, (-b * hi - rhi) * inv_a);
+    const float eps = 2e-3f + 5e-4f * hx;
+    return (mx + right + eps >= x0) && (mx + left - eps <= x1);
+}
+
 __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isects,
                                            const int32_t* __restrict__ offsets, int& start, int& end) {
     start = offsets[tile];
@@ -134,8 +164,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             if (i < end) {
                 ca = conics[g * 3 + 0]; cb = conics[g * 3 + 1]; cc = conics[g * 3 + 2]; op = opacities[g];
                 xy = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
-                const float2 ext = splat_extent(ca, cb, cc, op);
-                cand = (xy.x + ext.x >= qx0) && (xy.x - ext.x <= qx1) && (xy.y + ext.y >= qy0) && (xy.y - ext.y <= qy1);
+                cand = box_reachable(xy.x, xy.y, ca, cb, cc, op, qx0, qx1, qy0, qy1);
             }
             const unsigned long long mask = __ballot(cand);
             const int ncand = __builtin_popcountll(mask);
