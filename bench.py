@@ -12,7 +12,8 @@ before the timed region.  `value` = images/s over all ranks; `ms_per_step` = wal
 Multi-GPU (driver launches `torch.distributed.run ... bench.py --gpus N`): one process per GPU over
 RCCL; Gaussians replicated, one camera per rank per step (weak scaling), and — as BASELINE.json's
 north_star prescribes — an all-reduce of the densification statistics only (per-Gaussian screen-space
-gradient norm: SUM, visibility count: SUM, max radius: MAX; 12 B/Gaussian).
+gradient norm: SUM, visibility count: SUM, max radius: MAX; 12 B/Gaussian), issued when a densification would
+consume them (every 100 steps, the reference's cadence) and once at the end of the timed region.
 
 Extra objects on the JSON line:
   roofline      dominant kernel = composite backward; achieved = algorithmic bytes (76*I + 20*P,
@@ -198,25 +199,31 @@ def main():
     denom = torch.zeros(N, device=dev)
     max_radii = torch.zeros(N, device=dev)
 
-    def full_step():
+    from gspl_amd import distributed as gdist
+    DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
+    counter = {"n": 0}
+
+    def full_step(force_reduce=False):
         st = step()
         with torch.no_grad():
             densification_stats(st, accum, denom, max_radii)
-            if dist is not None:
-                dist.all_reduce(accum, op=dist.ReduceOp.SUM)
-                dist.all_reduce(denom, op=dist.ReduceOp.SUM)
-                dist.all_reduce(max_radii, op=dist.ReduceOp.MAX)
+            counter["n"] += 1
+            # statistics are accumulated locally and made identical on all ranks when a densification would consume
+            # them (every DENSIFY_INTERVAL steps) — and once at the end of the timed region so that every run pays
+            # for at least one reduction
+            if dist is not None and (force_reduce or counter["n"] % DENSIFY_INTERVAL == 0):
+                gdist.reduce_densification_stats(accum, denom, max_radii)
         return st
 
     for _ in range(args.warmup):
-        full_step()
+        full_step(force_reduce=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     _lib.profile_start()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = full_step()
+    for k in range(args.steps):
+        st = full_step(force_reduce=(k == args.steps - 1))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
