@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--api", default="vanilla", choices=["vanilla", "gsplat"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="auto", help="workload name for the CPU baseline leg, or 'auto'")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (code-path test on one GPU)")
+    p.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
     return p.parse_args()
 
 
@@ -177,13 +179,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP extension is the only compute path)"
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     import gspl_amd  # noqa: F401
     from gspl_amd import _lib, synthetic
