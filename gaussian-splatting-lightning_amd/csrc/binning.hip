@@ -299,12 +299,15 @@ __global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, cons
 #ifndef GSPL_DS_SB
 #define GSPL_DS_SB 1024
 #endif
+#ifndef GSPL_DS_BITS
+#define GSPL_DS_BITS 8
+#endif
 #ifndef GSPL_DS_SI
 #define GSPL_DS_SI 4
 #endif
 using DepthSortCfg = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 8>, rocprim::kernel_config<GSPL_DS_SB, GSPL_DS_SI>, 8,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 8>, rocprim::kernel_config<GSPL_DS_SB, GSPL_DS_SI>, GSPL_DS_BITS,
                                         rocprim::block_radix_rank_algorithm::match>,
     32 * 1024>;
 using TileSortCfg = rocprim::radix_sort_config<
