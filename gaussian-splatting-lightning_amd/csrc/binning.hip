@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, int tile_size, int tile_w, int tile_h,
-    uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
+    uint64_t* __restrict__ tile_keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int g = (int)order[i];
@@ -261,22 +261,24 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(
         int c0, c1;
         row_columns<MODE>(sc, ty, tile_size, minx, maxx, c0, c1);
         for (int tx = c0; tx < c1; ++tx) {
-            tile_keys[off] = (uint32_t)(ty * tile_w + tx);
-            vals[off] = (uint32_t)g;
+            // one 8-byte record (tile id in the sorted high word, splat id riding along in the low word)
+            tile_keys[off] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | (uint32_t)g;
             ++off;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint32_t* __restrict__ keys, int n_tiles,
-                                                          int32_t* __restrict__ offsets) {
+__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint64_t* __restrict__ keys, int n_tiles,
+                                                          int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_isects) return;
-    const int cur = (int)keys[i];
+    const uint64_t rec = keys[i];
+    flatten_ids[i] = (int32_t)(uint32_t)rec;
+    const int cur = (int)(rec >> 32);
     if (i == 0) {
         for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
     } else {
-        const int prev = (int)keys[i - 1];
+        const int prev = (int)(keys[i - 1] >> 32);
         for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
     }
     if (i == n_isects - 1)
@@ -329,7 +331,7 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     if (e != hipSuccess) return check_hip(e, "bin: scan size query");
     e = rocprim::radix_sort_pairs<DepthSortCfg>(nullptr, s1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort1 size query");
-    e = rocprim::radix_sort_pairs<TileSortCfg>(nullptr, s2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 32, (hipStream_t)0);
+    e = rocprim::radix_sort_keys<TileSortCfg>(nullptr, s2, (const uint64_t*)nullptr, (uint64_t*)nullptr, ni, 32, 64, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort2 size query");
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -338,7 +340,7 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     w.scan_tmp_bytes = scan_tmp; w.scan_tmp_off = take(scan_tmp);
     w.sort1_tmp_bytes = s1; w.sort1_tmp_off = take(s1);
     w.total_count = off;
-    w.tkeys_off = take(4 * ni); w.tvals_off = take(4 * ni); w.tkeys2_off = take(4 * ni);
+    w.tkeys_off = take(8 * ni); w.tvals_off = w.tkeys_off; w.tkeys2_off = take(8 * ni);
     w.sort2_tmp_bytes = s2; w.sort2_tmp_off = take(s2);
     w.total = off;
     return GSPL_OK;
@@ -413,23 +415,22 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total) return fail_ws("bin_emit_sort");
     char* ws = (char*)workspace;
-    uint32_t* tkeys = (uint32_t*)(ws + w.tkeys_off);
-    uint32_t* tvals = (uint32_t*)(ws + w.tvals_off);
-    uint32_t* tkeys2 = (uint32_t*)(ws + w.tkeys2_off);
+    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
+    uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
     else
-        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
     rc = check_launch("bin_emit");
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort2_tmp_bytes;
     const int bits = key_bits(n_tiles) - 32;
-    hipError_t e = rocprim::radix_sort_pairs<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, tvals, (uint32_t*)flatten_ids, (size_t)n_isects, 0,
-                                             bits > 0 ? bits : 1, s);
+    hipError_t e = rocprim::radix_sort_keys<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, (size_t)n_isects, 32,
+                                            32 + (bits > 0 ? bits : 1), s);
     if (e != hipSuccess) return check_hip(e, "bin_emit_sort: tile sort");
     const int64_t g2 = (n_isects + 255) / 256;
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint32_t*)tkeys2, n_tiles, offsets);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint64_t*)tkeys2, n_tiles, offsets, flatten_ids);
     return check_launch("bin_offsets");
 }
 
