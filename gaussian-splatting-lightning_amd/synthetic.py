@@ -12,6 +12,9 @@ WORKLOADS = {
     "S-1080p-1M": dict(n=1_000_000, width=1920, height=1080, fx=1600.0),
     "S-800-100k": dict(n=100_000, width=800, height=800, fx=1111.1),
     "S-smoke": dict(n=20_000, width=320, height=208, fx=300.0),
+    # stress points (not headline): garden-like count at the reference's images_4 resolution, and 4K
+    "S-garden-6M": dict(n=6_000_000, width=1297, height=840, fx=961.4),
+    "S-4k-2M": dict(n=2_000_000, width=3840, height=2160, fx=3200.0),
 }
 
 

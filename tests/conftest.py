@@ -20,3 +20,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_extension():
+    """A fresh checkout has no libgspl_hip.so (built artefacts are git-ignored): build it once per session.
+    hipcc cross-compiles for gfx950 without a GPU (~30 s cold)."""
+    lib = os.path.join(ROOT, "gaussian-splatting-lightning_amd", "libgspl_hip.so")
+    if not os.path.exists(lib) and not os.environ.get("GSPL_HIP_LIB"):
+        import gspl_amd  # noqa: F401
+        from gspl_amd import _lib
+        _lib.build()
+    yield
