@@ -167,10 +167,13 @@ __device__ __forceinline__ SplatCull make_cull(float mx, float my, float a, floa
     s.kind = 1;
     const float two_tau = 2.f * (tau * 1.001f + 1e-3f);
     s.two_tau_a = two_tau * a;
-    s.inv_a = 1.f / a;
-    s.hx = sqrtf(two_tau * c / s.det);
-    s.hy = sqrtf(two_tau * a / s.det);
-    s.dys = b * sqrtf(two_tau / (s.det * c));
+    // hardware rcp / sqrt (1 ulp) instead of the ~10-instruction IEEE expansions: the margins absorb the difference,
+    // and the count and emit kernels call the very same code, so their per-splat tile counts agree bit for bit
+    const float rdet = __builtin_amdgcn_rcpf(s.det);
+    s.inv_a = __builtin_amdgcn_rcpf(a);
+    s.hx = __builtin_amdgcn_sqrtf(two_tau * c * rdet) * 1.0002f;
+    s.hy = __builtin_amdgcn_sqrtf(two_tau * a * rdet) * 1.0002f;
+    s.dys = b * __builtin_amdgcn_sqrtf(two_tau * rdet * __builtin_amdgcn_rcpf(c));
     return s;
 }
 // x-span (absolute pixel coordinates) reachable inside the band y in [y0, y1]; returns false when empty.
@@ -178,11 +181,11 @@ __device__ __forceinline__ bool row_span(const SplatCull& s, float y0, float y1,
     float lo = y0 - s.my, hi = y1 - s.my;
     if (hi < -s.hy || lo > s.hy) return false;
     lo = fmaxf(lo, -s.hy); hi = fminf(hi, s.hy);
-    const float rlo = sqrtf(fmaxf(0.f, s.two_tau_a - s.det * lo * lo));
-    const float rhi = sqrtf(fmaxf(0.f, s.two_tau_a - s.det * hi * hi));
+    const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.f, s.two_tau_a - s.det * lo * lo));
+    const float rhi = __builtin_amdgcn_sqrtf(fmaxf(0.f, s.two_tau_a - s.det * hi * hi));
     const float right = (-s.dys >= lo && -s.dys <= hi) ? s.hx : fmaxf((-s.b * lo + rlo) * s.inv_a, (-s.b * hi + rhi) * s.inv_a);
     const float left = (s.dys >= lo && s.dys <= hi) ? -s.hx : fminf((-s.b * lo - rlo) * s.inv_a, (-s.b * hi - rhi) * s.inv_a);
-    const float eps = 1e-3f + 1e-4f * s.hx;
+    const float eps = 2e-3f + 3e-4f * s.hx;
     xl = s.mx + left - eps;
     xr = s.mx + right + eps;
     return true;
@@ -199,8 +202,9 @@ __device__ __forceinline__ void row_columns(const SplatCull& s, int ty, int tile
     float xl, xr;
     if (!row_span(s, y0, y0 + span, xl, xr)) return;
     // tile tx covers pixel centres [tx*ts + off, tx*ts + off + span]
-    c0 = max(minx, (int)ceilf((xl - off - span) / ts));
-    c1 = min(maxx, (int)floorf((xr - off) / ts) + 1);
+    const float rts = 1.f / ts;      // tile sizes are powers of two: exact
+    c0 = max(minx, (int)ceilf((xl - off - span) * rts));
+    c1 = min(maxx, (int)floorf((xr - off) * rts) + 1);
     if (c1 < c0) c1 = c0;
 }
 
@@ -264,6 +268,124 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(
             // one 8-byte record (tile id in the sorted high word, splat id riding along in the low word)
             tile_keys[off] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | (uint32_t)g;
             ++off;
+        }
+    }
+}
+
+// Load-balanced emission.  The serial version above lets every lane write its own run of records (4-8 B stores 30-60 B
+// apart: partial-line writes, and one huge splat serialises a whole wave).  Here a wave owns 64 consecutive splats of
+// the depth order = one CONTIGUOUS output range; lanes walk that range in stride (coalesced 8-B stores) and find the
+// owner of each output slot by binary search over the wave's prefix counts in LDS, then the tile row by a short scan
+// of the owner's per-row prefix (splats with more than EMIT_ROWS rows are emitted cooperatively, lanes over rows).
+static constexpr int EMIT_ROWS = 8;
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane) {
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    return incl - v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bin_emit_lb_kernel(
+    int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
+    const float* __restrict__ conics, const float* __restrict__ opacities,
+    const int64_t* __restrict__ cum_sorted, int tile_size, int tile_w, int tile_h,
+    uint64_t* __restrict__ tile_keys) {
+    __shared__ int s_start[4][65];
+    __shared__ uint32_t s_gid[4][64];
+    __shared__ int s_row0[4][64];
+    __shared__ uint16_t s_c0[4][64][EMIT_ROWS];
+    __shared__ uint16_t s_pre[4][64][EMIT_ROWS + 1];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int wave_first = blockIdx.x * 256 + w * 64;
+    if (wave_first >= N) return;
+    const int64_t wave_base = (wave_first == 0) ? 0 : cum_sorted[wave_first - 1];
+    const int wave_last = min(N, wave_first + 64) - 1;
+    const int total = (int)(cum_sorted[wave_last] - wave_base);
+    if (total == 0) return;
+
+    int g = 0, cnt = 0, start = total, minx = 0, miny = 0, maxx = 0, maxy = 0;
+    float mx = 0.f, my = 0.f, ca = 1.f, cb = 0.f, cc = 1.f, op = 0.f;
+    if (i < N) {
+        const int64_t off = (i == 0) ? 0 : cum_sorted[i - 1];
+        start = (int)(off - wave_base);
+        cnt = (int)(cum_sorted[i] - off);
+        g = (int)order[i];
+        if (cnt > 0) {
+            mx = means2d[g * 2 + 0]; my = means2d[g * 2 + 1];
+            tile_rect<MODE>(mx, my, radii[g], tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+            if (conics) { ca = conics[g * 3 + 0]; cb = conics[g * 3 + 1]; cc = conics[g * 3 + 2]; op = opacities[g]; }
+        }
+    }
+    SplatCull sc;
+    sc.kind = 2;
+    if (conics && cnt > 0) sc = make_cull(mx, my, ca, cb, cc, op);
+    const int rows = maxy - miny;
+    const bool big = cnt > 0 && rows > EMIT_ROWS;
+    s_start[w][l] = start;
+    if (l == 0) s_start[w][64] = total;
+    s_gid[w][l] = (uint32_t)g;
+    s_row0[w][l] = miny;
+    if (cnt > 0 && !big) {
+        int acc = 0;
+        for (int r = 0; r < EMIT_ROWS; ++r) {
+            int c0 = 0, c1 = 0;
+            if (r < rows) row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
+            s_c0[w][l][r] = (uint16_t)c0;
+            s_pre[w][l][r] = (uint16_t)acc;
+            acc += c1 - c0;
+        }
+        s_pre[w][l][EMIT_ROWS] = (uint16_t)acc;
+    }
+    const unsigned long long big_mask = __ballot(big);
+    const unsigned long long any_mask = __ballot(cnt > 0);
+    // ---- phase A: every output slot of the wave's range, owners found by binary search -----------------------
+    for (int k = l; k < total; k += 64) {
+        int lo = 0, hi = 63;                       // largest o with s_start[o] <= k and a non-empty segment after it
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_start[w][mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        // lo may point at an empty segment sharing the start: the owner is the LAST lane with start <= k, which the
+        // search returns because empty segments before the owner have start == owner's start and come earlier
+        const int o = lo;
+        if ((big_mask >> o) & 1ull) continue;      // emitted in phase B
+        const int kk = k - s_start[w][o];
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < EMIT_ROWS; ++q) r += (kk >= (int)s_pre[w][o][q]) ? 1 : 0;
+        const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
+        const int ty = s_row0[w][o] + r;
+        tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
+    }
+    (void)any_mask;
+    // ---- phase B: splats spanning many tile rows, one at a time, lanes over rows ---------------------------
+    unsigned long long m = big_mask;
+    while (m) {
+        const int o = (int)__builtin_ctzll(m);
+        m &= m - 1;
+        SplatCull so;
+        so.mx = __shfl(sc.mx, o); so.my = __shfl(sc.my, o); so.a = __shfl(sc.a, o); so.b = __shfl(sc.b, o);
+        so.det = __shfl(sc.det, o); so.two_tau_a = __shfl(sc.two_tau_a, o); so.inv_a = __shfl(sc.inv_a, o);
+        so.hx = __shfl(sc.hx, o); so.hy = __shfl(sc.hy, o); so.dys = __shfl(sc.dys, o); so.kind = __shfl(sc.kind, o);
+        const int ominx = __shfl(minx, o), omaxx = __shfl(maxx, o), ominy = __shfl(miny, o), omaxy = __shfl(maxy, o);
+        const uint32_t og = (uint32_t)__shfl(g, o);
+        int64_t out = wave_base + __shfl(start, o);
+        for (int rbase = ominy; rbase < omaxy; rbase += 64) {
+            const int ty = rbase + l;
+            int c0 = 0, c1 = 0;
+            if (ty < omaxy) row_columns<MODE>(so, ty, tile_size, ominx, omaxx, c0, c1);
+            const int n = c1 - c0;
+            const int pre = wave_excl_scan(n, l);
+            for (int tx = c0; tx < c1; ++tx)
+                tile_keys[out + pre + (tx - c0)] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | og;
+            out += __shfl(pre + n, 63);
         }
     }
 }
@@ -419,9 +541,9 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
     uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
     else
-        hipLaunchKernelGGL(bin_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
     rc = check_launch("bin_emit");
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort2_tmp_bytes;
