@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -37,9 +37,9 @@ _SIGNATURES = {
     "gspl_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                  c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float,
-                                 _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                 _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "gspl_sh_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
-    "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),
     "gspl_isect_workspace_bytes": (c_size_t, [c_int, c_int64]),
     "gspl_isect_count": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "gspl_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),

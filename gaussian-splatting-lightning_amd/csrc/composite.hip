@@ -239,31 +239,77 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
 template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (ABS ? 2 : 0); };
 
 static constexpr int BCHUNK = 128;     // splats staged per round in the backward kernel (LDS footprint -> occupancy)
-static constexpr int BATCH = 8;         // splats per phase-2 batch (one per 8-lane group)
-static constexpr int PAIR_STRIDE = 72;  // float2 per batch slot: 64 lanes + pad -> conflict-free ds_read_b64 in phase 2
+#ifndef GSPL_BWD_BATCH
+#define GSPL_BWD_BATCH 8
+#endif
+static constexpr int BATCH = GSPL_BWD_BATCH;   // splats per phase-2 batch
+static constexpr int GROUP = 64 / BATCH;       // phase-2 lanes that share one splat (8 or 4)
+static constexpr int COLS = 8 / GROUP;         // pixel columns each of those lanes walks (1 or 2)
+static_assert(BATCH == 8 || BATCH == 16, "phase-2 batch must be 8 or 16");
 
-// Sum over each aligned group of 8 lanes (three fused v_add_f32_dpp); every lane of the group gets the sum.
-__device__ __forceinline__ float group8_sum(float v) {
+// Staged record in LDS (floats): x y a/2 b | c/2 opacity quadrant-mask - | colour[D] (padded to a multiple of 4):
+// one address register per candidate, the fields are fetched with immediate offsets (b128 + b64 [+ colour]).
+template <int D> struct BwdRec { static constexpr int STRIDE = 8 + ((D + 3) & ~3); };
+
+// Sum over each aligned group of GROUP lanes (fused v_add_f32_dpp); every lane of the group gets the sum.
+__device__ __forceinline__ float group_sum(float v) {
     v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+    if (GROUP == 8) v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
     return v;
 }
 
+// box_reachable for the four 8x8 quadrants of one tile at once (bit w = quadrant w = (x half) | (y half) << 1); the
+// per-splat terms (tau, extents, the tangent offset) are shared, the chord ends are per y band.  (tx0, ty0) is the
+// centre of the tile's first pixel.
+__device__ __forceinline__ unsigned quadrant_mask(float mx, float my, float a, float b, float c, float opacity, float tx0, float ty0) {
+    const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
+    if (!(tau > 0.f)) return 0u;
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return 0xFu;      // not an ellipse: never cull
+    const float two_tau = 2.f * tau;
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    const float hy = __builtin_amdgcn_sqrtf(two_tau * a * rdet) * 1.0004f + 1e-3f;
+    const float tta = two_tau * a;
+    const float hx = __builtin_amdgcn_sqrtf(two_tau * c * rdet);
+    const float dys = b * __builtin_amdgcn_sqrtf(two_tau * rdet * __builtin_amdgcn_rcpf(c));
+    const float inv_a = __builtin_amdgcn_rcpf(a);
+    const float eps = 2e-3f + 5e-4f * hx;
+    unsigned m = 0u;
+#pragma unroll
+    for (int band = 0; band < 2; ++band) {
+        const float y0 = ty0 + 8.f * (float)band;
+        float lo = y0 - my, hi = (y0 + 7.f) - my;
+        if (hi < -hy || lo > hy) continue;
+        lo = fmaxf(lo, -hy); hi = fminf(hi, hy);
+        const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * lo * lo));
+        const float rhi = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * hi * hi));
+        const float right = (-dys >= lo && -dys <= hi) ? hx : fmaxf((-b * lo + rlo) * inv_a, (-b * hi + rhi) * inv_a);
+        const float left = (dys >= lo && dys <= hi) ? -hx : fminf((-b * lo - rlo) * inv_a, (-b * hi - rhi) * inv_a);
+        const float xr = mx + right + eps, xl = mx + left - eps;
+        if (xr >= tx0 && xl <= tx0 + 7.f) m |= 1u << (2 * band);
+        if (xr >= tx0 + 8.f && xl <= tx0 + 15.f) m |= 2u << (2 * band);
+    }
+    return m;
+}
+
 // Backward, two phases per wave (no extra workgroup barriers):
-//   phase 1 (lane = pixel of the 8x8 quadrant): walk the candidate splats back-to-front, rebuild alpha and
-//            T, and emit just TWO numbers per (pixel, splat): fac = alpha*T (colour weight) and
-//            sp = dL/dsigma; they go to a wave-private LDS slab [slot][lane].
-//   phase 2 (lane = (splat slot s, pixel column q), after 8 active splats): each lane walks the 8 pixels of
-//            its column for ITS splat and accumulates the 9..16 gradient moments with plain FMAs (dx is
-//            constant down a column, so only sum(sp), sum(sp*dy), sum(sp*dy^2) and the colour sums are
-//            per-pixel work); a 3-step DPP reduction over the 8 columns finishes the quadrant.
+//   phase 1 (lane = pixel of the wave's 8x8 quadrant): walk the candidate splats back-to-front, rebuild alpha and T,
+//            and emit just TWO numbers per (pixel, splat): fac = alpha*T (colour weight) and sp = dL/dsigma.  The
+//            running "colour behind" enters dL/dalpha only through its dot product with dL/dout, so ONE scalar
+//            R = T_final (v_alpha_out - bg.v_out) - sum_behind fac_k (colour_k . v_out) replaces D accumulators:
+//            dL/dalpha = R/(1-alpha) + T (colour . v_out).   fac and sp go to a wave-private LDS slab, stored
+//            column-major ([slot][column*8 + row]) so that phase 2 reads a pixel column as two b128 loads.
+//   phase 2 (lane = (splat slot, pixel column[s]), after BATCH active splats): each lane walks the 8 pixels of its
+//            column(s) for ITS splat with packed fp32 math (rows in pairs) and accumulates the moments
+//            sum(sp), sum(sp dy), sum(sp dy^2) and the colour sums (dx is constant down a column); a 2- or 3-step
+//            DPP reduction over the lanes of the group finishes the quadrant.
 //   The per-(tile, splat) totals of the four waves meet in LDS (one ds_add_f32 per lane) and leave as ONE
 //   fp32 L2 atomic per value per (tile, splat).
-// VALU work per (pixel, splat) pair drops to ~33 (phase 1) + ~9 (phase 2) instructions, against ~110 for a
-// per-splat 64-lane reduction of every gradient component.
+// Staging evaluates the exact alpha >= 1/255 reachability of each quadrant once per (tile, splat) (quadrant_mask), so
+// a wave only visits splats that can touch its 64 pixels.
 #ifndef GSPL_BWD_WAVES
-#define GSPL_BWD_WAVES 5     // <= 96 VGPRs: 5 waves/SIMD (with the 29 KB LDS footprint: 5 blocks/CU); 6 spills
+#define GSPL_BWD_WAVES 5     // <= 96 VGPRs: 5 waves/SIMD (with the ~28 KB LDS footprint: 5 blocks/CU)
 #endif
 template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
 __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
@@ -277,28 +323,31 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
+    constexpr int RS = BwdRec<D>::STRIDE;
+    constexpr bool VO_REGS = COLS * 8 * D <= 24;      // dL/dout of the lane's phase-2 column(s) lives in registers
+    constexpr int SLAB = 2 * BATCH * 64;              // floats per wave: fac plane, sp plane
     __shared__ int s_id[BCHUNK];
-    __shared__ float2 s_xy[BCHUNK];
-    __shared__ float4 s_co[BCHUNK];       // a, b, c, opacity
-    __shared__ float2 s_ext[BCHUNK];
-    __shared__ float s_col[BCHUNK * D];
+    __shared__ __attribute__((aligned(16))) float s_rec[BCHUNK * RS];
     __shared__ float s_acc[BCHUNK * NV];
-    __shared__ float2 s_pair[4 * BATCH * PAIR_STRIDE];
-    float* s_vo = reinterpret_cast<float*>(s_pair);      // only used before the main loop (4*64*D floats <= slab size)
-    static_assert(4 * 64 * D <= 2 * 4 * BATCH * PAIR_STRIDE, "s_vo alias too small");
+    __shared__ __attribute__((aligned(16))) float s_slab[4 * SLAB];
+    __shared__ __attribute__((aligned(16))) float s_vo_keep[VO_REGS ? 4 : 4 * 64 * D];
+    static_assert(4 * 64 * D <= 4 * SLAB, "s_vo alias too small");
+    float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column][channel][row]; aliased onto the slab when only read before the main loop
     __shared__ int s_last;
 
     const int tile = xcd_remap(blockIdx.x, n_tiles);
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    const int px = (tile % tile_w) * TILE + (w & 1) * 8 + (l & 7);
-    const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
+    const int tx = (tile % tile_w) * TILE, ty = (tile / tile_w) * TILE;
+    const int px = tx + (w & 1) * 8 + (l & 7);
+    const int py = ty + (w >> 1) * 8 + (l >> 3);
     const bool inside = (px < width) && (py < height);
     const float pxf = (float)px + TR::kPixelCentre, pyf = (float)py + TR::kPixelCentre;
-    const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
-    const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
+    const float qx0 = (float)(tx + (w & 1) * 8) + TR::kPixelCentre;
+    const float qy0 = (float)(ty + (w >> 1) * 8) + TR::kPixelCentre;
     const int64_t pix = (int64_t)py * width + px;
-    const int ps = l >> 3, pq = l & 7;   // phase-2 role: splat slot, pixel column
-    float2* pair_w = s_pair + w * BATCH * PAIR_STRIDE;
+    const int tl = (l & 7) * 8 + (l >> 3);             // this pixel's slot in the column-major slab
+    const int ps = l / GROUP, pg = l % GROUP;          // phase-2 role: splat slot, lane within the splat's group
+    float* slab = s_slab + w * SLAB;
 
     int start, end;
     tile_range(tile, n_tiles, n_isects, offsets, start, end);
@@ -307,29 +356,35 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     const float T_final = inside ? final_Ts[pix] : 1.f;
     float T = T_final;
     float v_out[D];
-    float buffer[D];
     float bgdot = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        buffer[c] = 0.f;
         v_out[c] = 0.f;
         if (inside) v_out[c] = CHW ? v_out_colors[(int64_t)c * width * height + pix] : v_out_colors[pix * D + c];
         if (backgrounds) bgdot += backgrounds[c] * v_out[c];
-        s_vo[(w * 64 + l) * D + c] = v_out[c];
+        s_vo[((w * 8 + (l & 7)) * D + c) * 8 + (l >> 3)] = v_out[c];
     }
     const float v_out_a = (inside && v_out_alphas) ? v_out_alphas[pix] : 0.f;
-    // d(out)/d(alpha_i) carries  T_final/(1-alpha_i) * (v_out_alpha - bg . v_out)
-    const float tail = T_final * (v_out_a - bgdot);
+    // R: the part of dL/dalpha_i * (1 - alpha_i) that does not depend on splat i's own colour; starts as
+    // T_final (v_out_alpha - bg . v_out) and loses fac_k (colour_k . v_out) for every splat k walked (see above)
+    float R = T_final * (v_out_a - bgdot);
 
     if (t == 0) s_last = start;
     for (int k = t; k < BCHUNK * NV; k += 256) s_acc[k] = 0.f;
     __syncthreads();
-    // phase-2 view of dL/d(out): the 8 pixels of column pq (rows 0..7 of this wave's quadrant)
-    float vo2[8][D];
+    // phase-2 view of dL/d(out): rows in pairs, for the lane's column(s)
+    v2f vo2[VO_REGS ? COLS : 1][4][D];
+    if constexpr (VO_REGS) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int cc = 0; cc < COLS; ++cc)
 #pragma unroll
-        for (int c = 0; c < D; ++c) vo2[i][c] = s_vo[(w * 64 + i * 8 + pq) * D + c];
+            for (int c = 0; c < D; ++c) {
+                const float4* vp = reinterpret_cast<const float4*>(s_vo + ((w * 8 + pg * COLS + cc) * D + c) * 8);
+                const float4 v0 = vp[0], v1 = vp[1];
+                vo2[cc][0][c] = (v2f){v0.x, v0.y}; vo2[cc][1][c] = (v2f){v0.z, v0.w};
+                vo2[cc][2][c] = (v2f){v1.x, v1.y}; vo2[cc][3][c] = (v2f){v1.z, v1.w};
+            }
+    }
     // wave-max of `last`, then one LDS atomic per wave
     int wl = last;
 #pragma unroll
@@ -339,71 +394,91 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     const int block_last = s_last;
     const int wave_last = wl;
 
-    int nb = 0;          // splats waiting in the phase-2 batch (wave-uniform)
-    int batch_j = 0;     // lane b holds the staged slot index j of batch entry b
+    int nb = 0;                              // splats waiting in the phase-2 batch (wave-uniform)
+    int batch_j = 0;                         // lane b holds the staged slot index of batch entry b
 
     auto phase2 = [&](int count) {
+        __builtin_amdgcn_wave_barrier();
         float vals[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) vals[k] = 0.f;
         const int j = __builtin_amdgcn_ds_bpermute(ps << 2, batch_j);
         const bool live = ps < count;
-        float4 co = make_float4(0.f, 0.f, 0.f, 1.f);
+        float ca = 0.f, cb = 0.f, cc_ = 0.f, co_ = 1.f;
         if (live) {
-            const float2 xy = s_xy[j];
-            co = s_co[j];
-            const float dx = xy.x - (qx0 + (float)pq);
-            const float dy0 = xy.y - qy0;
-            float S0 = 0.f, Sy = 0.f, Syy = 0.f, ax = 0.f, ay = 0.f;
-            float rgb[D];
+            const float* rec = s_rec + j * RS;
+            const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 b
+            const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // c/2 opacity
+            ca = 2.f * r0.z; cb = r0.w; cc_ = 2.f * r1.x; co_ = r1.y;
+            const float dy0 = r0.y - qy0;
+            const v2f dy0v = {dy0, dy0};
+            float Sx = 0.f, Sxx = 0.f, Sxy = 0.f, S0 = 0.f, Sy = 0.f, ax = 0.f, ay = 0.f;
+            v2f syy2 = {0.f, 0.f};
+            v2f rgb2[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) rgb[c] = 0.f;
-            const float2* col = pair_w + ps * PAIR_STRIDE + pq;
+            for (int c = 0; c < D; ++c) rgb2[c] = (v2f){0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float2 fs = col[i * 8];                 // (fac, sp) of pixel (column pq, row i)
-                const float dy = dy0 - (float)i;
+            for (int cc = 0; cc < COLS; ++cc) {
+                const int colq = pg * COLS + cc;
+                const float dx = r0.x - (qx0 + (float)colq);
+                const float4* Fp = reinterpret_cast<const float4*>(slab + ps * 64 + colq * 8);
+                const float4* Sp = reinterpret_cast<const float4*>(slab + BATCH * 64 + ps * 64 + colq * 8);
+                const float4 f0 = Fp[0], f1 = Fp[1], q0 = Sp[0], q1 = Sp[1];
+                const v2f F2[4] = {{f0.x, f0.y}, {f0.z, f0.w}, {f1.x, f1.y}, {f1.z, f1.w}};
+                const v2f S2[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
+                v2f s02 = {0.f, 0.f}, sy2 = {0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < D; ++c) rgb[c] = fmaf(fs.x, vo2[i][c], rgb[c]);
-                S0 += fs.y;
-                const float tq = fs.y * dy;
-                Sy += tq;
-                Syy = fmaf(tq, dy, Syy);
-                if constexpr (ABS) {
-                    ax += fabsf(fs.y * (co.x * dx + co.y * dy));
-                    ay += fabsf(fs.y * (co.y * dx + co.z * dy));
+                for (int k = 0; k < 4; ++k) {
+                    const v2f dy2 = dy0v - (v2f){(float)(2 * k), (float)(2 * k + 1)};
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        v2f vo;
+                        if constexpr (VO_REGS) vo = vo2[cc][k][c];
+                        else vo = *reinterpret_cast<const v2f*>(s_vo + ((w * 8 + colq) * D + c) * 8 + 2 * k);
+                        rgb2[c] = __builtin_elementwise_fma(F2[k], vo, rgb2[c]);
+                    }
+                    s02 += S2[k];
+                    const v2f tq = S2[k] * dy2;
+                    sy2 += tq;
+                    syy2 = __builtin_elementwise_fma(tq, dy2, syy2);
+                    if constexpr (ABS) {
+                        ax += fabsf(S2[k].x * (ca * dx + cb * dy2.x)) + fabsf(S2[k].y * (ca * dx + cb * dy2.y));
+                        ay += fabsf(S2[k].x * (cb * dx + cc_ * dy2.x)) + fabsf(S2[k].y * (cb * dx + cc_ * dy2.y));
+                    }
                 }
+                const float s0c = s02.x + s02.y, syc = sy2.x + sy2.y;
+                const float sxc = s0c * dx;
+                S0 += s0c; Sy += syc;
+                Sx += sxc;
+                Sxx = fmaf(sxc, dx, Sxx);
+                Sxy = fmaf(syc, dx, Sxy);
             }
-            const float Sx = S0 * dx;
-            vals[0] = Sx;            // -> sum sp*dx
-            vals[1] = Sy;            // -> sum sp*dy
-            vals[2] = Sx * dx;       // -> sum sp*dx^2
-            vals[3] = Sy * dx;       // -> sum sp*dx*dy
-            vals[4] = Syy;           // -> sum sp*dy^2
-            vals[5] = S0;            // -> sum sp
+            vals[0] = Sx;                    // -> sum sp*dx
+            vals[1] = Sy;                    // -> sum sp*dy
+            vals[2] = Sxx;                   // -> sum sp*dx^2
+            vals[3] = Sxy;                   // -> sum sp*dx*dy
+            vals[4] = syy2.x + syy2.y;       // -> sum sp*dy^2
+            vals[5] = S0;                    // -> sum sp
 #pragma unroll
-            for (int c = 0; c < D; ++c) vals[6 + c] = rgb[c];
+            for (int c = 0; c < D; ++c) vals[6 + c] = rgb2[c].x + rgb2[c].y;
             if constexpr (ABS) { vals[6 + D] = ax; vals[7 + D] = ay; }
         }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) vals[k] = group8_sum(vals[k]);
+        for (int k = 0; k < NV; ++k) vals[k] = group_sum(vals[k]);
         // moments -> gradients (every lane of the group holds the group totals)
         const float Sx = vals[0], Sy = vals[1];
-        vals[0] = co.x * Sx + co.y * Sy;                     // dL/dx
-        vals[1] = co.y * Sx + co.z * Sy;                     // dL/dy
+        vals[0] = ca * Sx + cb * Sy;                         // dL/dx
+        vals[1] = cb * Sx + cc_ * Sy;                        // dL/dy
         vals[2] = 0.5f * vals[2];                            // dL/da
         vals[4] = 0.5f * vals[4];                            // dL/dc      (vals[3] = dL/db as is)
-        vals[5] = (co.w != 0.f) ? -vals[5] * __builtin_amdgcn_rcpf(co.w) : 0.f;     // dL/dopacity = sum(vis * v_alpha) = -sum(sp) / o
-        // lane q of the group adds value q (and q+8): two ds_add_f32 per batch, per-lane addresses
-        float mine = vals[0];
+        vals[5] = (co_ != 0.f) ? -vals[5] * __builtin_amdgcn_rcpf(co_) : 0.f;     // dL/dopacity = sum(vis * v_alpha) = -sum(sp) / o
+        // lane g of the group adds values g, g + GROUP, ...: per-lane addresses, ceil(NV / GROUP) ds_add_f32 per batch
 #pragma unroll
-        for (int k = 1; k < 8 && k < NV; ++k) mine = (pq == k) ? vals[k] : mine;
-        if (live && pq < NV) atomicAdd(&s_acc[j * NV + pq], mine);
-        if constexpr (NV > 8) {
-            float mine2 = vals[8];
+        for (int r = 0; r * GROUP < NV; ++r) {
+            float mine = vals[r * GROUP];
 #pragma unroll
-            for (int k = 9; k < NV; ++k) mine2 = (pq == k - 8) ? vals[k] : mine2;
-            if (live && pq + 8 < NV) atomicAdd(&s_acc[j * NV + 8 + pq], mine2);
+            for (int k = 1; k < GROUP && r * GROUP + k < NV; ++k) mine = (pg == k) ? vals[r * GROUP + k] : mine;
+            if (live && r * GROUP + pg < NV) atomicAdd(&s_acc[j * NV + r * GROUP + pg], mine);
         }
     };
 
@@ -414,34 +489,36 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
         if (t < cnt) {
             const int g = flatten_ids[hi - 1 - t];
             s_id[t] = g;
-            const float4 co = make_float4(conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
-            s_xy[t] = make_float2(means2d[g * 2 + 0], means2d[g * 2 + 1]);
-            s_co[t] = co;
-            s_ext[t] = splat_extent(co.x, co.y, co.z, co.w);
+            const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
+            const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+            const unsigned qm = quadrant_mask(mx, my, ca, cb, cc, op, (float)tx + TR::kPixelCentre, (float)ty + TR::kPixelCentre);
+            float* rec = s_rec + t * RS;
+            *reinterpret_cast<float4*>(rec) = make_float4(mx, my, 0.5f * ca, cb);
+            *reinterpret_cast<float4*>(rec + 4) = make_float4(0.5f * cc, op, __uint_as_float(qm), 0.f);
 #pragma unroll
-            for (int c = 0; c < D; ++c) s_col[t * D + c] = colors[(int64_t)g * D + c];
+            for (int c = 0; c < D; ++c) rec[8 + c] = colors[(int64_t)g * D + c];
         }
         __syncthreads();
         if (wave_last > lo) {
 #pragma unroll 1
             for (int kk = 0; kk < BCHUNK / 64; ++kk) {
                 const int slot = kk * 64 + l;
-                const float2 cxy = s_xy[slot];
-                const float2 ext = s_ext[slot];
-                // candidate: staged, reached by some pixel of this quadrant, and its alpha >= 1/255 box touches the quadrant
-                const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && (cxy.x + ext.x >= qx0) && (cxy.x - ext.x <= qx1) &&
-                                  (cxy.y + ext.y >= qy0) && (cxy.y - ext.y <= qy1);
+                const unsigned qm = __float_as_uint(s_rec[slot * RS + 6]);
+                // candidate: staged, reached by some pixel of this quadrant, and able to reach alpha >= 1/255 inside it
+                const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && ((qm >> w) & 1u);
                 unsigned long long mask = __ballot(cand);
                 while (mask) {
                     const int j = kk * 64 + (int)__builtin_ctzll(mask);
                     mask &= mask - 1;
                     const int idx = hi - 1 - j;
-                    const float2 xy = s_xy[j];
-                    const float4 co = s_co[j];
-                    const float dx = xy.x - pxf, dy = xy.y - pyf;
-                    const float sigma = eval_sigma(0.5f * co.x, co.y, 0.5f * co.z, dx, dy);
+                    const float* rec = s_rec + j * RS;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 b
+                    const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // c/2 opacity
+                    const float dx = r0.x - pxf, dy = r0.y - pyf;
+                    const float sigma = eval_sigma(r0.z, r0.w, r1.x, dx, dy);
                     const float vis = __expf(-sigma);
-                    const float alpha = fminf(TR::kAlphaMax, co.w * vis);
+                    const float raw = r1.y * vis;
+                    const float alpha = fminf(TR::kAlphaMax, raw);
                     const bool valid = (idx < last) && (sigma >= 0.f) && (alpha >= kAlphaMin);
                     if (!__any(valid)) continue;
                     float fac = 0.f, sp = 0.f;
@@ -450,17 +527,16 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
                         const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
                         T *= ra;                               // transmittance in front of this splat
                         fac = alpha * T;
-                        float v_alpha = tail * ra;
+                        float cdot = rec[8] * v_out[0];
 #pragma unroll
-                        for (int c = 0; c < D; ++c) {
-                            const float col = s_col[j * D + c];
-                            v_alpha += (col * T - buffer[c] * ra) * v_out[c];
-                            buffer[c] += col * fac;
-                        }
-                        if (!TR::kClampKillsGrad || (co.w * vis <= TR::kAlphaMax)) sp = -co.w * vis * v_alpha;
+                        for (int c = 1; c < D; ++c) cdot = fmaf(rec[8 + c], v_out[c], cdot);
+                        const float v_alpha = fmaf(cdot, T, R * ra);
+                        R = fmaf(-cdot, fac, R);
+                        if (!TR::kClampKillsGrad || (raw <= TR::kAlphaMax)) sp = -raw * v_alpha;
                     }
-                    pair_w[nb * PAIR_STRIDE + l] = make_float2(fac, sp);
-                    batch_j = (l == nb) ? j : batch_j;
+                    slab[nb * 64 + tl] = fac;
+                    slab[BATCH * 64 + nb * 64 + tl] = sp;
+                    batch_j = gspl_writelane_i32(j, nb, batch_j);     // lane nb remembers the staged slot (one v_writelane)
                     if (++nb == BATCH) { phase2(BATCH); nb = 0; }
                 }
             }

@@ -189,6 +189,9 @@ __device__ __forceinline__ void conic_bwd(float a, float b, float c, float vA, f
 }
 
 // ---- wave64 helpers -----------------------------------------------------------------------------
+// v_writelane_b32: lane `lane` (wave-uniform) of `old` is replaced by the wave-uniform `value` (this clang has no builtin
+// for it; the declaration binds the LLVM intrinsic by name).
+__device__ int gspl_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks,
     int width, int height, float scale_modifier, float eps2d,
     const int32_t* __restrict__ radii,
-    const float* __restrict__ v_means2d, const float* __restrict__ v_depths,
-    const float* __restrict__ v_conics, const float* __restrict__ v_compensations,
+    const float* __restrict__ v_means2d, int s2, const float* __restrict__ v_depths,
+    const float* __restrict__ v_conics, int s3, const float* __restrict__ v_compensations,
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 
         // conic -> (a, b, c)
         float va, vb, vc;
-        conic_bwd(a, b, cc, v_conics[idx * 3 + 0], v_conics[idx * 3 + 1], v_conics[idx * 3 + 2], va, vb, vc);
+        conic_bwd(a, b, cc, v_conics[idx * s3 + 0], v_conics[idx * s3 + 1], v_conics[idx * s3 + 2], va, vb, vc);
         // compensation = sqrt(max(det0/det, 0))
         if (v_compensations) {
             const float ratio = det0 / det;
@@ -170,11 +170,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         ewa_bwd<true>(pc, S6, c.W, c.fx, c.fy, ctx, va, vb, vc, vpc, G6);
         // 2D mean: x2d = fx * x / (z + 1e-6) + cx
         const float rz = 1.f / (pc[2] + 1e-6f);
-        const float vx2 = v_means2d[idx * 2 + 0], vy2 = v_means2d[idx * 2 + 1];
+        const float vx2 = v_means2d[idx * s2 + 0], vy2 = v_means2d[idx * s2 + 1];
         vpc[0] += vx2 * c.fx * rz;
         vpc[1] += vy2 * c.fy * rz;
         vpc[2] += -(vx2 * c.fx * pc[0] + vy2 * c.fy * pc[1]) * rz * rz;
-        vpc[2] += v_depths[idx];
+        if (v_depths) vpc[2] += v_depths[idx];
         // p_c = W p + t
 #pragma unroll
         for (int j = 0; j < 3; ++j) vp[j] = c.W[0 * 3 + j] * vpc[0] + c.W[1 * 3 + j] * vpc[1] + c.W[2 * 3 + j] * vpc[2];
@@ -226,25 +226,28 @@ extern "C" int gspl_project_bwd(int C, int N,
                                 const float* viewmats, const float* Ks,
                                 int width, int height, float scale_modifier, float eps2d,
                                 const int32_t* radii,
-                                const float* v_means2d, const float* v_depths, const float* v_conics,
+                                const float* v_means2d, int v_means2d_stride, const float* v_depths,
+                                const float* v_conics, int v_conics_stride,
                                 const float* v_compensations,
                                 float* v_means, float* v_scales, float* v_quats, void* stream) {
     if (C < 0 || N < 0 || width <= 0 || height <= 0) return gspl::fail_arg("project_bwd: bad sizes");
     if ((int64_t)C * N == 0) return GSPL_OK;
-    if (!means || !scales || !quats || !viewmats || !Ks || !radii || !v_means2d || !v_depths || !v_conics ||
+    if (!means || !scales || !quats || !viewmats || !Ks || !radii || !v_means2d || !v_conics ||
         !v_means || !v_scales || !v_quats)
         return gspl::fail_arg("project_bwd: NULL required pointer");
     const int64_t total = (int64_t)C * N;
     const int block = 256;
     const int64_t grid = (total + block - 1) / block;
+    const int s2 = v_means2d_stride > 0 ? v_means2d_stride : 2, s3 = v_conics_stride > 0 ? v_conics_stride : 3;
+    if ((s2 != 2 || s3 != 3) && C != 1) return gspl::fail_arg("project_bwd: strided gradients need C == 1");
     if (C == 1) {
         hipLaunchKernelGGL(gspl::project_bwd_kernel<false>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream,
                            C, N, means, scales, quats, viewmats, Ks, width, height, scale_modifier, eps2d, radii,
-                           v_means2d, v_depths, v_conics, v_compensations, v_means, v_scales, v_quats);
+                           v_means2d, s2, v_depths, v_conics, s3, v_compensations, v_means, v_scales, v_quats);
     } else {
         hipLaunchKernelGGL(gspl::project_bwd_kernel<true>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream,
                            C, N, means, scales, quats, viewmats, Ks, width, height, scale_modifier, eps2d, radii,
-                           v_means2d, v_depths, v_conics, v_compensations, v_means, v_scales, v_quats);
+                           v_means2d, s2, v_depths, v_conics, s3, v_compensations, v_means, v_scales, v_quats);
     }
     return gspl::check_launch("project_bwd");
 }

@@ -424,7 +424,8 @@ extern "C" int gspl_sh_bwd(int N, int degree, int n_coeffs,
                            const float* dirs, const float* origin,
                            const float* dc, int dc_stride, const float* rest, int rest_stride,
                            const uint8_t* mask, int flags, const uint8_t* clamped,
-                           const float* v_colors,
+                           const float* v_colors, int v_colors_stride,
                            float* v_dc, float* v_rest, float* v_dirs, void* stream) {
-    return gspl::sh_bwd_launch(N, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors, 3, v_dc, v_rest, v_dirs, stream);
+    return gspl::sh_bwd_launch(N, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors,
+                               v_colors_stride > 0 ? v_colors_stride : 3, v_dc, v_rest, v_dirs, stream);
 }

@@ -40,6 +40,29 @@ def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
     return t.contiguous()
 
 
+def _rows(g: Optional[Tensor], width: int):
+    """(tensor, row stride in floats) for a gradient whose rows may be columns of a wider packed buffer
+    (what the compositing backward hands out): consumed in place when the layout allows, copied otherwise.
+    Stride 0 means dense."""
+    if g is None:
+        return None, 0
+    if g.dtype != torch.float32:
+        g = g.float()
+    if g.is_contiguous():
+        return g, 0
+    if g.shape[-1] == width and g.stride(-1) == 1:
+        lead = [d for d in range(g.dim() - 1) if g.shape[d] != 1]
+        if len(lead) == 1 and g.stride(lead[0]) >= width:
+            return g, g.stride(lead[0])
+    return g.contiguous(), 0
+
+
+def _raw_ptr(t: Optional[Tensor]):
+    """Device pointer of a possibly non-contiguous tensor's first element."""
+    import ctypes
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
 def _grad_or_zeros(g: Optional[Tensor], like_shape, device) -> Tensor:
     if g is None:
         return torch.zeros(like_shape, dtype=torch.float32, device=device)
@@ -85,10 +108,16 @@ class _ProjectFn(torch.autograd.Function):
         width, height, scale_modifier, eps2d, calc_comp = ctx.cfg
         C, N = radii.shape
         dev = means.device
-        v_means2d = _grad_or_zeros(v_means2d, (C, N, 2), dev)
-        v_depths = _grad_or_zeros(v_depths, (C, N), dev)
-        v_conics = _grad_or_zeros(v_conics, (C, N, 3), dev)
-        v_comps = _grad_or_zeros(v_comps, (C, N), dev) if calc_comp else None
+        s2 = s3 = 0
+        if C == 1 and v_means2d is not None and v_conics is not None:
+            # columns of the compositing backward's packed rows are read in place
+            v_means2d, s2 = _rows(v_means2d, 2)
+            v_conics, s3 = _rows(v_conics, 3)
+        else:
+            v_means2d = _grad_or_zeros(v_means2d, (C, N, 2), dev)
+            v_conics = _grad_or_zeros(v_conics, (C, N, 3), dev)
+        v_depths = _f32c(v_depths) if v_depths is not None else None
+        v_comps = (_f32c(v_comps) if v_comps is not None and v_comps.numel() else None) if calc_comp else None
         alloc = torch.empty if C == 1 else torch.zeros
         v_means = alloc((N, 3), dtype=torch.float32, device=dev)
         v_scales = alloc((N, 3), dtype=torch.float32, device=dev)
@@ -96,7 +125,7 @@ class _ProjectFn(torch.autograd.Function):
         L.call("gspl_project_bwd", 
             C, N, L.ptr(means), L.ptr(scales), L.ptr(quats), L.ptr(viewmats), L.ptr(Ks),
             width, height, scale_modifier, eps2d, L.ptr(radii),
-            L.ptr(v_means2d), L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comps),
+            _raw_ptr(v_means2d), s2, L.ptr(v_depths), _raw_ptr(v_conics), s3, L.ptr(v_comps),
             L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.stream())
         return (v_means, v_scales, v_quats) + (None,) * 12
 
@@ -190,7 +219,7 @@ class _SHFn(torch.autograd.Function):
         degree, flags, merged, n_coeffs, dc_stride, rest_stride = ctx.cfg
         N = dirs.shape[0]
         dev = dirs.device
-        v_colors = _f32c(v_colors)
+        v_colors, vcs = _rows(v_colors, 3)
         need_dirs = ctx.needs_input_grad[1]
         v_dirs = torch.empty((N, 3), dtype=torch.float32, device=dev) if need_dirs else None
         v_dc = torch.empty_like(dc)
@@ -203,7 +232,7 @@ class _SHFn(torch.autograd.Function):
             v_rest_ptr = L.ptr(v_rest) if n_coeffs > 1 else None
             rest_ptr = L.ptr(rest) if n_coeffs > 1 else None
         L.call("gspl_sh_bwd", N, degree, n_coeffs, L.ptr(dirs), L.ptr(origin), L.ptr(dc), dc_stride, rest_ptr, rest_stride,
-                                L.ptr(mask8), flags, L.ptr(clamped), L.ptr(v_colors),
+                                L.ptr(mask8), flags, L.ptr(clamped), _raw_ptr(v_colors), vcs,
                                 L.ptr(v_dc), v_rest_ptr, L.ptr(v_dirs), L.stream())
         return None, v_dirs, None, v_dc, v_rest, None, None
 

@@ -79,14 +79,17 @@ int gspl_project_fwd(int C, int N,
 /*    Backward of the above (autograd of gsplat's op; reference enters it through
  *    `manual_backward`, internal/gaussian_splatting.py:380).  v_means/v_scales/v_quats are
  *    OVERWRITTEN when C == 1 and must be zero-initialised by the caller when C > 1
- *    (accumulated with atomics across cameras).  v_compensations nullable. */
+ *    (accumulated with atomics across cameras).  v_compensations / v_depths nullable.  The strides let the
+ *    columns of gspl_composite_bwd_packed's row buffer be consumed in place (C == 1 only). */
 int gspl_project_bwd(int C, int N,
                      const float* means, const float* scales, const float* quats,
                      const float* viewmats, const float* Ks,
                      int width, int height,
                      float scale_modifier, float eps2d,
                      const int32_t* radii,
-                     const float* v_means2d, const float* v_depths, const float* v_conics,
+                     const float* v_means2d, int v_means2d_stride /* floats per row; 0 = dense [.,2] */,
+                     const float* v_depths /*nullable = 0*/,
+                     const float* v_conics, int v_conics_stride /* 0 = dense [.,3] */,
                      const float* v_compensations /*nullable*/,
                      float* v_means, float* v_scales, float* v_quats,
                      void* stream);
@@ -122,7 +125,7 @@ int gspl_sh_bwd(int N, int degree, int n_coeffs,
                 const float* dirs, const float* origin /*nullable*/,
                 const float* dc, int dc_stride, const float* rest, int rest_stride,
                 const uint8_t* mask /*nullable*/, int flags, const uint8_t* clamped /*nullable*/,
-                const float* v_colors,
+                const float* v_colors, int v_colors_stride /* floats per row; 0 = dense [N,3] */,
                 float* v_dc, float* v_rest, float* v_dirs /*nullable*/,
                 void* stream);
 

@@ -3,6 +3,9 @@
 
   python tools/prof_summary.py stats  <kernel_stats.csv> <n_launches_per_kernel> [out.csv]
   python tools/prof_summary.py pmc    <counter_collection.csv> [out.csv]
+  python tools/prof_summary.py seq    <kernel_trace.csv> <anchor kernel substring> [out.txt]
+      time-ordered kernel sequence of the LAST step (between the last two launches of the anchor kernel):
+      start offset, duration, idle gap before the launch (us)
 """
 import collections
 import csv
@@ -40,6 +43,26 @@ def stats(path, launches, out=None):
     print("\n".join(lines[:34] + lines[-1:]))
 
 
+def seq(path, anchor, out=None):
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+    a, b = idx[-2], idx[-1]
+    t0 = int(rows[a]["Start_Timestamp"])
+    lines, prev_end, busy = [], None, 0
+    for r in rows[a:b]:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = 0.0 if prev_end is None else (st - prev_end) / 1e3
+        lines.append("%9.1f %8.1f %7.1f  %s" % ((st - t0) / 1e3, (en - st) / 1e3, gap, short(r["Kernel_Name"])))
+        prev_end = en
+        busy += en - st
+    span = (int(rows[b]["Start_Timestamp"]) - t0) / 1e3
+    lines.append("step span %.1f us, kernels busy %.1f us, %d launches" % (span, busy / 1e3, b - a))
+    text = "start_us   dur_us  gap_us  kernel\n" + "\n".join(lines) + "\n"
+    if out:
+        open(out, "w").write(text)
+    print(text)
+
+
 def pmc(path, out=None):
     rows = list(csv.DictReader(open(path)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -57,7 +80,9 @@ def pmc(path, out=None):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "seq":
+        seq(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
