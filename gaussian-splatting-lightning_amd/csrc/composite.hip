@@ -19,8 +19,8 @@
 //     per-splat gradient values over the wave with DPP row operations (no LDS traffic), combines
 //     the four waves with one-lane LDS atomics, and issues ONE fp32 L2 atomic per value per
 //     (tile, splat) — 36 B per intersection, the algorithmic minimum of SURVEY.md §8d.
-//   * workgroup -> tile mapping is XCD-aware (xcd_remap): each XCD's L2 serves a contiguous band
-//     of tiles, whose lists overlap heavily.
+//   * workgroup -> tile mapping is XCD-aware (xcd_remap): runs of consecutive tiles (whose lists overlap heavily)
+//     share an XCD's L2, and the runs are dealt round-robin so that every XCD sees the same mix of dense and sparse rows.
 // Roofline: algorithmic bytes fwd 40*I + 20*P, bwd 76*I + 20*P (+8*I with absgrad); the kernels
 // are VALU/exp-bound under that model — bench.py reports both fractions.
 #include "gspl_device.h"
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     __shared__ __attribute__((aligned(16))) int s_pos[FLIST];      // list index (base + lane) of each candidate
     __shared__ __attribute__((aligned(16))) float s_col[FLIST * D];
 
-    const int unit = xcd_remap(blockIdx.x, 4 * n_tiles);     // (tile, quadrant), contiguous per XCD
+    const int unit = xcd_remap(blockIdx.x, 4 * n_tiles, 4 * GSPL_XCD_RUN);     // (tile, quadrant): the four quadrants of a tile stay on one XCD
     const int tile = unit >> 2, w = unit & 3, l = threadIdx.x;
     const int px = (tile % tile_w) * TILE + (w & 1) * 8 + (l & 7);
     const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
@@ -584,6 +584,285 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, TWO PIXELS PER LANE.  A workgroup is 2 waves per tile; wave w owns the 16x8 half tile of rows [8w, 8w+8)
+// and lane l carries pixel A = (column l&7, row l>>3) and pixel B = (column 8 + (l&7), same row).  Every per-pixel
+// quantity is a 2-vector {A, B}, so the whole phase-1 chain runs on packed fp32 instructions (v_pk_add/mul/fma_f32:
+// the splat's wave-uniform parameters are broadcast with op_sel), each LDS record read feeds 128 pixels instead of
+// 64, and the scalar loop bookkeeping per (tile, splat) halves.  dy is shared by the two pixels (same row).
+// Pixels that do not take a splat (alpha < 1/255, behind their last contributor, outside the image) run with
+// alpha = 0, which leaves T, R and the emitted (fac, sp) exactly neutral (1/(1-0) = 1), so no exec masking is needed.
+// Phase 2: lane = (slot s of P2_SLOTS, column c of the half tile's 16), 8 rows per lane, row_sum (16-lane DPP) finish.
+#ifndef GSPL_BWD2_CHUNK
+#define GSPL_BWD2_CHUNK 64
+#endif
+#ifndef GSPL_BWD2_WAVES
+#define GSPL_BWD2_WAVES 5
+#endif
+static constexpr int B2CHUNK = GSPL_BWD2_CHUNK;   // splats staged per round
+static constexpr int P2_SLOTS = 4;                // splats per phase-2 batch (16 lanes each)
+
+template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
+__global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
+    int n_tiles, int tile_w, int width, int height, int64_t n_isects,
+    const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+    const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
+    float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride) {
+    using TR = ModeTraits<MODE>;
+    constexpr int NV = BwdVals<D, ABS>::N;
+    constexpr int RS = BwdRec<D>::STRIDE;
+    constexpr bool VO_REGS = D <= 4;                  // dL/dout of the lane's phase-2 column lives in registers
+    constexpr int SLAB = 2 * P2_SLOTS * 128;          // floats per wave: fac plane, sp plane, [slot][column*8 + row]
+    static_assert(NV <= 16, "one ds_add round per batch");
+    __shared__ int s_id[B2CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_rec[B2CHUNK * RS];
+    __shared__ float s_acc[B2CHUNK * NV];
+    __shared__ __attribute__((aligned(16))) float s_slab[2 * SLAB];
+    __shared__ __attribute__((aligned(16))) float s_vo_keep[VO_REGS ? 4 : 2 * 128 * D];
+    static_assert(!VO_REGS || 2 * 128 * D <= 2 * SLAB, "s_vo alias too small");
+    float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column 0..15][channel][row]
+    __shared__ int s_last;
+
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int tx = (tile % tile_w) * TILE, ty = (tile / tile_w) * TILE;
+    const int pxA = tx + (l & 7), pxB = pxA + 8;
+    const int py = ty + w * 8 + (l >> 3);
+    const bool insideA = (pxA < width) && (py < height), insideB = (pxB < width) && (py < height);
+    const v2f pxf2 = {(float)pxA + TR::kPixelCentre, (float)pxB + TR::kPixelCentre};
+    const float pyf = (float)py + TR::kPixelCentre;
+    const float hx0 = (float)tx + TR::kPixelCentre;                 // centre of the half tile's first column
+    const float hy0 = (float)(ty + w * 8) + TR::kPixelCentre;       // ... and first row
+    const int64_t pixA = (int64_t)py * width + pxA, pixB = pixA + 8;
+    const int tl = (l & 7) * 8 + (l >> 3);             // pixel A's place in the column-major slab (B: + 64)
+    const int ps = l >> 4, pc = l & 15;                // phase-2 role: splat slot, column of the half tile
+    float* slab = s_slab + w * SLAB;
+
+    int start, end;
+    tile_range(tile, n_tiles, n_isects, offsets, start, end);
+
+    const int lastA = insideA ? last_ids[pixA] : start, lastB = insideB ? last_ids[pixB] : start;
+    v2f T2 = {insideA ? final_Ts[pixA] : 1.f, insideB ? final_Ts[pixB] : 1.f};
+    v2f vo[D];
+    v2f bgdot = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        vo[c] = (v2f){0.f, 0.f};
+        if (insideA) vo[c].x = CHW ? v_out_colors[(int64_t)c * width * height + pixA] : v_out_colors[pixA * D + c];
+        if (insideB) vo[c].y = CHW ? v_out_colors[(int64_t)c * width * height + pixB] : v_out_colors[pixB * D + c];
+        if (backgrounds) bgdot += backgrounds[c] * vo[c];
+        s_vo[((w * 16 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].x;
+        s_vo[((w * 16 + 8 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].y;
+    }
+    const v2f v_out_a = {(insideA && v_out_alphas) ? v_out_alphas[pixA] : 0.f, (insideB && v_out_alphas) ? v_out_alphas[pixB] : 0.f};
+    // R: see composite_bwd_kernel
+    v2f R2 = T2 * (v_out_a - bgdot);
+
+    if (t == 0) s_last = start;
+    for (int k = t; k < B2CHUNK * NV; k += 128) s_acc[k] = 0.f;
+    __syncthreads();
+    v2f vo2[VO_REGS ? 4 : 1][VO_REGS ? D : 1];         // phase-2 view of dL/dout: column pc, rows in pairs
+    if constexpr (VO_REGS) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const float4* vp = reinterpret_cast<const float4*>(s_vo + ((w * 16 + pc) * D + c) * 8);
+            const float4 v0 = vp[0], v1 = vp[1];
+            vo2[0][c] = (v2f){v0.x, v0.y}; vo2[1][c] = (v2f){v0.z, v0.w};
+            vo2[2][c] = (v2f){v1.x, v1.y}; vo2[3][c] = (v2f){v1.z, v1.w};
+        }
+    }
+    int wl = max(lastA, lastB);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl = max(wl, __shfl_xor(wl, off));
+    if (l == 0) atomicMax(&s_last, wl);
+    __syncthreads();
+    const int block_last = s_last;
+    const int wave_last = wl;
+
+    int nb = 0;                              // splats waiting in the phase-2 batch (wave-uniform)
+    int batch_j = 0;                         // lane b holds the staged slot index of batch entry b
+
+    auto phase2 = [&](int count) {
+        __builtin_amdgcn_wave_barrier();
+        float vals[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vals[k] = 0.f;
+        const int j = __builtin_amdgcn_ds_bpermute(ps << 2, batch_j);
+        const bool live = ps < count;
+        float ca = 0.f, cb = 0.f, cc_ = 0.f, co_ = 1.f;
+        if (live) {
+            const float* rec = s_rec + j * RS;
+            const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 c/2
+            const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // b opacity
+            ca = 2.f * r0.z; cb = r1.x; cc_ = 2.f * r0.w; co_ = r1.y;
+            const float dx = r0.x - (hx0 + (float)pc);
+            const float dy0 = r0.y - hy0;
+            const v2f dy0v = {dy0, dy0};
+            const float4* Fp = reinterpret_cast<const float4*>(slab + ps * 128 + pc * 8);
+            const float4* Sp = reinterpret_cast<const float4*>(slab + P2_SLOTS * 128 + ps * 128 + pc * 8);
+            const float4 f0 = Fp[0], f1 = Fp[1], q0 = Sp[0], q1 = Sp[1];
+            const v2f F2[4] = {{f0.x, f0.y}, {f0.z, f0.w}, {f1.x, f1.y}, {f1.z, f1.w}};
+            const v2f S2[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
+            v2f s02 = {0.f, 0.f}, sy2 = {0.f, 0.f}, syy2 = {0.f, 0.f};
+            v2f rgb2[D];
+            float ax = 0.f, ay = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) rgb2[c] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v2f dy2 = dy0v - (v2f){(float)(2 * k), (float)(2 * k + 1)};
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    v2f vv;
+                    if constexpr (VO_REGS) vv = vo2[k][c];
+                    else vv = *reinterpret_cast<const v2f*>(s_vo + ((w * 16 + pc) * D + c) * 8 + 2 * k);
+                    rgb2[c] = __builtin_elementwise_fma(F2[k], vv, rgb2[c]);
+                }
+                s02 += S2[k];
+                const v2f tq = S2[k] * dy2;
+                sy2 += tq;
+                syy2 = __builtin_elementwise_fma(tq, dy2, syy2);
+                if constexpr (ABS) {
+                    ax += fabsf(S2[k].x * (ca * dx + cb * dy2.x)) + fabsf(S2[k].y * (ca * dx + cb * dy2.y));
+                    ay += fabsf(S2[k].x * (cb * dx + cc_ * dy2.x)) + fabsf(S2[k].y * (cb * dx + cc_ * dy2.y));
+                }
+            }
+            const float S0 = s02.x + s02.y, Sy = sy2.x + sy2.y;
+            const float Sx = S0 * dx;
+            vals[0] = Sx;                    // -> sum sp*dx
+            vals[1] = Sy;                    // -> sum sp*dy
+            vals[2] = Sx * dx;               // -> sum sp*dx^2
+            vals[3] = Sy * dx;               // -> sum sp*dx*dy
+            vals[4] = syy2.x + syy2.y;       // -> sum sp*dy^2
+            vals[5] = S0;                    // -> sum sp
+#pragma unroll
+            for (int c = 0; c < D; ++c) vals[6 + c] = rgb2[c].x + rgb2[c].y;
+            if constexpr (ABS) { vals[6 + D] = ax; vals[7 + D] = ay; }
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vals[k] = row_sum(vals[k]);
+        const float Sx = vals[0], Sy = vals[1];
+        vals[0] = ca * Sx + cb * Sy;                         // dL/dx
+        vals[1] = cb * Sx + cc_ * Sy;                        // dL/dy
+        vals[2] = 0.5f * vals[2];                            // dL/da
+        vals[4] = 0.5f * vals[4];                            // dL/dc      (vals[3] = dL/db as is)
+        vals[5] = (co_ != 0.f) ? -vals[5] * __builtin_amdgcn_rcpf(co_) : 0.f;     // dL/dopacity = -sum(sp) / o
+        float mine = vals[0];
+#pragma unroll
+        for (int k = 1; k < NV; ++k) mine = (pc == k) ? vals[k] : mine;
+        if (live && pc < NV) atomicAdd(&s_acc[j * NV + pc], mine);
+    };
+
+    for (int hi = block_last; hi > start; hi -= B2CHUNK) {
+        const int lo = max(start, hi - B2CHUNK);
+        const int cnt = hi - lo;
+        if (t < cnt) {
+            const int g = flatten_ids[hi - 1 - t];
+            s_id[t] = g;
+            const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
+            const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+            const unsigned qm = quadrant_mask(mx, my, ca, cb, cc, op, (float)tx + TR::kPixelCentre, (float)ty + TR::kPixelCentre);
+            float* rec = s_rec + t * RS;
+            *reinterpret_cast<float4*>(rec) = make_float4(mx, my, 0.5f * ca, 0.5f * cc);
+            *reinterpret_cast<float4*>(rec + 4) = make_float4(cb, op, __uint_as_float(qm), 0.f);
+#pragma unroll
+            for (int c = 0; c < D; ++c) rec[8 + c] = colors[(int64_t)g * D + c];
+        }
+        __syncthreads();
+        if (wave_last > lo) {
+#pragma unroll 1
+            for (int kk = 0; kk < (B2CHUNK + 63) / 64; ++kk) {
+                const int slot = kk * 64 + l;
+                const unsigned qm = (slot < B2CHUNK) ? __float_as_uint(s_rec[slot * RS + 6]) : 0u;
+                // candidate: staged, in front of some pixel's last contributor, and able to reach alpha >= 1/255 in this half tile
+                const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && ((qm >> (2 * w)) & 3u);
+                unsigned long long mask = __ballot(cand);
+                while (mask) {
+                    const int j = kk * 64 + (int)__builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int idx = hi - 1 - j;
+                    const float* rec = s_rec + j * RS;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 c/2
+                    const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // b opacity
+                    // sigma, bit-identical per element to eval_sigma: fma(ha dx, dx, fma(hc dy, dy, (b dx) dy))
+                    const v2f dx2 = (v2f){r0.x, r0.x} - pxf2;
+                    const float dy = r0.y - pyf;
+                    const float hcdy = r0.w * dy;
+                    const v2f dy2 = {dy, dy};
+                    const v2f inner = __builtin_elementwise_fma((v2f){hcdy, hcdy}, dy2, ((v2f){r1.x, r1.x} * dx2) * dy2);
+                    const v2f sigma2 = __builtin_elementwise_fma((v2f){r0.z, r0.z} * dx2, dx2, inner);
+                    const v2f arg2 = sigma2 * (v2f){-1.4426950408889634f, -1.4426950408889634f};
+                    const v2f vis2 = {__builtin_amdgcn_exp2f(arg2.x), __builtin_amdgcn_exp2f(arg2.y)};
+                    const v2f raw2 = (v2f){r1.y, r1.y} * vis2;
+                    const float aA = fminf(TR::kAlphaMax, raw2.x), aB = fminf(TR::kAlphaMax, raw2.y);
+                    const bool validA = (idx < lastA) && (sigma2.x >= 0.f) && (aA >= kAlphaMin);
+                    const bool validB = (idx < lastB) && (sigma2.y >= 0.f) && (aB >= kAlphaMin);
+                    if (!__any(validA || validB)) continue;
+                    const v2f a2 = {validA ? aA : 0.f, validB ? aB : 0.f};
+                    v2f rw2;       // o * vis where the pixel takes a gradient through alpha, else 0
+                    if (TR::kClampKillsGrad) rw2 = (v2f){(validA && raw2.x <= TR::kAlphaMax) ? raw2.x : 0.f, (validB && raw2.y <= TR::kAlphaMax) ? raw2.y : 0.f};
+                    else rw2 = (v2f){validA ? raw2.x : 0.f, validB ? raw2.y : 0.f};
+                    const v2f om2 = (v2f){1.f, 1.f} - a2;
+                    const v2f ra2 = {__builtin_amdgcn_rcpf(om2.x), __builtin_amdgcn_rcpf(om2.y)};
+                    T2 *= ra2;                                 // transmittance in front of this splat
+                    const v2f fac2 = a2 * T2;
+                    v2f cdot2 = (v2f){rec[8], rec[8]} * vo[0];
+#pragma unroll
+                    for (int c = 1; c < D; ++c) cdot2 = __builtin_elementwise_fma((v2f){rec[8 + c], rec[8 + c]}, vo[c], cdot2);
+                    const v2f v_alpha2 = __builtin_elementwise_fma(cdot2, T2, R2 * ra2);
+                    R2 = __builtin_elementwise_fma(-cdot2, fac2, R2);
+                    const v2f sp2 = -rw2 * v_alpha2;
+                    float* F = slab + nb * 128 + tl;
+                    F[0] = fac2.x; F[64] = fac2.y;
+                    F[P2_SLOTS * 128] = sp2.x; F[P2_SLOTS * 128 + 64] = sp2.y;
+                    batch_j = gspl_writelane_i32(j, nb, batch_j);
+                    if (++nb == P2_SLOTS) { phase2(P2_SLOTS); nb = 0; }
+                }
+            }
+            if (nb) { phase2(nb); nb = 0; }
+        }
+        __syncthreads();
+        if constexpr (PACKED) {
+            float* __restrict__ v_packed = v_means2d;
+            for (int e = t; e < cnt * NV; e += 128) {
+                const float v = s_acc[e];
+                s_acc[e] = 0.f;
+                const int row = e / NV;
+                if (v != 0.f) atomicAdd(&v_packed[(int64_t)s_id[row] * packed_stride + (e - row * NV)], v);
+            }
+        } else if (t < cnt) {
+            const int g = s_id[t];
+            float v[NV];
+            bool any_nz = false;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                v[k] = s_acc[t * NV + k];
+                s_acc[t * NV + k] = 0.f;
+                any_nz = any_nz || (v[k] != 0.f);
+            }
+            if (any_nz) {
+                atomicAdd(&v_means2d[g * 2 + 0], v[0]);
+                atomicAdd(&v_means2d[g * 2 + 1], v[1]);
+                atomicAdd(&v_conics[g * 3 + 0], v[2]);
+                atomicAdd(&v_conics[g * 3 + 1], v[3]);
+                atomicAdd(&v_conics[g * 3 + 2], v[4]);
+                atomicAdd(&v_opacities[g], v[5]);
+#pragma unroll
+                for (int c = 0; c < D; ++c) atomicAdd(&v_colors[(int64_t)g * D + c], v[6 + c]);
+                if constexpr (ABS) {
+                    atomicAdd(&v_means2d_abs[g * 2 + 0], v[6 + D]);
+                    atomicAdd(&v_means2d_abs[g * 2 + 1], v[7 + D]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int D, int MODE, bool CHW>
 static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
@@ -603,6 +882,19 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
                       hipStream_t s, int packed_stride = 0) {
+#ifdef GSPL_BWD_V4
+    if (absgrad)
+        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
+                           n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
+                           offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
+    else
+        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(128), 0, s,
+                           n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
+                           offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
+    return check_launch("composite_bwd");
+#endif
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,

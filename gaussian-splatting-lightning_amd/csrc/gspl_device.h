@@ -216,14 +216,21 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md,
-// "Workgroup dispatch"), so consecutive tiles are dealt to different L2s.  Remap so that each XCD
-// owns a contiguous band of tiles (neighbouring tiles share splat records -> L2 hits).  Speed only.
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int per = n >> 3;          // full rounds
-    const int body = per << 3;
+// XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"),
+// and each XCD runs its workgroups in increasing b.  Units are dealt to the XCDs in RUNS of `run` consecutive units
+// (run r -> XCD r % 8): neighbouring tiles of a run share splat records (L2 hits inside the XCD), while all eight XCDs
+// sweep the image top to bottom together, so an image whose splats are concentrated in some rows (the usual case)
+// loads every XCD alike.  (Giving each XCD one contiguous eighth of the image, the first version of this mapping,
+// left the XCDs that own the dense middle rows running long after the others had finished.)  Speed only.
+#ifndef GSPL_XCD_RUN
+#define GSPL_XCD_RUN 32
+#endif
+__device__ __forceinline__ int xcd_remap(int b, int n, int run = GSPL_XCD_RUN) {
+    const int group = 8 * run;
+    const int body = (n / group) * group;
     if (b >= body) return b;         // tail handled in place
-    return (b & 7) * per + (b >> 3);
+    const int x = b & 7, i = b >> 3; // XCD, position in that XCD's queue
+    return ((i / run) * 8 + x) * run + (i % run);
 }
 
 }  // namespace gspl
