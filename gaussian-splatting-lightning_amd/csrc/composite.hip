@@ -757,11 +757,17 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         if (live && pc < NV) atomicAdd(&s_acc[j * NV + pc], mine);
     };
 
+    // the staged Gaussian ids are fetched one round ahead, so that a round's gather does not wait for them
+    int g_next = (block_last - 1 - t >= start && t < B2CHUNK) ? flatten_ids[block_last - 1 - t] : 0;
     for (int hi = block_last; hi > start; hi -= B2CHUNK) {
         const int lo = max(start, hi - B2CHUNK);
         const int cnt = hi - lo;
+        const int g = g_next;
+        {
+            const int i_next = hi - B2CHUNK - 1 - t;
+            if (i_next >= start && t < B2CHUNK) g_next = flatten_ids[i_next];
+        }
         if (t < cnt) {
-            const int g = flatten_ids[hi - 1 - t];
             s_id[t] = g;
             const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
             const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
@@ -882,7 +888,7 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
                       hipStream_t s, int packed_stride = 0) {
-#ifdef GSPL_BWD_V4
+#ifndef GSPL_BWD_V2      // default: the two-pixels-per-lane kernel; -DGSPL_BWD_V2 selects the one-pixel-per-lane kernel (A/B builds)
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
