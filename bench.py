@@ -81,6 +81,7 @@ def make_step(api, dev, wl, cam, tensors):
     else:
         vm = cam["world_to_camera"].T.contiguous().to(dev)
         center = cam["camera_center"].to(dev)
+        grad_scale = torch.tensor([0.5 * W, 0.5 * H], device=dev)      # what the renderers return as viewspace_points_grad_scale
 
         def step():
             for t in tensors:
@@ -88,12 +89,16 @@ def make_step(api, dev, wl, cam, tensors):
             xys, depths, radii, conics, comp, tiles, _ = ops.project_gaussians(
                 m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
             xys.retain_grad()
+            opac = o * comp[:, None]
+            # same order as HipGSplatRenderer.forward: count half of the binning, SH, emit half, compositing
+            pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, 16, conics=conics, opacities=opac)
             rgbs = ops.sh_view_colors(3, m, center, c, None, radii > 0)
-            img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, o * comp[:, None], H, W, 16, bg)
+            img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
+                                          isects=ops.bin_gaussians_end(pending))
             loss = (img.permute(2, 0, 1) - target).abs().mean()
             loss.backward()
             state["vs_grad"], state["radii"], state["loss"] = xys.grad, radii, loss
-            state["grad_scale"] = (0.5 * W, 0.5 * H)
+            state["grad_scale"] = grad_scale
             return state
     return step
 
@@ -103,7 +108,7 @@ def densification_stats(state, accum, denom, max_radii):
     (internal/density_controllers/vanilla_density_controller.py:101-123)."""
     g = state["vs_grad"][:, :2]
     if state["grad_scale"] is not None:
-        g = g * torch.tensor(state["grad_scale"], device=g.device)
+        g = g * state["grad_scale"]
     vis = state["radii"] > 0
     accum.add_(torch.where(vis, g.norm(dim=-1), torch.zeros((), device=g.device)))
     denom.add_(vis.to(denom.dtype))

@@ -16,13 +16,14 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
 GSPL_LAYOUT_HWC = 0
 GSPL_LAYOUT_CHW = 1
 GSPL_SH_ADD_HALF_CLAMP = 1
+GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
 
 
 class HipLibraryError(RuntimeError):
@@ -56,7 +57,7 @@ _SIGNATURES = {
                                           c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_float, c_float, c_float,
-                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+                                          _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_float, c_float, c_float,
                                           _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

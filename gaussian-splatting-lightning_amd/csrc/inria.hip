@@ -215,9 +215,10 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                                          int width, int height, int tile_size,
                                          float tanfovx, float tanfovy, float scale_modifier,
                                          int32_t* radii, float* means2d, float* depths, float* conics,
-                                         float* colors, uint8_t* clamped, float* cov3d, void* stream) {
+                                         float* colors, uint8_t* clamped, float* cov3d, int phases, void* stream) {
     using namespace gspl;
     if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0) return fail_arg("inria_preprocess_fwd: bad sizes");
+    if ((phases & ~GSPL_INRIA_ALL) || phases == 0) return fail_arg("inria_preprocess_fwd: bad phases");
     if (N == 0) return GSPL_OK;
     if (!means || !viewmatrix || !projmatrix || !radii || !means2d || !depths || !conics || !colors || !clamped || !cov3d)
         return fail_arg("inria_preprocess_fwd: NULL required pointer");
@@ -227,11 +228,14 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
         return fail_arg("inria_preprocess_fwd: bad degree / n_coeffs");
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
-    hipLaunchKernelGGL(inria_preprocess_fwd_kernel, dim3(grid), dim3(256), 0, s,
-                       N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
-                       tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d);
-    int rc = check_launch("inria_preprocess_fwd");
-    if (rc != GSPL_OK) return rc;
+    if (phases & GSPL_INRIA_GEOMETRY) {
+        hipLaunchKernelGGL(inria_preprocess_fwd_kernel, dim3(grid), dim3(256), 0, s,
+                           N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
+                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d);
+        int rc = check_launch("inria_preprocess_fwd");
+        if (rc != GSPL_OK) return rc;
+    }
+    if (!(phases & GSPL_INRIA_COLOURS)) return GSPL_OK;
     if (colors_precomp) {
         hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, colors_precomp, 3, colors, clamped);
         return check_launch("inria_preprocess_fwd(colors_precomp)");

@@ -155,6 +155,36 @@ def fully_fused_projection(
     return radii, means2d, depths, conics, (comps if calc_compensations else None)
 
 
+_CONSTS: dict = {}
+
+
+def _const_row(dev):
+    """[0, 0, 0, 1] on `dev` (last row of a world->camera matrix), built once per device."""
+    k = ("row", dev)
+    if k not in _CONSTS:
+        _CONSTS[k] = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    return _CONSTS[k]
+
+
+def _const_scalars(dev):
+    k = ("01", dev)
+    if k not in _CONSTS:
+        _CONSTS[k] = (torch.zeros((), dtype=torch.float32, device=dev), torch.ones((), dtype=torch.float32, device=dev))
+    return _CONSTS[k]
+
+
+def _cached_intrinsics(fx: float, fy: float, cx: float, cy: float, dev):
+    """K [3,3] on `dev` for python-float intrinsics; a training run cycles through a fixed camera set, so the
+    host->device copy happens once per camera instead of once per step."""
+    k = ("K", fx, fy, cx, cy, dev)
+    K = _CONSTS.get(k)
+    if K is None:
+        if len(_CONSTS) > 4096:
+            _CONSTS.clear()
+        K = _CONSTS[k] = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+    return K
+
+
 def project_gaussians(
         means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor, viewmat: Tensor,
         fx, fy, cx, cy, img_height: int, img_width: int, block_width: int,
@@ -163,17 +193,20 @@ def project_gaussians(
     Returns (xys [N,2], depths [N], radii [N] i32, conics [N,3], compensation [N], num_tiles_hit [N] i32,
     cov3d).  cov3d is returned as None: no in-scope renderer of the reference consumes it."""
     dev = means3d.device
-    vm = torch.eye(4, dtype=torch.float32, device=dev)
-    vm[: viewmat.shape[0], :] = viewmat.to(torch.float32)
+    N = means3d.shape[0]
+    viewmat = viewmat.to(torch.float32)
+    vm = viewmat if viewmat.shape[0] == 4 else torch.cat([viewmat, _const_row(dev)], dim=0)
     if isinstance(fx, Tensor):
-        K = torch.zeros(3, 3, dtype=torch.float32, device=dev)
-        K[0, 0], K[1, 1], K[0, 2], K[1, 2], K[2, 2] = fx, fy, cx, cy, 1.0
+        z, one = _const_scalars(dev)
+        K = torch.stack([fx.reshape(()).float(), z, cx.reshape(()).float(), z, fy.reshape(()).float(), cy.reshape(()).float(),
+                         z, z, one]).view(3, 3)
     else:
-        K = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]], dtype=torch.float32, device=dev)
+        K = _cached_intrinsics(float(fx), float(fy), float(cx), float(cy), dev)
     radii, xys, depths, conics, comps, tiles = _ProjectFn.apply(
         means3d, scales, quats, vm[None], K[None], img_width, img_height, block_width, glob_scale,
         filter_2d_kernel_size, clip_thresh, 1e10, 0.0, True, True)
-    return xys[0], depths[0], radii[0], conics[0], comps[0], tiles[0], None
+    # views, not selects: their backward is a view of the incoming gradient (select_backward allocates zeros + copies)
+    return xys.view(N, 2), depths.view(N), radii.view(N), conics.view(N, 3), comps.view(N), tiles.view(N), None
 
 
 # =============================================================================================
@@ -426,6 +459,74 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     return out[None], alphas[None, ..., None]
 
 
+class _PendingBins:
+    """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
+    way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
+    __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "offsets", "tile_w", "tile_h",
+                 "block_width", "host_count", "event", "dev")
+
+
+_PINNED_WORDS: list = []      # free list of pinned int64 words for the count read-back
+
+
+def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, img_width: int, block_width: int = 16,
+                        mode: int = L.GSPL_MODE_GSPLAT, conics: Optional[Tensor] = None,
+                        opacities: Optional[Tensor] = None) -> _PendingBins:
+    """First half of `bin_gaussians`: per-Gaussian tile counts, depth order and their scan (`gspl_bin_count`), then an
+    ASYNCHRONOUS copy of the total to the host.  Work that does not depend on the lists (the SH kernel) can be launched
+    before `bin_gaussians_end`, so the device is busy while the host waits for the one number that sizes the sort."""
+    if block_width != 16:
+        raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
+    lib = L.lib()
+    p = _PendingBins()
+    p.block_width = block_width
+    p.tile_w, p.tile_h = (img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width
+    p.mode = mode
+    p.means2d, depths = _f32c(xys.detach()), _f32c(depths.detach())
+    p.radii = radii.to(torch.int32).contiguous()
+    p.N = N = p.means2d.shape[0]
+    p.dev = dev = p.means2d.device
+    p.cull_c = p.cull_o = None
+    if conics is not None and opacities is not None:
+        p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
+    p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
+    p.order = p.cum = p.host_count = p.event = None
+    if N > 0:
+        p.order = torch.empty((N,), dtype=torch.int32, device=dev)
+        p.cum = torch.empty((N,), dtype=torch.int64, device=dev)
+        ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
+        if ws_bytes == 0:
+            raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
+               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(ws), ws_bytes, L.stream())
+        # the one host read-back of the pipeline (sizes the sort buffers)
+        p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((1,), dtype=torch.int64).pin_memory()
+        p.host_count.copy_(p.cum[-1:], non_blocking=True)
+        p.event = torch.cuda.Event()
+        p.event.record()
+    return p
+
+
+def bin_gaussians_end(p: _PendingBins):
+    """Second half: waits for the count, then emits and sorts the (tile, Gaussian) lists.
+    Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
+    lib = L.lib()
+    n_isects = 0
+    if p.N > 0:
+        p.event.synchronize()
+        n_isects = int(p.host_count[0])
+        _PINNED_WORDS.append(p.host_count)
+    N, dev = p.N, p.dev
+    flat = torch.empty((n_isects,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.gspl_bin_workspace_bytes(max(N, 1), n_isects) if n_isects > 0 else 0
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+    L.call("gspl_bin_emit_sort", N, p.mode, L.ptr(p.means2d) if N else None, L.ptr(p.radii) if N else None,
+           L.ptr(p.cull_c), L.ptr(p.cull_o), L.ptr(p.order), L.ptr(p.cum), p.block_width, p.tile_w, p.tile_h, n_isects,
+           L.ptr(flat) if n_isects else None, L.ptr(p.offsets), L.ptr(ws), ws_bytes, L.stream())
+    return flat, p.offsets
+
+
 def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, img_width: int, block_width: int = 16,
                   mode: int = L.GSPL_MODE_GSPLAT, conics: Optional[Tensor] = None, opacities: Optional[Tensor] = None):
     """Binning half of `rasterize_gaussians`, exposed so that several compositing passes over the same
@@ -433,38 +534,7 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, i
     With `conics` and `opacities` (the ones the compositing call will use) tile hits that cannot reach
     alpha >= 1/255 anywhere in the tile are not listed — same images and gradients, ~40 % shorter lists.
     Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
-    if block_width != 16:
-        raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
-    tile_w, tile_h = (img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width
-    lib = L.lib()
-    means2d, depths = _f32c(xys.detach()), _f32c(depths.detach())
-    radii = radii.to(torch.int32).contiguous()
-    N = means2d.shape[0]
-    dev = means2d.device
-    cull_c = cull_o = None
-    if conics is not None and opacities is not None:
-        cull_c, cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
-    offsets = torch.empty((tile_w * tile_h,), dtype=torch.int32, device=dev)
-    n_isects = 0
-    order = cum = None
-    if N > 0:
-        order = torch.empty((N,), dtype=torch.int32, device=dev)
-        cum = torch.empty((N,), dtype=torch.int64, device=dev)
-        ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
-        if ws_bytes == 0:
-            raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        L.call("gspl_bin_count", N, mode, L.ptr(means2d), L.ptr(radii), L.ptr(depths), L.ptr(cull_c), L.ptr(cull_o),
-               block_width, tile_w, tile_h,
-               L.ptr(order), L.ptr(cum), L.ptr(ws), ws_bytes, L.stream())
-        n_isects = int(cum[-1].item())      # the one host read-back of the pipeline (sizes the sort buffers)
-    flat = torch.empty((n_isects,), dtype=torch.int32, device=dev)
-    ws_bytes = lib.gspl_bin_workspace_bytes(max(N, 1), n_isects) if n_isects > 0 else 0
-    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-    L.call("gspl_bin_emit_sort", N, mode, L.ptr(means2d) if N else None, L.ptr(radii) if N else None,
-           L.ptr(cull_c), L.ptr(cull_o), L.ptr(order), L.ptr(cum), block_width, tile_w, tile_h, n_isects,
-           L.ptr(flat) if n_isects else None, L.ptr(offsets), L.ptr(ws), ws_bytes, L.stream())
-    return flat, offsets
+    return bin_gaussians_end(bin_gaussians_begin(xys, depths, radii, img_height, img_width, block_width, mode, conics, opacities))
 
 
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
@@ -523,14 +593,19 @@ class _InriaRasterizeFn(torch.autograd.Function):
         cov3d = torch.empty((N, 6), dtype=torch.float32, device=dev)
         tile = 16
         tile_w, tile_h = (W + tile - 1) // tile, (H + tile - 1) // tile
-        if N > 0:
-            L.call("gspl_inria_preprocess_fwd", 
-                N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
-                L.ptr(sh), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
-                float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
-                L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
-                L.stream())
-        flat, offsets = bin_gaussians(means2d, depths, radii, H, W, tile, mode=L.GSPL_MODE_INRIA, conics=conics, opacities=opac)
+        def preprocess(phases):
+            if N > 0:
+                L.call("gspl_inria_preprocess_fwd",
+                       N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
+                       L.ptr(sh), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
+                       float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
+                       L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
+                       phases, L.stream())
+        # geometry -> count/depth sort -> (count travels to the host while the SH kernel runs) -> emit/tile sort
+        preprocess(L.GSPL_INRIA_GEOMETRY)
+        pending = bin_gaussians_begin(means2d, depths, radii, H, W, tile, mode=L.GSPL_MODE_INRIA, conics=conics, opacities=opac)
+        preprocess(L.GSPL_INRIA_COLOURS)
+        flat, offsets = bin_gaussians_end(pending)
         n_isects = flat.shape[0]
         out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         alphas = torch.empty((H, W), dtype=torch.float32, device=dev)

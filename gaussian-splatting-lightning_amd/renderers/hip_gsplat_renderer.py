@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, viewspace_grad_scale
 
 DEFAULT_BLOCK_SIZE: int = 16
 DEFAULT_ANTI_ALIASED_STATUS: bool = True
@@ -89,9 +89,15 @@ class HipGSplatRenderer(Renderer):
 
         # sorted once, shared by every pass that composites with `opacities`; tile hits that cannot reach alpha >= 1/255
         # are not listed.  Passes with other opacities ("hard" depth) bin for themselves inside rasterize_gaussians.
-        isects = ops.bin_gaussians(xys, depths, radii, H, W, self.block_size, conics=conics, opacities=opacities)
+        # The count half is launched here; the emit half after the SH kernel, which keeps the device busy while the host
+        # waits for the number of intersections.
+        pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, self.block_size, conics=conics, opacities=opacities)
+        isects = None
 
         def rasterize(feats, background, return_alpha=False, opac=opacities, absgrad=False):
+            nonlocal isects
+            if isects is None:
+                isects = ops.bin_gaussians_end(pending)
             return ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, feats, opac, img_height=H, img_width=W,
                                            block_width=self.block_size, background=background, return_alpha=return_alpha,
                                            absgrad=absgrad, isects=isects if opac is opacities else None)
@@ -135,7 +141,7 @@ class HipGSplatRenderer(Renderer):
             "exp_depth": exp_depth_im, "exp_depth_inverted": exp_depth_inverted_im, "inverse_depth": inverse_depth_im,
             "hard_depth": hard_depth_im, "hard_inverse_depth": hard_inverse_depth_im,
             "viewspace_points": xys,
-            "viewspace_points_grad_scale": 0.5 * torch.tensor([[W, H]]).to(xys),
+            "viewspace_points_grad_scale": viewspace_grad_scale(W, H, xys),
             "visibility_filter": radii > 0,
             "radii": radii,
         }
@@ -159,7 +165,7 @@ class HipGSplatRenderer(Renderer):
         rgb = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, img_height=H, img_width=W,
                                       block_width=block_size, background=bg_color, return_alpha=False)
         return {"render": rgb.permute(2, 0, 1), "viewspace_points": xys,
-                "viewspace_points_grad_scale": 0.5 * torch.tensor([[W, H]]).to(xys),
+                "viewspace_points_grad_scale": viewspace_grad_scale(W, H, xys),
                 "visibility_filter": radii > 0, "radii": radii}
 
     @staticmethod
@@ -192,7 +198,7 @@ class HipGSplatRenderer(Renderer):
         rgb = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, img_height=H, img_width=W,
                                       block_width=block_size, background=bg_color, return_alpha=False)
         return {"render": rgb.permute(2, 0, 1), "viewspace_points": xys,
-                "viewspace_points_grad_scale": 0.5 * torch.tensor([[W, H]]).to(xys),
+                "viewspace_points_grad_scale": viewspace_grad_scale(W, H, xys),
                 "visibility_filter": radii > 0, "radii": radii}
 
     def get_available_outputs(self) -> Dict:

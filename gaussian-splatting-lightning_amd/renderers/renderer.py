@@ -82,3 +82,19 @@ def camera_hw(viewpoint_camera):
         else:
             w, h = w.item(), h.item()
     return int(w), int(h)
+
+
+_GRAD_SCALES: dict = {}
+
+
+def viewspace_grad_scale(W: int, H: int, like: torch.Tensor) -> torch.Tensor:
+    """0.5 * [[W, H]] on `like`'s device/dtype (what the reference builds every call with
+    `0.5 * torch.tensor([[W, H]]).to(xys)`, gsplat_renderer.py:196): cached, so that a step does not pay a
+    host->device copy for a constant."""
+    k = (W, H, like.device, like.dtype)
+    t = _GRAD_SCALES.get(k)
+    if t is None:
+        if len(_GRAD_SCALES) > 256:
+            _GRAD_SCALES.clear()
+        t = _GRAD_SCALES[k] = (0.5 * torch.tensor([[W, H]])).to(like)
+    return t

@@ -250,7 +250,11 @@ int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layo
  *      (internal/cameras/cameras.py:147-189); campos [3] device.
  *    Outputs: radii i32 [N], means2d [N,2] (pixels, integer-centred), depths [N], conics [N,3],
  *             colors [N,3], clamped u8 [N,3], cov3d [N,6] (saved for backward).
+ *    `phases` selects the geometry kernel, the colour kernel (which reads the radii the geometry
+ *    kernel wrote), or both; a caller that bins between the two hides the sort-size read-back of
+ *    gspl_bin_count behind the colour kernel.
  * ---------------------------------------------------------------------------------------- */
+enum { GSPL_INRIA_GEOMETRY = 1, GSPL_INRIA_COLOURS = 2, GSPL_INRIA_ALL = 3 };
 int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                               const float* means, const float* scales /*nullable*/,
                               const float* quats /*nullable*/, const float* cov3d_precomp /*nullable*/,
@@ -261,6 +265,7 @@ int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                               float tanfovx, float tanfovy, float scale_modifier,
                               int32_t* radii, float* means2d, float* depths, float* conics,
                               float* colors, uint8_t* clamped, float* cov3d,
+                              int phases /* GSPL_INRIA_GEOMETRY | GSPL_INRIA_COLOURS */,
                               void* stream);
 /*    Backward.  v_means2d is the composite kernel's pixel-unit gradient [N,2]; the returned
  *    v_means2d_ndc [N,3] is what the reference exposes as `viewspace_points.grad`
