@@ -237,44 +237,15 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
     keys[g] = n > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;      // splats without tiles sort to the end
 }
 
-__global__ __launch_bounds__(256) void bin_gather_counts_kernel(int N, const uint32_t* __restrict__ order,
-                                                                const int32_t* __restrict__ counts, int64_t* __restrict__ counts_sorted) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) counts_sorted[i] = counts[order[i]];
-}
+// counts[order[i]] as int64: the input "array" of the scan over per-splat tile counts in depth order (no gather pass)
+struct GatherCount {
+    const int32_t* counts;
+    __device__ int64_t operator()(uint32_t g) const { return (int64_t)counts[g]; }
+};
 
-template <int MODE>
-__global__ __launch_bounds__(256) void bin_emit_kernel(
-    int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
-    const float* __restrict__ conics, const float* __restrict__ opacities,
-    const int64_t* __restrict__ cum_sorted, int tile_size, int tile_w, int tile_h,
-    uint64_t* __restrict__ tile_keys) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int g = (int)order[i];
-    const int radius = radii[g];
-    if (radius <= 0) return;
-    int minx, miny, maxx, maxy;
-    const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
-    tile_rect<MODE>(mx, my, radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
-    int64_t off = (i == 0) ? 0 : cum_sorted[i - 1];
-    SplatCull sc;
-    sc.kind = 2;
-    if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
-    for (int ty = miny; ty < maxy; ++ty) {
-        int c0, c1;
-        row_columns<MODE>(sc, ty, tile_size, minx, maxx, c0, c1);
-        for (int tx = c0; tx < c1; ++tx) {
-            // one 8-byte record (tile id in the sorted high word, splat id riding along in the low word)
-            tile_keys[off] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | (uint32_t)g;
-            ++off;
-        }
-    }
-}
-
-// Load-balanced emission.  The serial version above lets every lane write its own run of records (4-8 B stores 30-60 B
+// Load-balanced emission.  A lane-per-splat loop would let every lane write its own run of records (stores 30-60 B
 // apart: partial-line writes, and one huge splat serialises a whole wave).  Here a wave owns 64 consecutive splats of
-// the depth order = one CONTIGUOUS output range; lanes walk that range in stride (coalesced 8-B stores) and find the
+// the depth order = one CONTIGUOUS output range; lanes walk that range in stride (coalesced stores of the 2-byte tile ids and 4-byte splat ids) and find the
 // owner of each output slot by binary search over the wave's prefix counts in LDS, then the tile row by a short scan
 // of the owner's per-row prefix (splats with more than EMIT_ROWS rows are emitted cooperatively, lanes over rows).
 static constexpr int EMIT_ROWS = 8;
@@ -294,7 +265,7 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, int tile_size, int tile_w, int tile_h,
-    uint64_t* __restrict__ tile_keys) {
+    uint16_t* __restrict__ rec_tile, uint32_t* __restrict__ rec_gid) {
     __shared__ int s_start[4][65];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_row0[4][64];
@@ -362,7 +333,8 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
         for (int q = 1; q < EMIT_ROWS; ++q) r += (kk >= (int)s_pre[w][o][q]) ? 1 : 0;
         const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
         const int ty = s_row0[w][o] + r;
-        tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
+        rec_tile[wave_base + k] = (uint16_t)(ty * tile_w + tx);
+        rec_gid[wave_base + k] = s_gid[w][o];
     }
     (void)any_mask;
     // ---- phase B: splats spanning many tile rows, one at a time, lanes over rows ---------------------------
@@ -383,24 +355,24 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
             if (ty < omaxy) row_columns<MODE>(so, ty, tile_size, ominx, omaxx, c0, c1);
             const int n = c1 - c0;
             const int pre = wave_excl_scan(n, l);
-            for (int tx = c0; tx < c1; ++tx)
-                tile_keys[out + pre + (tx - c0)] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | og;
+            for (int tx = c0; tx < c1; ++tx) {
+                rec_tile[out + pre + (tx - c0)] = (uint16_t)(ty * tile_w + tx);
+                rec_gid[out + pre + (tx - c0)] = og;
+            }
             out += __shfl(pre + n, 63);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint64_t* __restrict__ keys, int n_tiles,
-                                                          int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids) {
+__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint16_t* __restrict__ keys, int n_tiles,
+                                                          int32_t* __restrict__ offsets) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_isects) return;
-    const uint64_t rec = keys[i];
-    flatten_ids[i] = (int32_t)(uint32_t)rec;
-    const int cur = (int)(rec >> 32);
+    const int cur = (int)keys[i];
     if (i == 0) {
         for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
     } else {
-        const int prev = (int)(keys[i - 1] >> 32);
+        const int prev = (int)keys[i - 1];
         for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
     }
     if (i == n_isects - 1)
@@ -441,7 +413,7 @@ using TileSortCfg = rocprim::radix_sort_config<
     32 * 1024>;
 
 struct BinWorkspace {
-    size_t keys_off, ids_off, keys2_off, counts_off, counts64_off, scan_tmp_off, scan_tmp_bytes, sort1_tmp_off, sort1_tmp_bytes;
+    size_t keys_off, ids_off, keys2_off, counts_off, scan_tmp_off, scan_tmp_bytes, sort1_tmp_off, sort1_tmp_bytes;
     size_t tkeys_off, tvals_off, tkeys2_off, sort2_tmp_off, sort2_tmp_bytes;
     size_t total_count, total;
 };
@@ -449,20 +421,21 @@ struct BinWorkspace {
 static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     const size_t n = (size_t)(N > 0 ? N : 1), ni = (size_t)(n_isects > 0 ? n_isects : 1);
     size_t scan_tmp = 0, s1 = 0, s2 = 0;
-    hipError_t e = rocprim::inclusive_scan(nullptr, scan_tmp, (const int64_t*)nullptr, (int64_t*)nullptr, n, rocprim::plus<int64_t>(), (hipStream_t)0);
+    hipError_t e = rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator((const uint32_t*)nullptr, GatherCount{nullptr}),
+                                           (int64_t*)nullptr, n, rocprim::plus<int64_t>(), (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: scan size query");
     e = rocprim::radix_sort_pairs<DepthSortCfg>(nullptr, s1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort1 size query");
-    e = rocprim::radix_sort_keys<TileSortCfg>(nullptr, s2, (const uint64_t*)nullptr, (uint64_t*)nullptr, ni, 32, 64, (hipStream_t)0);
+    e = rocprim::radix_sort_pairs<TileSortCfg>(nullptr, s2, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 16, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort2 size query");
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     w.keys_off = take(4 * n); w.ids_off = take(4 * n); w.keys2_off = take(4 * n);
-    w.counts_off = take(4 * n); w.counts64_off = take(8 * n);
+    w.counts_off = take(4 * n);
     w.scan_tmp_bytes = scan_tmp; w.scan_tmp_off = take(scan_tmp);
     w.sort1_tmp_bytes = s1; w.sort1_tmp_off = take(s1);
     w.total_count = off;
-    w.tkeys_off = take(8 * ni); w.tvals_off = w.tkeys_off; w.tkeys2_off = take(8 * ni);
+    w.tkeys_off = take(2 * ni); w.tvals_off = take(4 * ni); w.tkeys2_off = take(2 * ni);
     w.sort2_tmp_bytes = s2; w.sort2_tmp_off = take(s2);
     w.total = off;
     return GSPL_OK;
@@ -495,7 +468,6 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     uint32_t* ids = (uint32_t*)(ws + w.ids_off);
     uint32_t* keys2 = (uint32_t*)(ws + w.keys2_off);
     int32_t* counts = (int32_t*)(ws + w.counts_off);
-    int64_t* counts64 = (int64_t*)(ws + w.counts64_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
@@ -507,11 +479,10 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     size_t tmp = w.sort1_tmp_bytes;
     hipError_t e = rocprim::radix_sort_pairs<DepthSortCfg>(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
     if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
-    hipLaunchKernelGGL(bin_gather_counts_kernel, dim3(grid), dim3(256), 0, s, N, (const uint32_t*)order, counts, counts64);
-    rc = check_launch("bin_gather_counts");
-    if (rc != GSPL_OK) return rc;
     tmp = w.scan_tmp_bytes;
-    e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp, counts64, cum_tiles, (size_t)N, rocprim::plus<int64_t>(), s);
+    e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp,
+                                rocprim::make_transform_iterator((const uint32_t*)order, GatherCount{counts}), cum_tiles, (size_t)N,
+                                rocprim::plus<int64_t>(), s);
     return check_hip(e, "bin_count: inclusive_scan");
 }
 
@@ -531,28 +502,31 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
         return check_launch("bin_emit_sort(fill)");
     }
     if (n_isects > 0x7fffffffll) return fail_arg("bin_emit_sort: more than 2^31-1 intersections");
+    if (n_tiles > 65536) { set_error("bin_emit_sort", "more than 65536 tiles (16-bit tile ids)"); return GSPL_ERR_UNSUPPORTED; }
     if (!means2d || !radii || !order || !cum_tiles || !flatten_ids || !workspace) return fail_arg("bin_emit_sort: NULL required pointer");
     BinWorkspace w;
     int rc = plan_bin(N, n_isects, w);
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total) return fail_ws("bin_emit_sort");
     char* ws = (char*)workspace;
-    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
-    uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
+    uint16_t* tkeys = (uint16_t*)(ws + w.tkeys_off);
+    uint32_t* tvals = (uint32_t*)(ws + w.tvals_off);
+    uint16_t* tkeys2 = (uint16_t*)(ws + w.tkeys2_off);
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
     else
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
     rc = check_launch("bin_emit");
     if (rc != GSPL_OK) return rc;
+    // stable sort of the depth-ordered (tile id u16, splat id u32) records by tile id; the sorted splat ids ARE flatten_ids
     size_t tmp = w.sort2_tmp_bytes;
     const int bits = key_bits(n_tiles) - 32;
-    hipError_t e = rocprim::radix_sort_keys<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, (size_t)n_isects, 32,
-                                            32 + (bits > 0 ? bits : 1), s);
+    hipError_t e = rocprim::radix_sort_pairs<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, tvals, (uint32_t*)flatten_ids,
+                                                         (size_t)n_isects, 0, bits > 0 ? bits : 1, s);
     if (e != hipSuccess) return check_hip(e, "bin_emit_sort: tile sort");
     const int64_t g2 = (n_isects + 255) / 256;
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint64_t*)tkeys2, n_tiles, offsets, flatten_ids);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint16_t*)tkeys2, n_tiles, offsets);
     return check_launch("bin_offsets");
 }
 
