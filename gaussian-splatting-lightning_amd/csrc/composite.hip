@@ -733,28 +733,39 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
             }
             const float S0 = s02.x + s02.y, Sy = sy2.x + sy2.y;
             const float Sx = S0 * dx;
-            vals[0] = Sx;                    // -> sum sp*dx
-            vals[1] = Sy;                    // -> sum sp*dy
-            vals[2] = Sx * dx;               // -> sum sp*dx^2
-            vals[3] = Sy * dx;               // -> sum sp*dx*dy
-            vals[4] = syy2.x + syy2.y;       // -> sum sp*dy^2
-            vals[5] = S0;                    // -> sum sp
+            // this lane's share of the gradients (linear in the moments, so the conversion commutes with the reduction)
+            vals[0] = ca * Sx + cb * Sy;                                    // dL/dx
+            vals[1] = cb * Sx + cc_ * Sy;                                   // dL/dy
+            vals[2] = 0.5f * (Sx * dx);                                     // dL/da
+            vals[3] = Sy * dx;                                              // dL/db
+            vals[4] = 0.5f * (syy2.x + syy2.y);                             // dL/dc
+            vals[5] = (co_ != 0.f) ? -S0 * __builtin_amdgcn_rcpf(co_) : 0.f;      // dL/dopacity = sum(vis * v_alpha) = -sum(sp) / o
 #pragma unroll
             for (int c = 0; c < D; ++c) vals[6 + c] = rgb2[c].x + rgb2[c].y;
             if constexpr (ABS) { vals[6 + D] = ax; vals[7 + D] = ay; }
         }
+        // Reduction over the 16 lanes of the slot in two halves: first inside each quad, for all NV values; then lane q of
+        // every quad keeps only the values k = q (mod 4) and those are summed across the four quads (row_ror 4, 8 keep
+        // q), so that the lanes of quad 0 end up owning values q, q+4, q+8, ... and add them to the tile's LDS totals.
 #pragma unroll
-        for (int k = 0; k < NV; ++k) vals[k] = row_sum(vals[k]);
-        const float Sx = vals[0], Sy = vals[1];
-        vals[0] = ca * Sx + cb * Sy;                         // dL/dx
-        vals[1] = cb * Sx + cc_ * Sy;                        // dL/dy
-        vals[2] = 0.5f * vals[2];                            // dL/da
-        vals[4] = 0.5f * vals[4];                            // dL/dc      (vals[3] = dL/db as is)
-        vals[5] = (co_ != 0.f) ? -vals[5] * __builtin_amdgcn_rcpf(co_) : 0.f;     // dL/dopacity = -sum(sp) / o
-        float mine = vals[0];
+        for (int k = 0; k < NV; ++k) {
+            vals[k] = dpp_add<0xB1, 0xF>(vals[k]);    // quad_perm [1,0,3,2]
+            vals[k] = dpp_add<0x4E, 0xF>(vals[k]);    // quad_perm [2,3,0,1]
+        }
+        constexpr int NK = (NV + 3) / 4;
+        const int pq = pc & 3;
+        float kept[NK];
 #pragma unroll
-        for (int k = 1; k < NV; ++k) mine = (pc == k) ? vals[k] : mine;
-        if (live && pc < NV) atomicAdd(&s_acc[j * NV + pc], mine);
+        for (int m = 0; m < NK; ++m) {
+            float v = vals[4 * m];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) v = (pq == q) ? ((4 * m + q < NV) ? vals[(4 * m + q < NV) ? 4 * m + q : 0] : 0.f) : v;
+            kept[m] = dpp_add<0x124, 0xF>(v);         // row_ror:4
+        }
+        row_ror8_add<NK>(kept);
+#pragma unroll
+        for (int m = 0; m < NK; ++m)
+            if (live && pc < 4 && 4 * m + pc < NV) atomicAdd(&s_acc[j * NV + 4 * m + pc], kept[m]);
     };
 
     // the staged Gaussian ids are fetched one round ahead, so that a round's gather does not wait for them
@@ -794,6 +805,9 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     const float* rec = s_rec + j * RS;
                     const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 c/2
                     const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // b opacity
+                    float col[D];                                                    // fetched with the record: one LDS round trip per candidate
+#pragma unroll
+                    for (int c = 0; c < D; ++c) col[c] = rec[8 + c];
                     // sigma, bit-identical per element to eval_sigma: fma(ha dx, dx, fma(hc dy, dy, (b dx) dy))
                     const v2f dx2 = (v2f){r0.x, r0.x} - pxf2;
                     const float dy = r0.y - pyf;
@@ -804,21 +818,21 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     const v2f arg2 = sigma2 * (v2f){-1.4426950408889634f, -1.4426950408889634f};
                     const v2f vis2 = {__builtin_amdgcn_exp2f(arg2.x), __builtin_amdgcn_exp2f(arg2.y)};
                     const v2f raw2 = (v2f){r1.y, r1.y} * vis2;
-                    const float aA = fminf(TR::kAlphaMax, raw2.x), aB = fminf(TR::kAlphaMax, raw2.y);
-                    const bool validA = (idx < lastA) && (sigma2.x >= 0.f) && (aA >= kAlphaMin);
-                    const bool validB = (idx < lastB) && (sigma2.y >= 0.f) && (aB >= kAlphaMin);
+                    // alpha = min(kAlphaMax, raw) >= 1/255  <=>  raw >= 1/255
+                    const bool validA = (idx < lastA) && (sigma2.x >= 0.f) && (raw2.x >= kAlphaMin);
+                    const bool validB = (idx < lastB) && (sigma2.y >= 0.f) && (raw2.y >= kAlphaMin);
                     if (!__any(validA || validB)) continue;
-                    const v2f a2 = {validA ? aA : 0.f, validB ? aB : 0.f};
-                    v2f rw2;       // o * vis where the pixel takes a gradient through alpha, else 0
-                    if (TR::kClampKillsGrad) rw2 = (v2f){(validA && raw2.x <= TR::kAlphaMax) ? raw2.x : 0.f, (validB && raw2.y <= TR::kAlphaMax) ? raw2.y : 0.f};
-                    else rw2 = (v2f){validA ? raw2.x : 0.f, validB ? raw2.y : 0.f};
+                    const v2f rv2 = {validA ? raw2.x : 0.f, validB ? raw2.y : 0.f};
+                    const v2f a2 = {fminf(TR::kAlphaMax, rv2.x), fminf(TR::kAlphaMax, rv2.y)};
+                    v2f rw2 = rv2;     // o * vis where the pixel takes a gradient through alpha, else 0
+                    if (TR::kClampKillsGrad) rw2 = (v2f){(rv2.x <= TR::kAlphaMax) ? rv2.x : 0.f, (rv2.y <= TR::kAlphaMax) ? rv2.y : 0.f};
                     const v2f om2 = (v2f){1.f, 1.f} - a2;
                     const v2f ra2 = {__builtin_amdgcn_rcpf(om2.x), __builtin_amdgcn_rcpf(om2.y)};
                     T2 *= ra2;                                 // transmittance in front of this splat
                     const v2f fac2 = a2 * T2;
-                    v2f cdot2 = (v2f){rec[8], rec[8]} * vo[0];
+                    v2f cdot2 = (v2f){col[0], col[0]} * vo[0];
 #pragma unroll
-                    for (int c = 1; c < D; ++c) cdot2 = __builtin_elementwise_fma((v2f){rec[8 + c], rec[8 + c]}, vo[c], cdot2);
+                    for (int c = 1; c < D; ++c) cdot2 = __builtin_elementwise_fma((v2f){col[c], col[c]}, vo[c], cdot2);
                     const v2f v_alpha2 = __builtin_elementwise_fma(cdot2, T2, R2 * ra2);
                     R2 = __builtin_elementwise_fma(-cdot2, fac2, R2);
                     const v2f sp2 = -rw2 * v_alpha2;

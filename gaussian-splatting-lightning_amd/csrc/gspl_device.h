@@ -205,6 +205,28 @@ __device__ __forceinline__ float row_sum(float v) {
     v = dpp_add<0x140, 0xF>(v);   // row_mirror
     return v;
 }
+// In-place v += <dpp>(v) for N registers, written as v_add_f32_dpp by hand.  When the adds of a reduction's LAST step
+// are only consumed under a lane condition the compiler sinks them into the conditional block and can no longer fuse
+// them with their DPP moves (3 instructions per value instead of 1).  One s_nop 1 covers the VALU-write -> DPP-read
+// hazard (2 wait states) for each group of up to four independent adds.
+#define GSPL_DPP_ADD_INPLACE(NAME, CTRL)                                                                         \
+    template <int N>                                                                                             \
+    __device__ __forceinline__ void NAME(float (&v)[N]) {                                                        \
+        int k = 0;                                                                                               \
+        _Pragma("unroll") for (; k + 4 <= N; k += 4)                                                             \
+            asm volatile("s_nop 1\n\t"                                                                           \
+                         "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+                         "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+                         "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"         \
+                         "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"               \
+                         : "+v"(v[k]), "+v"(v[k + 1]), "+v"(v[k + 2]), "+v"(v[k + 3]));                          \
+        _Pragma("unroll") for (; k < N; ++k)                                                                     \
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"  \
+                         : "+v"(v[k]));                                                                          \
+    }
+GSPL_DPP_ADD_INPLACE(row_mirror_add, "row_mirror")
+GSPL_DPP_ADD_INPLACE(row_ror8_add, "row_ror:8")
+
 // Sum over the 64 lanes of the wave; the total is valid in lane 63 (row 3).
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
