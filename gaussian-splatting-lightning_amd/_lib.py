@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -24,6 +24,7 @@ GSPL_LAYOUT_HWC = 0
 GSPL_LAYOUT_CHW = 1
 GSPL_SH_ADD_HALF_CLAMP = 1
 GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
+GSPL_BIN_SPAN_BYTES = 32
 
 
 class HipLibraryError(RuntimeError):
@@ -46,8 +47,8 @@ _SIGNATURES = {
     "gspl_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, _P, _P]),
     "gspl_bin_workspace_bytes": (c_size_t, [c_int, c_int64]),
-    "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
-    "gspl_bin_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
+    "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "gspl_bin_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_composite_fwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_composite_bwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,

@@ -208,33 +208,64 @@ __device__ __forceinline__ void row_columns(const SplatCull& s, int ty, int tile
     if (c1 < c0) c1 = c0;
 }
 
+// Per-splat span record written by bin_keys_kernel (a coalesced pass in memory order) and gathered by the emit kernel
+// (which walks the splats in DEPTH order, i.e. at random addresses): one 32-byte line per splat instead of four
+// scattered reads (means2d, radii, conics, opacities) plus the span arithmetic all over again.
+struct __attribute__((aligned(16))) SpanRecord {
+    uint16_t miny;              // first tile row
+    uint16_t rows;              // number of tile rows; SPAN_BIG: not representable here (more than EMIT_ROWS rows or a row wider than 255)
+    uint16_t c0[8];             // first reachable tile column of each row
+    uint8_t n[8];               // reachable tiles of each row
+    uint32_t pad;
+};
+static_assert(sizeof(SpanRecord) == 32, "span record is one 32-byte line");
+static constexpr int EMIT_ROWS = 8;
+static constexpr uint16_t SPAN_BIG = 0xFFFFu;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void bin_keys_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
     const float* __restrict__ conics, const float* __restrict__ opacities,
-    int tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, int32_t* __restrict__ counts) {
+    int tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, int32_t* __restrict__ counts,
+    SpanRecord* __restrict__ spans) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     int n = 0;
     const int radius = radii[g];
+    // the record is assembled in eight 32-bit words (static indices only, so that it stays in registers)
+    uint32_t w0 = 0u, wc[4] = {0u, 0u, 0u, 0u}, wn[2] = {0u, 0u};
     if (radius > 0) {
         int minx, miny, maxx, maxy;
         const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
         tile_rect<MODE>(mx, my, radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
-        if (conics) {
-            const SplatCull sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
-            for (int ty = miny; ty < maxy; ++ty) {
-                int c0, c1;
-                row_columns<MODE>(sc, ty, tile_size, minx, maxx, c0, c1);
-                n += c1 - c0;
-            }
-        } else {
-            n = max(maxx - minx, 0) * max(maxy - miny, 0);
+        SplatCull sc;
+        sc.kind = 2;
+        if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
+        const int rows = max(maxy - miny, 0);
+        bool big = rows > EMIT_ROWS;
+#pragma unroll
+        for (int r = 0; r < EMIT_ROWS; ++r) {
+            int c0 = 0, c1 = 0;
+            if (r < rows) row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
+            const int w = c1 - c0;
+            n += w;
+            big = big || w > 255;
+            wc[r >> 1] |= (uint32_t)(c0 & 0xFFFF) << (16 * (r & 1));
+            wn[r >> 2] |= (uint32_t)(w & 0xFF) << (8 * (r & 3));
         }
+        for (int r = EMIT_ROWS; r < rows; ++r) {
+            int c0, c1;
+            row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
+            n += c1 - c0;
+        }
+        w0 = (uint32_t)(miny & 0xFFFF) | ((big ? (uint32_t)SPAN_BIG : (uint32_t)rows) << 16);
     }
     counts[g] = n;
     ids[g] = (uint32_t)g;
     keys[g] = n > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;      // splats without tiles sort to the end
+    uint4* dst = reinterpret_cast<uint4*>(spans + g);      // layout of SpanRecord (little endian)
+    dst[0] = make_uint4(w0, wc[0], wc[1], wc[2]);
+    dst[1] = make_uint4(wc[3], wn[0], wn[1], 0u);
 }
 
 // counts[order[i]] as int64: the input "array" of the scan over per-splat tile counts in depth order (no gather pass)
@@ -243,13 +274,11 @@ struct GatherCount {
     __device__ int64_t operator()(uint32_t g) const { return (int64_t)counts[g]; }
 };
 
-// Load-balanced emission.  A lane-per-splat loop would let every lane write its own run of records (stores 30-60 B
+// Load-balanced emission.  A lane-per-splat loop would let every lane write its own run of records (8 B stores 30-60 B
 // apart: partial-line writes, and one huge splat serialises a whole wave).  Here a wave owns 64 consecutive splats of
-// the depth order = one CONTIGUOUS output range; lanes walk that range in stride (coalesced stores of the 2-byte tile ids and 4-byte splat ids) and find the
+// the depth order = one CONTIGUOUS output range; lanes walk that range in stride (coalesced 8-B stores) and find the
 // owner of each output slot by binary search over the wave's prefix counts in LDS, then the tile row by a short scan
 // of the owner's per-row prefix (splats with more than EMIT_ROWS rows are emitted cooperatively, lanes over rows).
-static constexpr int EMIT_ROWS = 8;
-
 __device__ __forceinline__ int wave_excl_scan(int v, int lane) {
     int incl = v;
 #pragma unroll
@@ -264,8 +293,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
-    const int64_t* __restrict__ cum_sorted, int tile_size, int tile_w, int tile_h,
-    uint16_t* __restrict__ rec_tile, uint32_t* __restrict__ rec_gid) {
+    const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, int tile_size, int tile_w, int tile_h,
+    uint64_t* __restrict__ tile_keys) {
     __shared__ int s_start[4][65];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_row0[4][64];
@@ -281,35 +310,40 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     if (total == 0) return;
 
     int g = 0, cnt = 0, start = total, minx = 0, miny = 0, maxx = 0, maxy = 0;
-    float mx = 0.f, my = 0.f, ca = 1.f, cb = 0.f, cc = 1.f, op = 0.f;
+    uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = make_uint4(0u, 0u, 0u, 0u);      // the splat's SpanRecord as eight words
     if (i < N) {
         const int64_t off = (i == 0) ? 0 : cum_sorted[i - 1];
         start = (int)(off - wave_base);
         cnt = (int)(cum_sorted[i] - off);
         g = (int)order[i];
         if (cnt > 0) {
-            mx = means2d[g * 2 + 0]; my = means2d[g * 2 + 1];
-            tile_rect<MODE>(mx, my, radii[g], tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
-            if (conics) { ca = conics[g * 3 + 0]; cb = conics[g * 3 + 1]; cc = conics[g * 3 + 2]; op = opacities[g]; }
+            const uint4* src = reinterpret_cast<const uint4*>(spans + g);
+            ra = src[0];
+            rb = src[1];
         }
     }
+    const uint32_t rec_rows = ra.x >> 16, rec_miny = ra.x & 0xFFFFu;
+    const uint32_t wc[4] = {ra.y, ra.z, ra.w, rb.x}, wn[2] = {rb.y, rb.z};
+    const bool big = cnt > 0 && rec_rows == (uint32_t)SPAN_BIG;
+    // the few splats the record cannot describe (many tile rows, or a very wide row) recompute their spans from the inputs
     SplatCull sc;
     sc.kind = 2;
-    if (conics && cnt > 0) sc = make_cull(mx, my, ca, cb, cc, op);
-    const int rows = maxy - miny;
-    const bool big = cnt > 0 && rows > EMIT_ROWS;
+    if (big) {
+        const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+        tile_rect<MODE>(mx, my, radii[g], tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+        if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
+    }
     s_start[w][l] = start;
     if (l == 0) s_start[w][64] = total;
     s_gid[w][l] = (uint32_t)g;
-    s_row0[w][l] = miny;
+    s_row0[w][l] = big ? miny : (int)rec_miny;
     if (cnt > 0 && !big) {
         int acc = 0;
+#pragma unroll
         for (int r = 0; r < EMIT_ROWS; ++r) {
-            int c0 = 0, c1 = 0;
-            if (r < rows) row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
-            s_c0[w][l][r] = (uint16_t)c0;
+            s_c0[w][l][r] = (uint16_t)(wc[r >> 1] >> (16 * (r & 1)));
             s_pre[w][l][r] = (uint16_t)acc;
-            acc += c1 - c0;
+            acc += (int)((wn[r >> 2] >> (8 * (r & 3))) & 0xFFu);
         }
         s_pre[w][l][EMIT_ROWS] = (uint16_t)acc;
     }
@@ -333,8 +367,7 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
         for (int q = 1; q < EMIT_ROWS; ++q) r += (kk >= (int)s_pre[w][o][q]) ? 1 : 0;
         const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
         const int ty = s_row0[w][o] + r;
-        rec_tile[wave_base + k] = (uint16_t)(ty * tile_w + tx);
-        rec_gid[wave_base + k] = s_gid[w][o];
+        tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
     }
     (void)any_mask;
     // ---- phase B: splats spanning many tile rows, one at a time, lanes over rows ---------------------------
@@ -355,24 +388,24 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
             if (ty < omaxy) row_columns<MODE>(so, ty, tile_size, ominx, omaxx, c0, c1);
             const int n = c1 - c0;
             const int pre = wave_excl_scan(n, l);
-            for (int tx = c0; tx < c1; ++tx) {
-                rec_tile[out + pre + (tx - c0)] = (uint16_t)(ty * tile_w + tx);
-                rec_gid[out + pre + (tx - c0)] = og;
-            }
+            for (int tx = c0; tx < c1; ++tx)
+                tile_keys[out + pre + (tx - c0)] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | og;
             out += __shfl(pre + n, 63);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint16_t* __restrict__ keys, int n_tiles,
-                                                          int32_t* __restrict__ offsets) {
+__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint64_t* __restrict__ keys, int n_tiles,
+                                                          int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_isects) return;
-    const int cur = (int)keys[i];
+    const uint64_t rec = keys[i];
+    flatten_ids[i] = (int32_t)(uint32_t)rec;
+    const int cur = (int)(rec >> 32);
     if (i == 0) {
         for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
     } else {
-        const int prev = (int)keys[i - 1];
+        const int prev = (int)(keys[i - 1] >> 32);
         for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
     }
     if (i == n_isects - 1)
@@ -426,7 +459,7 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     if (e != hipSuccess) return check_hip(e, "bin: scan size query");
     e = rocprim::radix_sort_pairs<DepthSortCfg>(nullptr, s1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort1 size query");
-    e = rocprim::radix_sort_pairs<TileSortCfg>(nullptr, s2, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 16, (hipStream_t)0);
+    e = rocprim::radix_sort_keys<TileSortCfg>(nullptr, s2, (const uint64_t*)nullptr, (uint64_t*)nullptr, ni, 32, 64, (hipStream_t)0);
     if (e != hipSuccess) return check_hip(e, "bin: sort2 size query");
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -435,7 +468,7 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     w.scan_tmp_bytes = scan_tmp; w.scan_tmp_off = take(scan_tmp);
     w.sort1_tmp_bytes = s1; w.sort1_tmp_off = take(s1);
     w.total_count = off;
-    w.tkeys_off = take(2 * ni); w.tvals_off = take(4 * ni); w.tkeys2_off = take(2 * ni);
+    w.tkeys_off = take(8 * ni); w.tvals_off = w.tkeys_off; w.tkeys2_off = take(8 * ni);
     w.sort2_tmp_bytes = s2; w.sort2_tmp_off = take(s2);
     w.total = off;
     return GSPL_OK;
@@ -452,12 +485,13 @@ extern "C" size_t gspl_bin_workspace_bytes(int N, int64_t n_isects) {
 extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
                               const float* conics, const float* opacities,
                               int tile_size, int tile_w, int tile_h,
-                              int32_t* order, int64_t* cum_tiles, void* workspace, size_t workspace_bytes, void* stream) {
+                              int32_t* order, int64_t* cum_tiles, void* spans, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gspl;
     if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_count: bad sizes");
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_count: bad mode");
     if (N == 0) return GSPL_OK;
-    if (!means2d || !radii || !depths || !order || !cum_tiles || !workspace) return fail_arg("bin_count: NULL required pointer");
+    if (!means2d || !radii || !depths || !order || !cum_tiles || !spans || !workspace) return fail_arg("bin_count: NULL required pointer");
+    if (tile_w > 65535 || tile_h > 65535) { set_error("bin_count", "more than 65535 tile rows or columns"); return GSPL_ERR_UNSUPPORTED; }
     if ((conics == nullptr) != (opacities == nullptr)) return fail_arg("bin_count: conics and opacities go together");
     BinWorkspace w;
     int rc = plan_bin(N, 0, w);
@@ -471,9 +505,9 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts);
+        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans);
     else
-        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts);
+        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans);
     rc = check_launch("bin_keys");
     if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort1_tmp_bytes;
@@ -488,7 +522,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
 
 extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const int32_t* radii,
                                   const float* conics, const float* opacities,
-                                  const int32_t* order, const int64_t* cum_tiles,
+                                  const int32_t* order, const int64_t* cum_tiles, const void* spans,
                                   int tile_size, int tile_w, int tile_h, int64_t n_isects,
                                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gspl;
@@ -502,31 +536,28 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
         return check_launch("bin_emit_sort(fill)");
     }
     if (n_isects > 0x7fffffffll) return fail_arg("bin_emit_sort: more than 2^31-1 intersections");
-    if (n_tiles > 65536) { set_error("bin_emit_sort", "more than 65536 tiles (16-bit tile ids)"); return GSPL_ERR_UNSUPPORTED; }
-    if (!means2d || !radii || !order || !cum_tiles || !flatten_ids || !workspace) return fail_arg("bin_emit_sort: NULL required pointer");
+    if (!means2d || !radii || !order || !cum_tiles || !spans || !flatten_ids || !workspace) return fail_arg("bin_emit_sort: NULL required pointer");
     BinWorkspace w;
     int rc = plan_bin(N, n_isects, w);
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total) return fail_ws("bin_emit_sort");
     char* ws = (char*)workspace;
-    uint16_t* tkeys = (uint16_t*)(ws + w.tkeys_off);
-    uint32_t* tvals = (uint32_t*)(ws + w.tvals_off);
-    uint16_t* tkeys2 = (uint16_t*)(ws + w.tkeys2_off);
+    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
+    uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys);
     else
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, tile_size, tile_w, tile_h, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys);
     rc = check_launch("bin_emit");
     if (rc != GSPL_OK) return rc;
-    // stable sort of the depth-ordered (tile id u16, splat id u32) records by tile id; the sorted splat ids ARE flatten_ids
     size_t tmp = w.sort2_tmp_bytes;
     const int bits = key_bits(n_tiles) - 32;
-    hipError_t e = rocprim::radix_sort_pairs<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, tvals, (uint32_t*)flatten_ids,
-                                                         (size_t)n_isects, 0, bits > 0 ? bits : 1, s);
+    hipError_t e = rocprim::radix_sort_keys<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, (size_t)n_isects, 32,
+                                            32 + (bits > 0 ? bits : 1), s);
     if (e != hipSuccess) return check_hip(e, "bin_emit_sort: tile sort");
     const int64_t g2 = (n_isects + 255) / 256;
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint16_t*)tkeys2, n_tiles, offsets);
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint64_t*)tkeys2, n_tiles, offsets, flatten_ids);
     return check_launch("bin_offsets");
 }
 

@@ -462,7 +462,7 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
 class _PendingBins:
     """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
-    __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "offsets", "tile_w", "tile_h",
+    __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "spans", "offsets", "tile_w", "tile_h",
                  "block_width", "host_count", "event", "dev")
 
 
@@ -490,16 +490,17 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     if conics is not None and opacities is not None:
         p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
     p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
-    p.order = p.cum = p.host_count = p.event = None
+    p.order = p.cum = p.spans = p.host_count = p.event = None
     if N > 0:
         p.order = torch.empty((N,), dtype=torch.int32, device=dev)
         p.cum = torch.empty((N,), dtype=torch.int64, device=dev)
+        p.spans = torch.empty((N, L.GSPL_BIN_SPAN_BYTES // 4), dtype=torch.int32, device=dev)
         ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
         if ws_bytes == 0:
             raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
-               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(ws), ws_bytes, L.stream())
+               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.spans), L.ptr(ws), ws_bytes, L.stream())
         # the one host read-back of the pipeline (sizes the sort buffers)
         p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((1,), dtype=torch.int64).pin_memory()
         p.host_count.copy_(p.cum[-1:], non_blocking=True)
@@ -522,7 +523,7 @@ def bin_gaussians_end(p: _PendingBins):
     ws_bytes = lib.gspl_bin_workspace_bytes(max(N, 1), n_isects) if n_isects > 0 else 0
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
     L.call("gspl_bin_emit_sort", N, p.mode, L.ptr(p.means2d) if N else None, L.ptr(p.radii) if N else None,
-           L.ptr(p.cull_c), L.ptr(p.cull_o), L.ptr(p.order), L.ptr(p.cum), p.block_width, p.tile_w, p.tile_h, n_isects,
+           L.ptr(p.cull_c), L.ptr(p.cull_o), L.ptr(p.order), L.ptr(p.cum), L.ptr(p.spans), p.block_width, p.tile_w, p.tile_h, n_isects,
            L.ptr(flat) if n_isects else None, L.ptr(p.offsets), L.ptr(ws), ws_bytes, L.stream())
     return flat, p.offsets
 

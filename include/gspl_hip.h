@@ -168,18 +168,22 @@ int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids,
  *    conservative margin).  The dropped pairs contribute nothing to any pixel, so composited images and
  *    gradients are unchanged, while the lists shrink by ~40 % (the 3-sigma square of the reference's
  *    rect is loose, the more so for low opacities).  Pass the SAME opacities the compositing call uses.
+ *    spans: caller-owned scratch of GSPL_BIN_SPAN_BYTES per splat, written by gspl_bin_count (the reachable tile
+ *    columns of each tile row of the splat) and read back, in depth order, by gspl_bin_emit_sort — one 32-byte
+ *    line per splat instead of re-gathering means2d / radii / conics / opacities at random addresses.
  * ---------------------------------------------------------------------------------------- */
+enum { GSPL_BIN_SPAN_BYTES = 32 };
 size_t gspl_bin_workspace_bytes(int N, int64_t n_isects);
 int gspl_bin_count(int N, int mode,
                    const float* means2d, const int32_t* radii, const float* depths,
                    const float* conics /*nullable*/, const float* opacities /*nullable*/,
                    int tile_size, int tile_w, int tile_h,
-                   int32_t* order, int64_t* cum_tiles,
+                   int32_t* order, int64_t* cum_tiles, void* spans /* GSPL_BIN_SPAN_BYTES * N, 16-byte aligned */,
                    void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_emit_sort(int N, int mode,
                        const float* means2d, const int32_t* radii,
                        const float* conics /*nullable*/, const float* opacities /*nullable*/,
-                       const int32_t* order, const int64_t* cum_tiles,
+                       const int32_t* order, const int64_t* cum_tiles, const void* spans,
                        int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int32_t* flatten_ids, int32_t* offsets,
                        void* workspace, size_t workspace_bytes, void* stream);
