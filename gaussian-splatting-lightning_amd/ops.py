@@ -459,6 +459,41 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     return out[None], alphas[None, ..., None]
 
 
+class _side_stream:
+    """`with _side_stream(dev) as s:` runs the enclosed launches on a per-device side stream that first waits for everything
+    already enqueued on the current stream; `s.join()` makes the current stream wait for them.  Set GSPL_SIDE_STREAM=0 to
+    keep everything on the caller's stream."""
+    _streams: dict = {}
+
+    def __init__(self, dev):
+        import os
+        self.enabled = os.environ.get("GSPL_SIDE_STREAM", "1") != "0"
+        self.dev = dev
+        self.ctx = None
+        if self.enabled:
+            key = (dev.type, dev.index)
+            s = _side_stream._streams.get(key)
+            if s is None:
+                s = _side_stream._streams[key] = torch.cuda.Stream(device=dev)
+            self.stream = s
+
+    def __enter__(self):
+        if self.enabled:
+            self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+
 class _PendingBins:
     """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
@@ -602,11 +637,15 @@ class _InriaRasterizeFn(torch.autograd.Function):
                        float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
                        L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
                        phases, L.stream())
-        # geometry -> count/depth sort -> (count travels to the host while the SH kernel runs) -> emit/tile sort
+        # geometry, then two independent chains: the SH kernel (HBM-bound, one launch) on a side stream, and the count /
+        # depth-sort half of the binning (a dozen small latency-bound launches) on the caller's stream; the host meanwhile
+        # waits for the one number that sizes the tile sort.
         preprocess(L.GSPL_INRIA_GEOMETRY)
+        with _side_stream(dev) as side:
+            preprocess(L.GSPL_INRIA_COLOURS)
         pending = bin_gaussians_begin(means2d, depths, radii, H, W, tile, mode=L.GSPL_MODE_INRIA, conics=conics, opacities=opac)
-        preprocess(L.GSPL_INRIA_COLOURS)
         flat, offsets = bin_gaussians_end(pending)
+        side.join()
         n_isects = flat.shape[0]
         out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         alphas = torch.empty((H, W), dtype=torch.float32, device=dev)
