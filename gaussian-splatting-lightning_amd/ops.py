@@ -717,3 +717,26 @@ class GaussianRasterizer(torch.nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return _InriaRasterizeFn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                        self.raster_settings)
+
+
+# =============================================================================================
+# simple_knn  
+# =============================================================================================
+def distCUDA2(points: Tensor) -> Tensor:
+    """Drop-in for `simple_knn._C.distCUDA2` (reference call site: internal/models/vanilla_gaussian.py:122-124):
+    points [N,3] on the GPU -> [N] mean squared distance to the three nearest other points (fp32)."""
+    lib = L.lib()
+    if not points.is_cuda:
+        raise RuntimeError("distCUDA2: points must be on the GPU (the reference calls it with `.cuda()`)")
+    pts = _f32c(points.detach()).reshape(-1, 3)
+    N = pts.shape[0]
+    out = torch.empty((N,), dtype=torch.float32, device=pts.device)
+    if N == 0:
+        return out
+    ws_bytes = lib.gspl_knn_workspace_bytes(N)
+    if ws_bytes == 0:
+        raise RuntimeError("gspl_knn_workspace_bytes failed: " + lib.gspl_last_error().decode())
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=pts.device)
+    with torch.cuda.device(pts.device):
+        L.call("gspl_knn3_mean_dist2", N, L.ptr(pts), L.ptr(out), L.ptr(ws), ws_bytes, L.stream())
+    return out

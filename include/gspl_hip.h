@@ -290,6 +290,18 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               float* v_colors_precomp /*nullable*/, float* v_means2d_ndc,
                               void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 7. Mean squared distance to the 3 nearest neighbours ("next" row SURVEY.md §8f rank 1).
+ *    Replaces `simple_knn._C.distCUDA2` at its one call site, the initial scales of
+ *    `VanillaGaussianModel.setup_from_pcd` (internal/models/vanilla_gaussian.py:122-125):
+ *        out[i] = mean over the 3 nearest OTHER points j of |p_i - p_j|^2     (fp32)
+ *    points [N,3] f32, out [N] f32.  Exact (uniform grid + expanding shells).  With fewer than three
+ *    other points the mean is taken over those that exist (0 for a single point).
+ * ---------------------------------------------------------------------------------------- */
+size_t gspl_knn_workspace_bytes(int N);
+int gspl_knn3_mean_dist2(int N, const float* points, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
