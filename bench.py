@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="S-1080p-1M")
     p.add_argument("--api", default="vanilla", choices=["vanilla", "gsplat"])
+    p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
+                   help="l1: mean |render - target| with torch ops; photometric: the reference's training loss "
+                        "0.8 L1 + 0.2 (1 - SSIM) (vanilla_metrics.py:66-68) through the fused HIP loss kernels")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="auto", help="workload name for the CPU baseline leg, or 'auto'")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (code-path test on one GPU)")
@@ -53,7 +56,7 @@ def parse():
     return p.parse_args()
 
 
-def make_step(api, dev, wl, cam, tensors):
+def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
     import gspl_amd  # noqa: F401
     from gspl_amd import ops
     m, s, q, o, c = tensors
@@ -61,6 +64,10 @@ def make_step(api, dev, wl, cam, tensors):
     bg = torch.zeros(3, device=dev)
     target = torch.full((3, H, W), 0.5, device=dev)
     state = {}
+    if loss_kind == "photometric":
+        loss_fn = lambda img: ops.photometric_loss(img, target, 0.2)
+    else:
+        loss_fn = lambda img: (img - target).abs().mean()
     if api == "vanilla":
         settings = ops.GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
@@ -73,7 +80,7 @@ def make_step(api, dev, wl, cam, tensors):
                 t.grad = None
             screen = torch.zeros_like(m, requires_grad=True)
             render, radii = rast(means3D=m, means2D=screen, opacities=o, shs=c, scales=s, rotations=q)
-            loss = (render - target).abs().mean()
+            loss = loss_fn(render)
             loss.backward()
             state["vs_grad"], state["radii"], state["loss"] = screen.grad, radii, loss
             state["grad_scale"] = None
@@ -95,7 +102,7 @@ def make_step(api, dev, wl, cam, tensors):
             rgbs = ops.sh_view_colors(3, m, center, c, None, radii > 0)
             img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
                                           isects=ops.bin_gaussians_end(pending))
-            loss = (img.permute(2, 0, 1) - target).abs().mean()
+            loss = loss_fn(img.permute(2, 0, 1))
             loss.backward()
             state["vs_grad"], state["radii"], state["loss"] = xys.grad, radii, loss
             state["grad_scale"] = grad_scale
@@ -205,7 +212,7 @@ def main():
     # every rank renders its own camera (cameras sharded): a small per-rank dolly keeps the work equal
     cam = synthetic.camera(wl["width"], wl["height"], wl["fx"], distance=4.0 + 0.01 * rank)
     tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
-    step = make_step(args.api, dev, wl, cam, tensors)
+    step = make_step(args.api, dev, wl, cam, tensors, args.loss)
     N = wl["n"]
     accum = torch.zeros(N, device=dev)
     denom = torch.zeros(N, device=dev)
@@ -284,7 +291,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "api": args.api, "n_gaussians": N, "width": wl["width"], "height": wl["height"],
-                       "sh_degree": 3, "step": "renderer fwd + L1 loss + full bwd + densification stats",
+                       "sh_degree": 3, "loss": args.loss,
+                       "step": "renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd + densification stats",
                        "parallelism": f"replicated Gaussians, {world} camera(s)/step, all-reduce of densification stats only"},
             "stages_ms": stages,
             "fwd_ms": round(sum(v for k, v in stages.items() if "_bwd" not in k), 4),

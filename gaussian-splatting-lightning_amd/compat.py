@@ -1,7 +1,8 @@
 """Import shims for the reference's un-vendored native helpers that this package replaces.
 
 The reference imports them by their own module names inside functions, e.g.
-`from simple_knn._C import distCUDA2` (internal/models/vanilla_gaussian.py:122).  `install()` registers stand-in
+`from simple_knn._C import distCUDA2` (internal/models/vanilla_gaussian.py:122) or `from fused_ssim import fused_ssim`
+(internal/metrics/vanilla_metrics.py:36).  `install()` registers stand-in
 modules under those names — only for packages that are NOT importable — so that the reference runs unedited once
 `gspl_amd.renderers` has been imported (which the `--model.renderer gspl_amd.renderers.<Name>` option does while the
 configuration is parsed, long before the model is initialised from a point cloud).
@@ -36,4 +37,11 @@ def install() -> list:
         sys.modules["simple_knn"] = pkg
         sys.modules["simple_knn._C"] = sub
         installed.append("simple_knn._C")
+    if _missing("fused_ssim"):
+        from . import ops
+        mod = types.ModuleType("fused_ssim")
+        mod.__doc__ = "gspl_amd stand-in for fused_ssim (HIP; see gspl_amd.ops.fused_ssim)"
+        mod.fused_ssim = ops.fused_ssim
+        sys.modules["fused_ssim"] = mod
+        installed.append("fused_ssim")
     return installed

@@ -740,3 +740,72 @@ def distCUDA2(points: Tensor) -> Tensor:
     with torch.cuda.device(pts.device):
         L.call("gspl_knn3_mean_dist2", N, L.ptr(pts), L.ptr(out), L.ptr(ws), ws_bytes, L.stream())
     return out
+
+
+# =============================================================================================
+# fused photometric loss terms  
+# =============================================================================================
+class _L1SSIMFn(torch.autograd.Function):
+    """(mean |x - y|, mean SSIM(x, y)); gradients flow to the first image only (the second is the ground truth),
+    as in the `fused_ssim` package the reference can opt into (vanilla_metrics.py:35-39)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, train):
+        lib = L.lib()
+        if not img1.is_cuda or not img2.is_cuda:
+            raise RuntimeError("l1_ssim: images must be on the GPU")
+        if img1.shape != img2.shape or img1.dim() < 2:
+            raise ValueError(f"l1_ssim: shapes {tuple(img1.shape)} vs {tuple(img2.shape)}")
+        x, y = _f32c(img1), _f32c(img2)
+        H, W = int(x.shape[-2]), int(x.shape[-1])
+        planes = x.numel() // (H * W) if H * W > 0 else 0
+        if planes == 0:
+            raise ValueError("l1_ssim: empty image")
+        dev = x.device
+        means = torch.empty((2,), dtype=torch.float32, device=dev)
+        keep = bool(train) and img1.requires_grad
+        maps = torch.empty((3, planes, H, W), dtype=torch.float32, device=dev) if keep else None
+        ws_bytes = lib.gspl_loss_workspace_bytes(planes, H, W)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.call("gspl_loss_l1_ssim_fwd", planes, H, W, L.ptr(x), L.ptr(y), L.ptr(means),
+                   L.ptr(maps[0]) if keep else None, L.ptr(maps[1]) if keep else None, L.ptr(maps[2]) if keep else None,
+                   L.ptr(ws), ws_bytes, L.stream())
+        ctx.save_for_backward(x, y, maps)
+        ctx.dims = (planes, H, W, img1.shape)
+        return means[0], means[1]
+
+    @staticmethod
+    def backward(ctx, v_l1, v_ssim):
+        x, y, maps = ctx.saved_tensors
+        planes, H, W, shape = ctx.dims
+        if maps is None and v_ssim is not None:
+            raise RuntimeError("l1_ssim: backward through SSIM needs train=True in the forward")
+        v_img = torch.empty_like(x)
+        v_l1 = _f32c(v_l1) if v_l1 is not None else None
+        v_ssim = _f32c(v_ssim) if v_ssim is not None else None
+        use_ssim = maps is not None and v_ssim is not None
+        with torch.cuda.device(x.device):
+            L.call("gspl_loss_l1_ssim_bwd", planes, H, W, L.ptr(x), L.ptr(y),
+                   L.ptr(maps[0]) if use_ssim else None, L.ptr(maps[1]) if use_ssim else None, L.ptr(maps[2]) if use_ssim else None,
+                   L.ptr(v_l1), L.ptr(v_ssim), 1.0 if v_l1 is not None else 0.0, 1.0 if use_ssim else 0.0, L.ptr(v_img), L.stream())
+        return v_img.reshape(shape), None, None
+
+
+def l1_ssim(img1: Tensor, img2: Tensor, train: bool = True):
+    """(mean |img1 - img2|, mean SSIM) of [..., H, W] images in one pass over the pixels; differentiable w.r.t. img1."""
+    return _L1SSIMFn.apply(img1, img2, train)
+
+
+def fused_ssim(img1: Tensor, img2: Tensor, padding: str = "same", train: bool = True) -> Tensor:
+    """Drop-in for `fused_ssim.fused_ssim` as the reference calls it (internal/metrics/vanilla_metrics.py:36-38,
+    taming_3dgs_density_controller.py:405): img [B,C,H,W] -> mean SSIM, gradient to img1."""
+    if padding != "same":
+        raise NotImplementedError("fused_ssim: only padding='same' (the reference's call sites use the default)")
+    return _L1SSIMFn.apply(img1, img2, train)[1]
+
+
+def photometric_loss(image: Tensor, gt_image: Tensor, lambda_dssim: float = 0.2) -> Tensor:
+    """(1 - lambda) * L1 + lambda * (1 - SSIM): the reference's training loss (vanilla_metrics.py:66-68), fused."""
+    l1, ssim = _L1SSIMFn.apply(image, gt_image, True)
+    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim)

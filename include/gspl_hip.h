@@ -302,6 +302,26 @@ size_t gspl_knn_workspace_bytes(int N);
 int gspl_knn3_mean_dist2(int N, const float* points, float* out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 8. Fused photometric loss terms ("next" row SURVEY.md §8f rank 2): mean |x - y| and mean SSIM.
+ *    Replaces `l1_loss` + `ssim` (internal/utils/ssim.py:17-63) and the opt-in `fused_ssim` package
+ *    (internal/metrics/vanilla_metrics.py:35-39) in  loss = (1-l) L1 + l (1 - SSIM)  (:57-70).
+ *    SSIM: 11x11 Gaussian window (sigma 1.5, separable), zero padding, C1 = 0.01^2, C2 = 0.03^2, mean
+ *    over all planes * H * W elements.  img1, img2: [planes, H, W] f32 contiguous (planes = batch * channels).
+ *      fwd: out_means[2] = (mean |img1-img2|, mean SSIM); dm_* [planes,H,W] (all three or none): the
+ *           derivative maps the backward needs (pass NULL for evaluation only).
+ *      bwd: v_img1 = weight_l1 * v_l1_mean * d(L1)/d(img1) + weight_ssim * v_ssim_mean * d(SSIM)/d(img1);
+ *           v_*_mean are device scalars (NULL = 1); dm_* NULL drops the SSIM term.
+ * ---------------------------------------------------------------------------------------- */
+size_t gspl_loss_workspace_bytes(int planes, int H, int W);
+int gspl_loss_l1_ssim_fwd(int planes, int H, int W, const float* img1, const float* img2,
+                          float* out_means, float* dm_dmu1 /*nullable*/, float* dm_ds1, float* dm_ds12,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int gspl_loss_l1_ssim_bwd(int planes, int H, int W, const float* img1, const float* img2,
+                          const float* dm_dmu1 /*nullable*/, const float* dm_ds1, const float* dm_ds12,
+                          const float* v_l1_mean /*nullable*/, const float* v_ssim_mean /*nullable*/,
+                          float weight_l1, float weight_ssim, float* v_img1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,9 @@ Fixtures
                        tests/gaussian_projection_test.py:30-113 (inputs and expected values), plus the
                        current reference function's output on it (xys differ from the literals by the
                        documented +0.5 px convention change)
+  ref_ssim.npz         l1_loss() / ssim() of internal/utils/ssim.py on seeded image pairs (smooth, noisy, constant,
+                       odd sizes that do not fill the 16x16 tiles, batch of 2) + autograd gradients w.r.t. the first
+                       image of the reference loss 0.8 L1 + 0.2 (1 - SSIM)
 """
 import importlib.util
 import os
@@ -178,6 +181,40 @@ def gen_kat():
     print("ref_kat.npz radii", cur["cur_radii"], "xys", cur["cur_xys"][[1, 3]])
 
 
+def gen_ssim():
+    ss = _load("ref_ssim", "internal/utils/ssim.py")
+    g = torch.Generator().manual_seed(11)
+    out = {}
+
+    def smooth(c, h, w):
+        yy, xx = torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij")
+        base = torch.stack([0.5 + 0.4 * torch.sin(6.0 * xx + k) * torch.cos(4.0 * yy - k) for k in range(c)])
+        return base.clamp(0, 1)
+
+    cases = {
+        "smooth_3x37x53": (smooth(3, 37, 53), (smooth(3, 37, 53) + 0.05 * torch.randn(3, 37, 53, generator=g)).clamp(0, 1)),
+        "noise_3x64x48": (torch.rand(3, 64, 48, generator=g), torch.rand(3, 64, 48, generator=g)),
+        "const_3x20x20": (torch.full((3, 20, 20), 0.3), torch.full((3, 20, 20), 0.5)),
+        "tiny_1x7x5": (torch.rand(1, 7, 5, generator=g), torch.rand(1, 7, 5, generator=g)),
+        "batch_2x3x33x17": (torch.rand(2, 3, 33, 17, generator=g), torch.rand(2, 3, 33, 17, generator=g)),
+    }
+    for name, (a, b) in cases.items():
+        a = a.clone().requires_grad_(True)
+        a4 = a if a.dim() == 4 else a.unsqueeze(0)
+        b4 = b if b.dim() == 4 else b.unsqueeze(0)
+        l1 = ss.l1_loss(a4, b4)
+        s = ss.ssim(a4, b4)
+        loss = 0.8 * l1 + 0.2 * (1.0 - s)
+        (grad,) = torch.autograd.grad(loss, a)
+        out[name + "/img1"] = a.detach().numpy()
+        out[name + "/img2"] = b.numpy()
+        out[name + "/l1"] = l1.detach().numpy()
+        out[name + "/ssim"] = s.detach().numpy()
+        out[name + "/grad"] = grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_ssim.npz"), **out)
+    print("ref_ssim.npz", {k: float(v) for k, v in out.items() if k.endswith("/ssim")})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are committed, nothing to do")
@@ -186,3 +223,4 @@ if __name__ == "__main__":
     gen_sh()
     gen_sortkey()
     gen_kat()
+    gen_ssim()
