@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
                    help="l1: mean |render - target| with torch ops; photometric: the reference's training loss "
                         "0.8 L1 + 0.2 (1 - SSIM) (vanilla_metrics.py:66-68) through the fused HIP loss kernels")
+    p.add_argument("--optimizer", default="none", choices=["none", "fused-adam", "selective-adam", "torch-adam"],
+                   help="optionally put an optimizer step inside the timed step (single-GPU study; the multi-GPU protocol of "
+                        "north_star exchanges densification statistics only, so the default step has none)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="auto", help="workload name for the CPU baseline leg, or 'auto'")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (code-path test on one GPU)")
@@ -213,6 +216,17 @@ def main():
     cam = synthetic.camera(wl["width"], wl["height"], wl["fx"], distance=4.0 + 0.01 * rank)
     tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
     step = make_step(args.api, dev, wl, cam, tensors, args.loss)
+    optimizer = None
+    if args.optimizer != "none":
+        # eps 1e-15 as the reference (internal/models/vanilla_gaussian.py:266-300).  The bench tensors are ACTIVATED values
+        # (post-exp scales, post-sigmoid opacities), so the reference's learning rates — meant for the raw parameters —
+        # are scaled down by 1e3: the optimizer's cost is measured without letting the synthetic scene drift.
+        groups = [{"params": [t], "lr": lr * 1e-3} for t, lr in zip(tensors, (1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3))]
+        if args.optimizer == "torch-adam":
+            optimizer = torch.optim.Adam(groups, eps=1e-15)
+        else:
+            from gspl_amd import optimizers as gopt
+            optimizer = (gopt.FusedAdam if args.optimizer == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15)
     N = wl["n"]
     accum = torch.zeros(N, device=dev)
     denom = torch.zeros(N, device=dev)
@@ -226,6 +240,11 @@ def main():
         st = step()
         with torch.no_grad():
             densification_stats(st, accum, denom, max_radii)
+            if optimizer is not None:
+                if args.optimizer == "selective-adam":
+                    optimizer.step(st["radii"] > 0)
+                else:
+                    optimizer.step()
             counter["n"] += 1
             # statistics are accumulated locally and made identical on all ranks when a densification would consume
             # them (every DENSIFY_INTERVAL steps) — and once at the end of the timed region so that every run pays
@@ -291,8 +310,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "api": args.api, "n_gaussians": N, "width": wl["width"], "height": wl["height"],
-                       "sh_degree": 3, "loss": args.loss,
-                       "step": "renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd + densification stats",
+                       "sh_degree": 3, "loss": args.loss, "optimizer": args.optimizer,
+                       "step": "renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd + densification stats"
+                               + ("" if args.optimizer == "none" else " + " + args.optimizer + " step"),
                        "parallelism": f"replicated Gaussians, {world} camera(s)/step, all-reduce of densification stats only"},
             "stages_ms": stages,
             "fwd_ms": round(sum(v for k, v in stages.items() if "_bwd" not in k), 4),

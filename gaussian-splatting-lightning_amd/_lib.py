@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -25,6 +25,13 @@ GSPL_LAYOUT_CHW = 1
 GSPL_SH_ADD_HALF_CLAMP = 1
 GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
 GSPL_BIN_SPAN_BYTES = 32
+GSPL_ADAM_MAX_TENSORS = 16
+
+
+class AdamTensor(ctypes.Structure):
+    """`gspl_adam_tensor` of include/gspl_hip.h."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("lr", ctypes.c_float), ("row_elems", ctypes.c_int32)]
 
 
 class HipLibraryError(RuntimeError):
@@ -50,6 +57,7 @@ _SIGNATURES = {
     "gspl_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gspl_loss_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_loss_l1_ssim_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P]),
+    "gspl_selective_adam": (c_int, [c_int, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, _P]),
     "gspl_knn_workspace_bytes": (c_size_t, [c_int]),
     "gspl_knn3_mean_dist2": (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_size_t, _P]),

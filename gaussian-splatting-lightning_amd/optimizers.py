@@ -1,0 +1,144 @@
+"""Fused optimizers for the per-Gaussian parameter tensors.
+
+`SelectiveAdam` mirrors gsplat's optimizer of that name as the reference wraps it (internal/optimizers.py:26-58,
+`configs/gsplat_v1-accel_more.yaml`): Adam without bias correction whose `step(visibility)` only touches the rows of
+visible Gaussians (parameters AND moments of the others stay as they are), all parameter groups in one HIP launch.
+`FusedAdam` is the unmasked, bias-corrected update of `torch.optim.Adam` (the reference's default,
+internal/models/vanilla_gaussian.py:266-300) through the same kernel.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+class _FusedAdamBase(torch.optim.Optimizer):
+    _bias_correction = True
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    def _launch(self, visibility: Optional[torch.Tensor]):
+        L.lib()
+        # tensors are batched per (N, betas, eps, step count): the reference has one parameter per group, all [N, ...]
+        batches = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("fused Adam: parameters must be contiguous fp32 tensors on the GPU")
+                if p.grad.is_sparse:
+                    raise RuntimeError("fused Adam: sparse gradients are not supported")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                N = p.shape[0] if p.dim() > 0 else 1
+                row = p.numel() // max(N, 1)
+                key = (p.device, N, b1, b2, group["eps"], st["step"] if self._bias_correction else 0)
+                batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), row))
+        for (dev, N, b1, b2, eps, step), items in batches.items():
+            vis = None
+            if visibility is not None:
+                if visibility.shape[0] != N:
+                    raise ValueError(f"visibility has {visibility.shape[0]} rows, parameters {N}")
+                vis = visibility.to(device=dev, dtype=torch.uint8).contiguous()
+            bc1 = 1.0 - b1 ** step if self._bias_correction else 1.0
+            bc2s = math.sqrt(1.0 - b2 ** step) if self._bias_correction else 1.0
+            for i in range(0, len(items), L.GSPL_ADAM_MAX_TENSORS):
+                chunk = items[i:i + L.GSPL_ADAM_MAX_TENSORS]
+                table = (L.AdamTensor * len(chunk))()
+                for k, (p, g, m, v, lr, row) in enumerate(chunk):
+                    table[k] = L.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr, row)
+                with torch.cuda.device(dev):
+                    L.call("gspl_selective_adam", len(chunk), ctypes.cast(table, ctypes.c_void_p), N, L.ptr(vis),
+                           b1, b2, eps, bc1, bc2s, L.stream())
+
+
+class SelectiveAdam(_FusedAdamBase):
+    """`SelectiveAdam(params, eps, betas).step(visibility)`: gsplat's visibility-masked Adam (no bias correction)."""
+    _bias_correction = False
+
+    def __init__(self, params, eps: float = 1e-8, betas=(0.9, 0.999), lr: float = 1e-3):
+        super().__init__(params, lr=lr, betas=betas, eps=eps)
+
+    @torch.no_grad()
+    def step(self, visibility: torch.Tensor):
+        self._launch(visibility)
+
+
+class FusedAdam(_FusedAdamBase):
+    """`torch.optim.Adam` semantics (bias-corrected, every row) for [N, ...] fp32 parameters, one launch per step."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._launch(None)
+        return loss
+
+
+# ---- configuration classes in the shape of internal/optimizers.py (selected with e.g.
+#      `--model.gaussian.optimization.optimizer gspl_amd.optimizers.HipSelectiveAdam`) ---------------------------------
+try:                                                            # inside the reference repository: its own base class
+    from internal.optimizers import OptimizerConfig as _OptimizerConfig     # type: ignore
+except Exception:                                               # stand-alone (tests, bench): interface-identical stub
+    class _OptimizerConfig:                                     # internal/optimizers.py:8-11
+        def instantiate(self, params, lr: float, *args, **kwargs):
+            raise NotImplementedError()
+
+from dataclasses import dataclass, field  # noqa: E402
+from typing import Tuple  # noqa: E402
+
+
+@dataclass
+class HipFusedAdam(_OptimizerConfig):
+    """Drop-in for `internal.optimizers.Adam` (internal/optimizers.py:14-22): same update, one launch per step."""
+
+    def instantiate(self, params, lr: float, *args, **kwargs):
+        return FusedAdam(params, lr, *args, **kwargs)
+
+
+@dataclass
+class HipSelectiveAdam(_OptimizerConfig):
+    """Drop-in for `internal.optimizers.SelectiveAdam` (internal/optimizers.py:25-58)."""
+    betas: Tuple[float, float] = field(default_factory=lambda: (0.9, 0.999))
+
+    def instantiate(self, params, lr: float, *args, **kwargs):
+        params = list(params)
+        for group in params:
+            if isinstance(group, dict) and "lr" not in group:
+                group["lr"] = lr
+
+        class Adapter(SelectiveAdam):
+            def on_after_backward(self, outputs, batch, gaussian_model, global_step, pl_module):
+                vs = outputs["viewspace_points"]
+                # the fork's rasterizer tags Gaussians that reached a pixel; without the tag, the projected-visibility mask
+                self.visibility = getattr(vs, "has_hit_any_pixels", None)
+                if self.visibility is None:
+                    self.visibility = outputs["visibility_filter"]
+
+            @torch.no_grad()
+            def step(self, closure=None):
+                loss = None
+                if closure is not None:
+                    with torch.enable_grad():
+                        loss = closure()
+                SelectiveAdam.step(self, self.visibility)
+                return loss
+
+        return Adapter(params, betas=tuple(self.betas), lr=lr, *args, **kwargs)

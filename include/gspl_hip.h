@@ -322,6 +322,31 @@ int gspl_loss_l1_ssim_bwd(int planes, int H, int W, const float* img1, const flo
                           const float* v_l1_mean /*nullable*/, const float* v_ssim_mean /*nullable*/,
                           float weight_l1, float weight_ssim, float* v_img1, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 9. Visibility-masked fused Adam over all per-Gaussian tensors ("next" row SURVEY.md §8f rank 3).
+ *    Replaces gsplat `SelectiveAdam` (internal/optimizers.py:26-58) and, with visible = NULL and the
+ *    bias corrections of step t, the per-property `torch.optim.Adam` steps (vanilla_gaussian.py:266-300).
+ *    For every element of every row n with visible[n] != 0 (NULL: all rows):
+ *        m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ *        p -= (lr / bias_correction1) * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ *    (bias_correction1 = 1 - b1^t, bias_correction2_sqrt = sqrt(1 - b2^t); pass 1, 1 for gsplat's
+ *    uncorrected update).  Masked rows keep parameter and moments.  All tensors are [N, row_elems]
+ *    f32, contiguous, 16-byte aligned; up to GSPL_ADAM_MAX_TENSORS per call, one launch.
+ * ---------------------------------------------------------------------------------------- */
+enum { GSPL_ADAM_MAX_TENSORS = 16 };
+typedef struct gspl_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float lr;
+    int32_t row_elems;
+} gspl_adam_tensor;
+int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host array */, int N,
+                        const uint8_t* visible /*nullable, device [N]*/,
+                        float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif
