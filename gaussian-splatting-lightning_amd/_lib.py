@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -66,9 +66,9 @@ _SIGNATURES = {
                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_composite_bwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
-                                   _P, _P, _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _P, _P, _P]),
     "gspl_composite_bwd_packed": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
-                                          c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+                                          c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_float, c_float, c_float,
                                           _P, _P, _P, _P, _P, _P, _P, c_int, _P]),

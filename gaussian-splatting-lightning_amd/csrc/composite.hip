@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
     const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
     float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
-    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride) {
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride,
+    uint8_t* __restrict__ hit_flags) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
     constexpr int RS = BwdRec<D>::STRIDE;
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
                     const float alpha = fminf(TR::kAlphaMax, raw);
                     const bool valid = (idx < last) && (sigma >= 0.f) && (alpha >= kAlphaMin);
                     if (!__any(valid)) continue;
+                    if (hit_flags && l == 0) hit_flags[s_id[j]] = 1;      // some pixel takes this splat (has_hit_any_pixels)
                     float fac = 0.f, sp = 0.f;
                     if (valid) {
                         // v_rcp_f32 (1 ulp): an IEEE division here expands to ~10 VALU instructions per (pixel, splat) pair
@@ -611,7 +613,8 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
     float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
-    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride) {
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride,
+    uint8_t* __restrict__ hit_flags) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
     constexpr int RS = BwdRec<D>::STRIDE;
@@ -822,6 +825,9 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     const bool validA = (idx < lastA) && (sigma2.x >= 0.f) && (raw2.x >= kAlphaMin);
                     const bool validB = (idx < lastB) && (sigma2.y >= 0.f) && (raw2.y >= kAlphaMin);
                     if (!__any(validA || validB)) continue;
+                    // some pixel takes this splat (has_hit_any_pixels): tagged in LDS with a fire-and-forget ds_or (a read-modify-write
+                    // would put an LDS round trip into every candidate's critical path), reported at the flush
+                    if (hit_flags && l == 0) atomicOr(&s_id[j], (int)0x80000000);
                     const v2f rv2 = {validA ? raw2.x : 0.f, validB ? raw2.y : 0.f};
                     const v2f a2 = {fminf(TR::kAlphaMax, rv2.x), fminf(TR::kAlphaMax, rv2.y)};
                     v2f rw2 = rv2;     // o * vis where the pixel takes a gradient through alpha, else 0
@@ -852,10 +858,10 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                 const float v = s_acc[e];
                 s_acc[e] = 0.f;
                 const int row = e / NV;
-                if (v != 0.f) atomicAdd(&v_packed[(int64_t)s_id[row] * packed_stride + (e - row * NV)], v);
+                if (v != 0.f) atomicAdd(&v_packed[(int64_t)(s_id[row] & 0x7fffffff) * packed_stride + (e - row * NV)], v);
             }
         } else if (t < cnt) {
-            const int g = s_id[t];
+            const int g = s_id[t] & 0x7fffffff;
             float v[NV];
             bool any_nz = false;
 #pragma unroll
@@ -879,6 +885,7 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                 }
             }
         }
+        if (hit_flags && t < cnt && s_id[t] < 0) hit_flags[s_id[t] & 0x7fffffff] = 1;      // one store per (tile, splat) that was composited
         __syncthreads();
     }
 }
@@ -901,30 +908,30 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* final_Ts, const int32_t* last_ids,
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
-                      hipStream_t s, int packed_stride = 0) {
+                      hipStream_t s, int packed_stride = 0, uint8_t* hit_flags = nullptr) {
 #ifndef GSPL_BWD_V2      // default: the two-pixels-per-lane kernel; -DGSPL_BWD_V2 selects the one-pixel-per-lane kernel (A/B builds)
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
-                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     else
         hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(128), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
-                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     return check_launch("composite_bwd");
 #endif
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
-                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     else
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
-                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride);
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     return check_launch("composite_bwd");
 }
 
@@ -985,7 +992,7 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
                                   const float* final_Ts, const int32_t* last_ids,
                                   const float* v_out_colors, const float* v_out_alphas,
                                   float* v_means2d, float* v_means2d_abs,
-                                  float* v_conics, float* v_colors, float* v_opacities, void* stream) {
+                                  float* v_conics, float* v_colors, float* v_opacities, uint8_t* hit_flags, void* stream) {
     using namespace gspl;
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_bwd: bad argument");
     if (rc != GSPL_OK) return rc;
@@ -997,7 +1004,7 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
     hipStream_t s = (hipStream_t)stream;
     const bool absgrad = v_means2d_abs != nullptr;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWD(kD, M, C) rc = launch_bwd<kD, M, C>(absgrad, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, s)
+#define CALL_BWD(kD, M, C) rc = launch_bwd<kD, M, C>(absgrad, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, s, 0, hit_flags)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWD) }
@@ -1021,7 +1028,7 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
                                          const int32_t* offsets, const int32_t* flatten_ids,
                                          const float* final_Ts, const int32_t* last_ids,
                                          const float* v_out_colors, const float* v_out_alphas,
-                                         float* v_packed, int packed_stride, int absgrad, void* stream) {
+                                         float* v_packed, int packed_stride, int absgrad, uint8_t* hit_flags, void* stream) {
     using namespace gspl;
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_bwd_packed: bad argument");
     if (rc != GSPL_OK) return rc;
@@ -1033,7 +1040,7 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
     hipStream_t s = (hipStream_t)stream;
     const bool ag = absgrad != 0;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride)
+#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride, hit_flags)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWDP) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWDP) }

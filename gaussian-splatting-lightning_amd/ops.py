@@ -355,6 +355,12 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 # =============================================================================================
 # compositing
 # =============================================================================================
+# When True, the compositing backward also reports which splats some pixel actually composited and attaches the mask as
+# `has_hit_any_pixels` to the caller's screen-space tensor (the fork-only side channel gsplat's SelectiveAdam adapter
+# reads, internal/optimizers.py:39).  Off by default: it is one more byte store per (tile, splat) in the hot kernel.
+TRACK_HIT_PIXELS = False
+
+
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets, flatten_ids,
@@ -399,10 +405,13 @@ class _CompositeFn(torch.autograd.Function):
         if n_isects > 0 and N > 0:
             v_out = _grad_or_zeros(v_out, final_Ts.shape + (D,) if layout == L.GSPL_LAYOUT_HWC else (D,) + final_Ts.shape, dev)
             v_alphas = _f32c(v_alphas) if v_alphas is not None else None
+            hit = torch.zeros((N,), dtype=torch.uint8, device=dev) if TRACK_HIT_PIXELS else None
             L.call("gspl_composite_bwd_packed",
                 N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
                 width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids), L.ptr(final_Ts), L.ptr(last_ids),
-                L.ptr(v_out), L.ptr(v_alphas), L.ptr(packed), RS, 1 if absgrad else 0, L.stream())
+                L.ptr(v_out), L.ptr(v_alphas), L.ptr(packed), RS, 1 if absgrad else 0, L.ptr(hit), L.stream())
+            if hit is not None:
+                ctx.means2d_ref.has_hit_any_pixels = hit.bool()
         v_means2d, v_conics, v_opac, v_colors = packed[:, 0:2], packed[:, 2:5], packed[:, 5], packed[:, 6:6 + D]
         v_abs = packed[:, 6 + D:8 + D] if absgrad else None
         if absgrad:
@@ -660,6 +669,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
         ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
                    float(s.scale_modifier), colors_precomp is not None, opacities.shape)
         ctx.mark_non_differentiable(radii)
+        ctx.means2D_ref = means2D       # the caller's screen-space tensor: `.has_hit_any_pixels` is attached to it in backward
         return out, radii
 
     @staticmethod
@@ -675,10 +685,13 @@ class _InriaRasterizeFn(torch.autograd.Function):
         RS = _packed_row_stride(9)
         packed = torch.zeros((N, RS), dtype=torch.float32, device=dev)       # x y | a b c | opacity | r g b | pad
         if n_isects > 0:
+            hit = torch.zeros((N,), dtype=torch.uint8, device=dev) if TRACK_HIT_PIXELS else None
             L.call("gspl_composite_bwd_packed",
                 N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
                 L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat), L.ptr(final_Ts), L.ptr(last_ids),
-                L.ptr(v_out), None, L.ptr(packed), RS, 0, L.stream())
+                L.ptr(v_out), None, L.ptr(packed), RS, 0, L.ptr(hit), L.stream())
+            if hit is not None and ctx.means2D_ref is not None:
+                ctx.means2D_ref.has_hit_any_pixels = hit.bool()
         v_opac = packed[:, 5]
         v_means = torch.empty((N, 3), dtype=torch.float32, device=dev)
         v_ndc = torch.empty((N, 3), dtype=torch.float32, device=dev)

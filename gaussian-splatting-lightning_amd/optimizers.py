@@ -123,6 +123,8 @@ class HipSelectiveAdam(_OptimizerConfig):
         for group in params:
             if isinstance(group, dict) and "lr" not in group:
                 group["lr"] = lr
+        from . import ops
+        ops.TRACK_HIT_PIXELS = True      # the compositing backward now reports `viewspace_points.has_hit_any_pixels`
 
         class Adapter(SelectiveAdam):
             def on_after_backward(self, outputs, batch, gaussian_model, global_step, pl_module):

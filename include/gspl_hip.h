@@ -227,6 +227,9 @@ int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int layout,
                        const float* v_out_colors, const float* v_out_alphas /*nullable*/,
                        float* v_means2d, float* v_means2d_abs /*nullable*/,
                        float* v_conics, float* v_colors, float* v_opacities,
+                       uint8_t* hit_flags /*nullable: u8 [N], zero-initialised; set to 1 for every splat that some pixel
+                                            composited (alpha >= 1/255 before termination) — the fork's
+                                            `means2d.has_hit_any_pixels`, internal/optimizers.py:39 */,
                        void* stream);
 
 /*    5b. Same backward with the gradients delivered as ONE packed row per splat:
@@ -242,7 +245,7 @@ int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layo
                               const float* final_Ts, const int32_t* last_ids,
                               const float* v_out_colors, const float* v_out_alphas /*nullable*/,
                               float* v_packed, int packed_stride /* floats per row, >= 6+D(+2) */, int absgrad,
-                              void* stream);
+                              uint8_t* hit_flags /*nullable*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 6. Inria-convention preprocess (the front half of the fused `GaussianRasterizer`).

@@ -38,11 +38,12 @@ def hip_composite_bwd(mode, means2d, conics, colors, opac, bg, W, H, offsets, fl
     z = lambda *s: torch.zeros(s, dtype=torch.float32, device=d)
     v_xy, v_con, v_col, v_op = z(N, 2), z(N, 3), z(N, D), z(N)
     v_abs = z(N, 2) if absgrad else None
+    hit = torch.zeros(N, dtype=torch.uint8, device=d)
     L.check(lib.gspl_composite_bwd(N, flat.shape[0], D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
                                    L.ptr(bg), W, H, 16, tw, th, L.ptr(offsets), L.ptr(flat), L.ptr(final_T), L.ptr(last),
                                    L.ptr(v_out), L.ptr(v_alpha), L.ptr(v_xy), L.ptr(v_abs), L.ptr(v_con), L.ptr(v_col),
-                                   L.ptr(v_op), L.stream()), "composite_bwd")
-    return dict(v_means2d=v_xy, v_means2d_abs=v_abs, v_conics=v_con, v_colors=v_col, v_opacities=v_op)
+                                   L.ptr(v_op), L.ptr(hit), L.stream()), "composite_bwd")
+    return dict(v_means2d=v_xy, v_means2d_abs=v_abs, v_conics=v_con, v_colors=v_col, v_opacities=v_op, hit=hit)
 
 
 def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0):

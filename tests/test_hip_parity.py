@@ -314,6 +314,12 @@ def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
     assert keep.mean() > 0.9            # splats touching a fragile pixel are excused (a pixel touches many splats)
     for k in ("v_means2d", "v_means2d_abs", "v_conics", "v_colors", "v_opacities"):
         assert_close_scaled(got[k].cpu().numpy()[keep], ref[k][keep], 1e-4, f"{k} mode={mode} D={D}", frac_ok=0.9995)
+    # hit flags (the fork's `has_hit_any_pixels`): a splat some pixel composited has a colour weight alpha*T > 0 there, so with a
+    # random dL/dout its oracle colour gradient is non-zero — and zero for every splat no pixel took
+    hit = got["hit"].cpu().numpy().astype(bool)
+    ref_hit = (np.abs(ref["v_colors"]) > 0).any(axis=1)
+    assert np.array_equal(hit[keep], ref_hit[keep])
+    assert 0 < hit.sum() < hit.size or not big
 
 
 def test_composite_layout_chw_equals_hwc(hip):
