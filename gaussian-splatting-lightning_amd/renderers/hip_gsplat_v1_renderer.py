@@ -4,7 +4,7 @@ dataclass, `GSplatV1RendererModule`, and the static `GSplatV1` helper class that
 distributed renderer and several research renderers call (`preprocess_camera`, `project`, `isect_encode`,
 `rasterize`).  All native calls go to the HIP ops.
 
-Not built (raise NotImplementedError, §8f "next"): tile-based culling (StopThePop), fisheye/ortho camera models.
+Not built (raise NotImplementedError, §8f "next"): fisheye/ortho camera models.
 """
 from __future__ import annotations
 
@@ -29,8 +29,6 @@ class HipGSplatV1Renderer(RendererConfig):
     max_viewspace_grad_scale: float = 65535.
 
     def instantiate(self, *args, **kwargs) -> "HipGSplatV1RendererModule":
-        if self.tile_based_culling:
-            raise NotImplementedError("tile_based_culling is not built yet (DESIGN.md, next rows)")
         return HipGSplatV1RendererModule(self)
 
 
@@ -80,6 +78,8 @@ class HipGSplatV1RendererModule(Renderer):
         self.config = config
         self.runtime_options = RuntimeOptions()
         self.isect_encode = GSplatV1.isect_encode_with_unused_opacities
+        if self.config.tile_based_culling:                       # gsplat_v1_renderer.py:85-87
+            self.isect_encode = GSplatV1.isect_encode_tile_based_culling
         self._inv_depth_alt_state = 0
         self._inv_depth_alt = [self.RENDER_TYPE_BITS["inverse_depth"], self.RENDER_TYPE_BITS["hard_inverse_depth"]]
 
@@ -258,19 +258,31 @@ class GSplatV1:
         return cls.isect_encode(preprocessed_camera, projection_results, tile_size)
 
     @classmethod
-    def isect_encode_tile_based_culling(cls, *args, **kwargs):
-        raise NotImplementedError("tile-based culling is not built yet (DESIGN.md, next rows)")
+    def isect_encode_tile_based_culling(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16):
+        """Tile-based culling (StopThePop; reference: gsplat_v1_renderer.py:477-522): a (tile, Gaussian) pair is listed only
+        if the Gaussian can reach alpha >= 1/255 somewhere in the tile.  Here that is the list-only two-level binning with
+        its exact ellipse-vs-tile test (`ops.bin_gaussians`), so the 64-bit keys are never materialised:
+        -> (tiles_per_gauss = None, isect_ids = None, flatten_ids [I'], isect_offsets [1,th,tw]); the reference consumes only
+        the last two (`rasterize`, gsplat_v1_renderer.py:588-601).  `opacities` [1,N]: the ones compositing will use."""
+        img_width, img_height = preprocessed_camera[-1]
+        radii, means2d, depths, conics, _ = projection_results
+        tile_width = math.ceil(int(img_width) / float(tile_size))
+        tile_height = math.ceil(int(img_height) / float(tile_size))
+        flatten_ids, offsets = ops.bin_gaussians(means2d.reshape(-1, 2), depths.reshape(-1), radii.reshape(-1), int(img_height), int(img_width),
+                                                 tile_size, conics=conics.reshape(-1, 3), opacities=opacities.reshape(-1))
+        return None, None, flatten_ids, offsets.reshape(1, tile_height, tile_width)
 
     @classmethod
     def preprocess(cls, preprocessed_camera: Tuple, means3d, scales, quats, eps2d: float = 0.3, anti_aliased: bool = True,
                    tile_size: int = 16, tile_based_culling: bool = False, opacities: torch.Tensor = None):
-        if tile_based_culling:
-            raise NotImplementedError("tile-based culling is not built yet")
         projections = cls.project(preprocessed_camera, means3d=means3d, scales=scales, quats=quats, eps2d=eps2d, anti_aliased=anti_aliased)
         opacities = opacities.unsqueeze(0).squeeze(-1)
         if anti_aliased:
             opacities = opacities * projections[-1]
-        isects = cls.isect_encode(preprocessed_camera, projections, tile_size=tile_size)
+        if tile_based_culling:
+            isects = cls.isect_encode_tile_based_culling(preprocessed_camera, projections, opacities, tile_size=tile_size)
+        else:
+            isects = cls.isect_encode(preprocessed_camera, projections, tile_size=tile_size)
         radii, means2d, depths, conics, compensations = projections
         return (radii, means2d.squeeze(0), depths, conics, compensations), isects, opacities
 

@@ -73,14 +73,15 @@ def test_hip_vanilla_renderer_contract_and_parity():
     assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].detach().max()) > 0
 
 
-@pytest.mark.parametrize("which", ["v0", "v1"])
+@pytest.mark.parametrize("which", ["v0", "v1", "v1-tile-culling"])
 def test_hip_gsplat_renderers_contract_and_parity(which):
     import gspl_amd  # noqa: F401
     from gspl_amd.renderers import HipGSplatRenderer, HipGSplatV1Renderer
     params, cam, wimg, bg = _scene(seed=32)
     model = FakeGaussianModel(*[p.to(DEV) for p in params])
     camera = FakeCamera(cam, DEV)
-    renderer = HipGSplatRenderer(absgrad=True) if which == "v0" else HipGSplatV1Renderer().instantiate()
+    renderer = HipGSplatRenderer(absgrad=True) if which == "v0" else \
+        HipGSplatV1Renderer(tile_based_culling=(which == "v1-tile-culling")).instantiate()
     out = renderer(camera, model, bg.to(DEV))
     for k in ("render", "viewspace_points", "viewspace_points_grad_scale", "visibility_filter", "radii"):
         assert k in out
