@@ -77,7 +77,10 @@ class HipGSplatV1RendererModule(Renderer):
         super().__init__()
         self.config = config
         self.runtime_options = RuntimeOptions()
-        self.isect_encode = GSplatV1.isect_encode_with_unused_opacities
+        # the module consumes only (flatten_ids, isect_offsets): the list-only binning yields exactly the lists of
+        # isect_tiles + isect_offset_encode without materialising and sorting 64-bit keys (2 + 4 radix passes instead of 6
+        # over 12-byte pairs); the static GSplatV1.isect_encode keeps the keyed version for callers that want isect_ids
+        self.isect_encode = GSplatV1.isect_encode_lists_only
         if self.config.tile_based_culling:                       # gsplat_v1_renderer.py:85-87
             self.isect_encode = GSplatV1.isect_encode_tile_based_culling
         self._inv_depth_alt_state = 0
@@ -256,6 +259,17 @@ class GSplatV1:
     @classmethod
     def isect_encode_with_unused_opacities(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16):
         return cls.isect_encode(preprocessed_camera, projection_results, tile_size)
+
+    @classmethod
+    def isect_encode_lists_only(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16):
+        """Same per-tile lists as `isect_encode` (bit-identical flatten_ids / isect_offsets, tests/test_hip_parity.py), without
+        the 64-bit keys: -> (None, None, flatten_ids [I], isect_offsets [1,th,tw])."""
+        img_width, img_height = preprocessed_camera[-1]
+        radii, means2d, depths, _, _ = projection_results
+        tile_width = math.ceil(int(img_width) / float(tile_size))
+        tile_height = math.ceil(int(img_height) / float(tile_size))
+        flatten_ids, offsets = ops.bin_gaussians(means2d.reshape(-1, 2), depths.reshape(-1), radii.reshape(-1), int(img_height), int(img_width), tile_size)
+        return None, None, flatten_ids, offsets.reshape(1, tile_height, tile_width)
 
     @classmethod
     def isect_encode_tile_based_culling(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16):
