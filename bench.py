@@ -119,10 +119,12 @@ def densification_stats(state, accum, denom, max_radii):
     g = state["vs_grad"][:, :2]
     if state["grad_scale"] is not None:
         g = g * state["grad_scale"]
-    vis = state["radii"] > 0
-    accum.add_(torch.where(vis, g.norm(dim=-1), torch.zeros((), device=g.device)))
-    denom.add_(vis.to(denom.dtype))
-    torch.maximum(max_radii, state["radii"].to(max_radii.dtype), out=max_radii)
+    radii = state["radii"]
+    # a Gaussian that is not visible has an exactly zero screen-space gradient, so the masked accumulation of the reference
+    # (`accum[visible] += norm`, vanilla_density_controller.py:117-123) equals the unmasked one
+    accum.add_(torch.linalg.vector_norm(g, dim=-1))
+    denom.add_(radii > 0)
+    torch.maximum(max_radii, radii, out=max_radii)
 
 
 def cpu_baseline(workload_name, api):
@@ -230,7 +232,7 @@ def main():
     N = wl["n"]
     accum = torch.zeros(N, device=dev)
     denom = torch.zeros(N, device=dev)
-    max_radii = torch.zeros(N, device=dev)
+    max_radii = torch.zeros(N, dtype=torch.int32, device=dev)
 
     from gspl_amd import distributed as gdist
     DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
 // out[0] = mean |x - y|, out[1] = mean SSIM; one workgroup of 1024 threads, fixed summation order, fp64 accumulation.
 // The per-thread loads are issued in batches of eight (a one-load-per-iteration loop is a chain of ~1.5 us global-memory
 // round trips: it took 100 us for the 24 480 tiles of a 1080p image).
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(int n_tiles, const float2* __restrict__ partials, double inv_count, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(int n_tiles, const float2* __restrict__ partials, double inv_count, float* __restrict__ out,
+                                                           float w_l1, float w_ssim, int write_loss) {
     __shared__ double s_a[16], s_b[16];
     double a = 0.0, b = 0.0;
     const int t = threadIdx.x;
@@ -208,7 +209,9 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(int n_tiles, const fl
         double ta = 0.0, tb = 0.0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { ta += s_a[k]; tb += s_b[k]; }
-        out[0] = (float)(ta * inv_count); out[1] = (float)(tb * inv_count);
+        const float l1 = (float)(ta * inv_count), ssim = (float)(tb * inv_count);
+        out[0] = l1; out[1] = ssim;
+        if (write_loss) out[2] = w_l1 * l1 + w_ssim * (1.f - ssim);      // the training loss of vanilla_metrics.py:66-68
     }
 }
 
@@ -305,16 +308,16 @@ extern "C" size_t gspl_loss_workspace_bytes(int planes, int H, int W) {
     return tiles * 2 * sizeof(float);
 }
 
-extern "C" int gspl_loss_l1_ssim_fwd(int planes, int H, int W, const float* img1, const float* img2,
-                                     float* out_means, float* dm_dmu1, float* dm_ds1, float* dm_ds12,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+static int loss_fwd_common(int planes, int H, int W, const float* img1, const float* img2, float w_l1, float w_ssim, int write_loss,
+                           float* out_means, float* dm_dmu1, float* dm_ds1, float* dm_ds12,
+                           void* workspace, size_t workspace_bytes, void* stream, const char* who) {
     using namespace gspl;
-    if (planes <= 0 || H <= 0 || W <= 0) return fail_arg("loss_l1_ssim_fwd: bad sizes");
-    if (!img1 || !img2 || !out_means || !workspace) return fail_arg("loss_l1_ssim_fwd: NULL required pointer");
+    if (planes <= 0 || H <= 0 || W <= 0) return fail_arg(who);
+    if (!img1 || !img2 || !out_means || !workspace) return fail_arg(who);
     const bool train = dm_dmu1 != nullptr;
-    if (train && (!dm_ds1 || !dm_ds12)) return fail_arg("loss_l1_ssim_fwd: the three derivative maps go together");
-    if (workspace_bytes < gspl_loss_workspace_bytes(planes, H, W)) return fail_ws("loss_l1_ssim_fwd");
-    if (planes > 65535) return fail_arg("loss_l1_ssim_fwd: more than 65535 planes");
+    if (train && (!dm_ds1 || !dm_ds12)) return fail_arg(who);
+    if (workspace_bytes < gspl_loss_workspace_bytes(planes, H, W)) return fail_ws(who);
+    if (planes > 65535) return fail_arg(who);
     static const SsimWindow win = make_window();
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((W + LTX - 1) / LTX, (H + LTY - 1) / LTY, planes), block(256);
@@ -327,8 +330,23 @@ extern "C" int gspl_loss_l1_ssim_fwd(int planes, int H, int W, const float* img1
     if (rc != GSPL_OK) return rc;
     const int n_tiles = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const float2*)partials,
-                       1.0 / ((double)planes * H * W), out_means);
+                       1.0 / ((double)planes * H * W), out_means, w_l1, w_ssim, write_loss);
     return check_launch("loss_reduce");
+}
+
+extern "C" int gspl_loss_l1_ssim_fwd(int planes, int H, int W, const float* img1, const float* img2,
+                                     float* out_means, float* dm_dmu1, float* dm_ds1, float* dm_ds12,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return loss_fwd_common(planes, H, W, img1, img2, 0.f, 0.f, 0, out_means, dm_dmu1, dm_ds1, dm_ds12, workspace, workspace_bytes, stream,
+                           "loss_l1_ssim_fwd: bad argument");
+}
+
+extern "C" int gspl_loss_photometric_fwd(int planes, int H, int W, const float* img1, const float* img2,
+                                         float weight_l1, float weight_ssim, float* out_terms,
+                                         float* dm_dmu1, float* dm_ds1, float* dm_ds12,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    return loss_fwd_common(planes, H, W, img1, img2, weight_l1, weight_ssim, 1, out_terms, dm_dmu1, dm_ds1, dm_ds12, workspace, workspace_bytes,
+                           stream, "loss_photometric_fwd: bad argument");
 }
 
 extern "C" int gspl_loss_l1_ssim_bwd(int planes, int H, int W, const float* img1, const float* img2,

@@ -818,7 +818,51 @@ def fused_ssim(img1: Tensor, img2: Tensor, padding: str = "same", train: bool = 
     return _L1SSIMFn.apply(img1, img2, train)[1]
 
 
+class _PhotometricLossFn(torch.autograd.Function):
+    """loss = w_l1 * mean|x - y| + w_ssim * (1 - mean SSIM) as ONE forward (tile kernel + reduction that also forms the
+    weighted sum) and ONE backward kernel: no element-wise torch kernels between the two."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, w_l1, w_ssim):
+        lib = L.lib()
+        if not img1.is_cuda or not img2.is_cuda:
+            raise RuntimeError("photometric_loss: images must be on the GPU")
+        if img1.shape != img2.shape or img1.dim() < 2:
+            raise ValueError(f"photometric_loss: shapes {tuple(img1.shape)} vs {tuple(img2.shape)}")
+        x, y = _f32c(img1), _f32c(img2)
+        H, W = int(x.shape[-2]), int(x.shape[-1])
+        planes = x.numel() // (H * W) if H * W > 0 else 0
+        if planes == 0:
+            raise ValueError("photometric_loss: empty image")
+        dev = x.device
+        means = torch.empty((3,), dtype=torch.float32, device=dev)          # (L1, SSIM, weighted loss)
+        keep = img1.requires_grad
+        maps = torch.empty((3, planes, H, W), dtype=torch.float32, device=dev) if keep else None
+        ws_bytes = lib.gspl_loss_workspace_bytes(planes, H, W)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            L.call("gspl_loss_photometric_fwd", planes, H, W, L.ptr(x), L.ptr(y), float(w_l1), float(w_ssim), L.ptr(means),
+                   L.ptr(maps[0]) if keep else None, L.ptr(maps[1]) if keep else None, L.ptr(maps[2]) if keep else None,
+                   L.ptr(ws), ws_bytes, L.stream())
+        ctx.save_for_backward(x, y, maps)
+        ctx.cfg = (planes, H, W, img1.shape, float(w_l1), float(w_ssim))
+        ctx.terms = means            # (L1, SSIM) of the last call, for logging without another pass
+        return means[2]
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        x, y, maps = ctx.saved_tensors
+        planes, H, W, shape, w_l1, w_ssim = ctx.cfg
+        v_img = torch.empty_like(x)
+        v = _f32c(v_loss)
+        with torch.cuda.device(x.device):
+            # d loss = w_l1 * d L1 - w_ssim * d SSIM, both scaled by the same upstream scalar
+            L.call("gspl_loss_l1_ssim_bwd", planes, H, W, L.ptr(x), L.ptr(y),
+                   L.ptr(maps[0]), L.ptr(maps[1]), L.ptr(maps[2]), L.ptr(v), L.ptr(v), w_l1, -w_ssim, L.ptr(v_img), L.stream())
+        return v_img.reshape(shape), None, None, None
+
+
 def photometric_loss(image: Tensor, gt_image: Tensor, lambda_dssim: float = 0.2) -> Tensor:
-    """(1 - lambda) * L1 + lambda * (1 - SSIM): the reference's training loss (vanilla_metrics.py:66-68), fused."""
-    l1, ssim = _L1SSIMFn.apply(image, gt_image, True)
-    return (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim)
+    """(1 - lambda) * L1 + lambda * (1 - SSIM): the reference's training loss (vanilla_metrics.py:66-68), one forward and one
+    backward kernel."""
+    return _PhotometricLossFn.apply(image, gt_image, 1.0 - lambda_dssim, lambda_dssim)

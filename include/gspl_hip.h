@@ -320,6 +320,13 @@ size_t gspl_loss_workspace_bytes(int planes, int H, int W);
 int gspl_loss_l1_ssim_fwd(int planes, int H, int W, const float* img1, const float* img2,
                           float* out_means, float* dm_dmu1 /*nullable*/, float* dm_ds1, float* dm_ds12,
                           void* workspace, size_t workspace_bytes, void* stream);
+/*    The training loss in one go: out_terms[3] = (mean|x-y|, mean SSIM, weight_l1 * L1 + weight_ssim * (1 - SSIM)),
+ *    i.e. vanilla_metrics.py:66-68 with weight_l1 = 1 - lambda_dssim, weight_ssim = lambda_dssim.  Its backward is
+ *    gspl_loss_l1_ssim_bwd with both upstream pointers = dL/dloss and weights (weight_l1, -weight_ssim). */
+int gspl_loss_photometric_fwd(int planes, int H, int W, const float* img1, const float* img2,
+                              float weight_l1, float weight_ssim, float* out_terms,
+                              float* dm_dmu1 /*nullable*/, float* dm_ds1, float* dm_ds12,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int gspl_loss_l1_ssim_bwd(int planes, int H, int W, const float* img1, const float* img2,
                           const float* dm_dmu1 /*nullable*/, const float* dm_ds1, const float* dm_ds12,
                           const float* v_l1_mean /*nullable*/, const float* v_ssim_mean /*nullable*/,

@@ -67,5 +67,6 @@ def test_renderer_plugins_importable_and_picklable():
     mod = cfg.instantiate()
     assert isinstance(mod, Renderer) and isinstance(HipVanillaRenderer(), Renderer) and isinstance(HipGSplatRenderer(), Renderer)
     assert "rgb" in mod.get_available_outputs() and mod.parse_render_types(["rgb", "alpha"]) == 1 | 2 | 4
-    with pytest.raises(NotImplementedError):
-        HipGSplatV1Renderer(tile_based_culling=True).instantiate()
+    from gspl_amd.renderers import GSplatV1
+    culling = HipGSplatV1Renderer(tile_based_culling=True).instantiate()
+    assert culling.isect_encode == GSplatV1.isect_encode_tile_based_culling and mod.isect_encode == GSplatV1.isect_encode_lists_only
