@@ -92,10 +92,15 @@ template <bool TRAIN>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(
     int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
     float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1, float* __restrict__ dm_ds12, float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) lv2 s_p[LPY][LPS];           // (x, y)
-    __shared__ __attribute__((aligned(16))) lv2 s_hm[LTX][LRS];          // [column][row] (mu1, mu2) after the horizontal pass
-    __shared__ __attribute__((aligned(16))) lv2 s_hq[LTX][LRS];          // (E[x^2], E[y^2])
-    __shared__ __attribute__((aligned(16))) float s_hc[LTX][LRS];        // E[xy]
+    // LDS: the input patch, then (after every thread has its inputs in registers) the transposed horizontal results on
+    // top of it — 18 KB per workgroup instead of 27, i.e. 8 instead of 5 workgroups per CU
+    constexpr int PATCH_BYTES = LPY * LPS * (int)sizeof(lv2);
+    constexpr int HRES_BYTES = LTX * LRS * (2 * (int)sizeof(lv2) + (int)sizeof(float));
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES > HRES_BYTES ? PATCH_BYTES : HRES_BYTES];
+    lv2 (*s_p)[LPS] = reinterpret_cast<lv2 (*)[LPS]>(s_raw);                                      // (x, y)
+    lv2 (*s_hm)[LRS] = reinterpret_cast<lv2 (*)[LRS]>(s_raw);                                     // [column][row] (mu1, mu2)
+    lv2 (*s_hq)[LRS] = reinterpret_cast<lv2 (*)[LRS]>(s_raw + LTX * LRS * sizeof(lv2));           // (E[x^2], E[y^2])
+    float (*s_hc)[LRS] = reinterpret_cast<float (*)[LRS]>(s_raw + 2 * LTX * LRS * sizeof(lv2));   // E[xy]
     __shared__ float s_red[4];
     const int plane = blockIdx.z;
     const int x0 = blockIdx.x * LTX, y0 = blockIdx.y * LTY;
@@ -120,27 +125,39 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
         if (i < LPY * LPS) s_p[i / LPS][i % LPS] = pv[k];
     }
     __syncthreads();
-    // horizontal pass: 26 rows x 8 segments of 4 columns (208 threads)
-    if (t < LPY * LHSEG) {
-        const int r = t / LHSEG, c0 = (t % LHSEG) * 4;
-        lv2 v[16], q[16], o[4];
+    // horizontal pass: 26 rows x 8 segments of 4 columns (208 threads); the L1 term of the segment's own pixels rides along
+    float l1_acc = 0.f, ssim_acc = 0.f;
+    const bool hthread = t < LPY * LHSEG;
+    const int hr = t / LHSEG, hc0 = (t % LHSEG) * 4;
+    lv2 hv[16];
+    if (hthread) {
+        load16(&s_p[hr][hc0], hv);
+        if (hr >= LH && hr < LH + LTY) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = x0 + hc0 + j, gy = y0 + hr - LH;
+                if (gx < W && gy < H) l1_acc += fabsf(hv[LH + j].x - hv[LH + j].y);
+            }
+        }
+    }
+    __syncthreads();                 // every thread holds its inputs: the patch may be overwritten
+    if (hthread) {
+        lv2 q[16], o[4];
         float xy[16], oc[4];
-        load16(&s_p[r][c0], v);
-        window4(v, win, o);
+        window4(hv, win, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_hm[c0 + j][r] = o[j];
+        for (int j = 0; j < 4; ++j) s_hm[hc0 + j][hr] = o[j];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { q[i] = v[i] * v[i]; xy[i] = v[i].x * v[i].y; }
+        for (int i = 0; i < 16; ++i) { q[i] = hv[i] * hv[i]; xy[i] = hv[i].x * hv[i].y; }
         window4(q, win, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_hq[c0 + j][r] = o[j];
+        for (int j = 0; j < 4; ++j) s_hq[hc0 + j][hr] = o[j];
         window4(xy, win, oc);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_hc[c0 + j][r] = oc[j];
+        for (int j = 0; j < 4; ++j) s_hc[hc0 + j][hr] = oc[j];
     }
     __syncthreads();
     // vertical pass: 32 columns x 4 segments of 4 rows (128 threads), each thread finishes 4 pixels
-    float l1_acc = 0.f, ssim_acc = 0.f;
     if (t < LTX * LVSEG) {
         const int c = t % LTX, r0 = (t / LTX) * 4;
         lv2 v[16], mu[4], ee[4];
@@ -159,8 +176,6 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
                 const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cd = mu1_sq + mu2_sq + C1, Dd = s1 + s2 + C2;
                 const float m = (A * B) / (Cd * Dd);
                 ssim_acc += m;
-                const lv2 px = s_p[r0 + j + LH][c + LH];
-                l1_acc += fabsf(px.x - px.y);
                 if (TRAIN) {
                     // partial derivatives of m w.r.t. (mu1, s1, s12), then the mu1 dependence of s1 = E[x^2] - mu1^2 and
                     // s12 = E[xy] - mu1 mu2 folded into the first, so that the backward only needs dE-type convolutions
@@ -222,10 +237,13 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
     const float* __restrict__ dm_dmu1, const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12,
     const float* __restrict__ v_l1_mean, const float* __restrict__ v_ssim_mean, float scale_l1, float scale_ssim,
     float* __restrict__ v_img1) {
-    __shared__ __attribute__((aligned(16))) lv2 s_da[LPY][LPS];          // (dm_dmu1, dm_ds1)
-    __shared__ __attribute__((aligned(16))) float s_dc[LPY][LPS];        // dm_ds12
-    __shared__ __attribute__((aligned(16))) lv2 s_ha[LTX][LRS];          // [column][row]
-    __shared__ __attribute__((aligned(16))) float s_hc[LTX][LRS];
+    constexpr int PATCH_BYTES = LPY * LPS * ((int)sizeof(lv2) + (int)sizeof(float));
+    constexpr int HRES_BYTES = LTX * LRS * ((int)sizeof(lv2) + (int)sizeof(float));
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES > HRES_BYTES ? PATCH_BYTES : HRES_BYTES];
+    lv2 (*s_da)[LPS] = reinterpret_cast<lv2 (*)[LPS]>(s_raw);                                     // (dm_dmu1, dm_ds1)
+    float (*s_dc)[LPS] = reinterpret_cast<float (*)[LPS]>(s_raw + LPY * LPS * sizeof(lv2));       // dm_ds12
+    lv2 (*s_ha)[LRS] = reinterpret_cast<lv2 (*)[LRS]>(s_raw);                                     // [column][row], over the patch
+    float (*s_hc)[LRS] = reinterpret_cast<float (*)[LRS]>(s_raw + LTX * LRS * sizeof(lv2));
     const int plane = blockIdx.z;
     const int x0 = blockIdx.x * LTX, y0 = blockIdx.y * LTY;
     const int t = threadIdx.x;
@@ -263,18 +281,21 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
         if (i < LPY * LPS) { s_da[i / LPS][i % LPS] = pa[k]; s_dc[i / LPS][i % LPS] = pc[k]; }
     }
     __syncthreads();
-    if (t < LPY * LHSEG) {
+    {
+        const bool hthread = t < LPY * LHSEG;
         const int r = t / LHSEG, c0 = (t % LHSEG) * 4;
         lv2 v[16], o[4];
         float vc[16], oc[4];
-        load16(&s_da[r][c0], v);
-        window4(v, win, o);
+        if (hthread) { load16(&s_da[r][c0], v); load16(&s_dc[r][c0], vc); }
+        __syncthreads();             // every thread holds its inputs: the patch may be overwritten
+        if (hthread) {
+            window4(v, win, o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_ha[c0 + j][r] = o[j];
-        load16(&s_dc[r][c0], vc);
-        window4(vc, win, oc);
+            for (int j = 0; j < 4; ++j) s_ha[c0 + j][r] = o[j];
+            window4(vc, win, oc);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_hc[c0 + j][r] = oc[j];
+            for (int j = 0; j < 4; ++j) s_hc[c0 + j][r] = oc[j];
+        }
     }
     __syncthreads();
     if (t < LTX * LVSEG) {
