@@ -595,6 +595,9 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
 // Pixels that do not take a splat (alpha < 1/255, behind their last contributor, outside the image) run with
 // alpha = 0, which leaves T, R and the emitted (fac, sp) exactly neutral (1/(1-0) = 1), so no exec masking is needed.
 // Phase 2: lane = (slot s of P2_SLOTS, column c of the half tile's 16), 8 rows per lane, row_sum (16-lane DPP) finish.
+#ifdef GSPL_COUNT_PAIRS
+__device__ unsigned long long g_pair_stats[4];      // instrumentation build only: candidates, valid pixel pairs, candidates with any valid pixel
+#endif
 #ifndef GSPL_BWD2_CHUNK
 #define GSPL_BWD2_CHUNK 64
 #endif
@@ -824,6 +827,17 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     // alpha = min(kAlphaMax, raw) >= 1/255  <=>  raw >= 1/255
                     const bool validA = (idx < lastA) && (sigma2.x >= 0.f) && (raw2.x >= kAlphaMin);
                     const bool validB = (idx < lastB) && (sigma2.y >= 0.f) && (raw2.y >= kAlphaMin);
+#ifdef GSPL_COUNT_PAIRS
+                    {
+                        const unsigned long long ba = __ballot(validA), bb = __ballot(validB);
+                        if (l == 0) {
+                            atomicAdd(&g_pair_stats[0], 1ull);
+                            atomicAdd(&g_pair_stats[1], (unsigned long long)(__builtin_popcountll(ba) + __builtin_popcountll(bb)));
+                            if (ba | bb) atomicAdd(&g_pair_stats[2], 1ull);
+                            if (ba && bb) atomicAdd(&g_pair_stats[3], 1ull);
+                        }
+                    }
+#endif
                     if (!__any(validA || validB)) continue;
                     // some pixel takes this splat (has_hit_any_pixels): tagged in LDS with a fire-and-forget ds_or (a read-modify-write
                     // would put an LDS round trip into every candidate's critical path), reported at the flush
@@ -1051,3 +1065,16 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
 #undef CALL_BWDP
     return rc;
 }
+
+#ifdef GSPL_COUNT_PAIRS
+// instrumentation build only: copy (and optionally reset) the pair counters of composite_bwd2_kernel
+extern "C" int gspl_debug_pair_stats(unsigned long long* out4, int reset) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(gspl::g_pair_stats), 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gspl::g_pair_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
