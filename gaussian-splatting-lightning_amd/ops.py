@@ -15,7 +15,6 @@ All arithmetic happens in libgspl_hip.so; nothing here falls back to PyTorch mat
 """
 from __future__ import annotations
 
-import math
 from typing import NamedTuple, Optional, Tuple
 
 import torch

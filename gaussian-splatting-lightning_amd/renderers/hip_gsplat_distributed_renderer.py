@@ -15,7 +15,7 @@ Random redistribution (:432-510) uses one all_to_all_single per tensor (`distrib
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 import torch.distributed as dist

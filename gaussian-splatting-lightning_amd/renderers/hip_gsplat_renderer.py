@@ -11,7 +11,7 @@ Differences that are deliberate:
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 
