@@ -15,6 +15,8 @@ WORKLOADS = {
     # stress points (not headline): garden-like count at the reference's images_4 resolution, and 4K
     "S-garden-6M": dict(n=6_000_000, width=1297, height=840, fx=961.4),
     "S-4k-2M": dict(n=2_000_000, width=3840, height=2160, fx=3200.0),
+    # BASELINE.json configs[2] proxy: a garden-sized model (~6 M Gaussians) at the metric resolution
+    "S-1080p-6M": dict(n=6_000_000, width=1920, height=1080, fx=1600.0),
 }
 
 
