@@ -17,6 +17,9 @@
 
 namespace gspl {
 
+#ifndef GSPL_SH_U
+#define GSPL_SH_U 6
+#endif
 static constexpr int SH_BLOCK = 256;
 static constexpr int SH_MAX_K = 25;
 
@@ -103,7 +106,7 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ g, int rows,
         const float4* g4 = reinterpret_cast<const float4*>(g);
         // batches of U independent 16-B loads per lane before any LDS write: keeps U KiB per wave in flight
         // (a load -> scatter -> load chain leaves the memory pipe idle most of the time: SQ_WAIT_ANY was 77 %)
-        constexpr int U = 6;
+        constexpr int U = GSPL_SH_U;
         for (int b4 = t; b4 < n4; b4 += SH_BLOCK * U) {
             float4 v[U];
 #pragma unroll
