@@ -73,6 +73,27 @@ def test_hip_vanilla_renderer_contract_and_parity():
     assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].detach().max()) > 0
 
 
+def test_config1_lego_proxy_800x800_100k_vanilla_renderer_vs_oracle():
+    """BASELINE.json configs[0]/[1] proxy (S-800-100k: 100 000 Gaussians of the Blender init box at 800x800, SH degree 3,
+    vanilla renderer) end to end against the fp64 oracle: render within 1e-5, every parameter gradient within 1e-4."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import synthetic
+    from gspl_amd.renderers import HipVanillaRenderer
+    wl = synthetic.WORKLOADS["S-800-100k"]
+    params = O.synthetic_scene(wl["n"], seed=42)
+    cam = O.synthetic_camera(wl["width"], wl["height"], wl["fx"])
+    g = torch.Generator().manual_seed(1)
+    wimg = torch.randn(3, wl["height"], wl["width"], generator=g)
+    bg = torch.zeros(3)
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    out = HipVanillaRenderer()(FakeCamera(cam, DEV), model, bg.to(DEV))
+    out["viewspace_points"].retain_grad()
+    (out["render"] * wimg.to(DEV)).sum().backward()
+    r, dl = _oracle_grads("inria", params, cam, wimg, bg)
+    _check(model, dl, out["render"], r)
+    assert int(out["visibility_filter"].sum()) > 90_000          # the survey measured V = 94 935 with the reference's projection
+
+
 @pytest.mark.parametrize("which", ["v0", "v1", "v1-tile-culling"])
 def test_hip_gsplat_renderers_contract_and_parity(which):
     import gspl_amd  # noqa: F401
