@@ -215,7 +215,7 @@ def main():
     wl = synthetic.WORKLOADS[args.workload]
     means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
     # every rank renders its own camera (cameras sharded): a small per-rank dolly keeps the work equal
-    cam = synthetic.camera(wl["width"], wl["height"], wl["fx"], distance=4.0 + 0.01 * rank)
+    cam = synthetic.camera(wl["width"], wl["height"], wl["fx"], distance=wl.get("distance", 4.0) + 0.01 * rank)
     tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
     step = make_step(args.api, dev, wl, cam, tensors, args.loss)
     optimizer = None

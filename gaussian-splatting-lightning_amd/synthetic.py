@@ -17,6 +17,9 @@ WORKLOADS = {
     "S-4k-2M": dict(n=2_000_000, width=3840, height=2160, fx=3200.0),
     # BASELINE.json configs[2] proxy: a garden-sized model (~6 M Gaussians) at the metric resolution
     "S-1080p-6M": dict(n=6_000_000, width=1920, height=1080, fx=1600.0),
+    # camera INSIDE the cloud (distance 0.4 from its centre): roughly half of the Gaussians are behind the camera or outside
+    # the frustum, as in real captures; exercises the visibility-masked SH loads
+    "S-1080p-1M-inside": dict(n=1_000_000, width=1920, height=1080, fx=1600.0, distance=0.4),
 }
 
 
