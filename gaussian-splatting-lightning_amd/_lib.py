@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -24,7 +24,7 @@ GSPL_LAYOUT_HWC = 0
 GSPL_LAYOUT_CHW = 1
 GSPL_SH_ADD_HALF_CLAMP = 1
 GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
-GSPL_BIN_SPAN_BYTES = 32
+GSPL_BIN_SPAN_BYTES = 64
 GSPL_ADAM_MAX_TENSORS = 16
 
 

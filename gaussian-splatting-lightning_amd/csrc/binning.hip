@@ -213,13 +213,16 @@ __device__ __forceinline__ void row_columns(const SplatCull& s, int ty, int tile
 // scattered reads (means2d, radii, conics, opacities) plus the span arithmetic all over again.
 struct __attribute__((aligned(16))) SpanRecord {
     uint16_t miny;              // first tile row
-    uint16_t rows;              // number of tile rows; SPAN_BIG: not representable here (more than EMIT_ROWS rows or a row wider than 255)
+    uint16_t rows;              // number of tile rows; SPAN_BIG: not representable (more than EMIT_ROWS rows or a row wider than 255)
     uint16_t c0[8];             // first reachable tile column of each row
     uint8_t n[8];               // reachable tiles of each row
     uint32_t pad;
 };
 static_assert(sizeof(SpanRecord) == 32, "span record is one 32-byte line");
-static constexpr int EMIT_ROWS = 8;
+// Rows 8..15 of splats taller than 8 tile rows live in a second 32-byte record (words: c0[8..15] as 4 words, n[8..15] as 2
+// words), in a second array after the N primary records: written and read only for those splats, so the common case
+// stays at one line per splat while close-up splats up to 16 tile rows (radius ~128 px) keep the load-balanced path.
+static constexpr int EMIT_ROWS = 16;
 static constexpr uint16_t SPAN_BIG = 0xFFFFu;
 
 template <int MODE>
@@ -232,8 +235,10 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
     if (g >= N) return;
     int n = 0;
     const int radius = radii[g];
-    // the record is assembled in eight 32-bit words (static indices only, so that it stays in registers)
-    uint32_t w0 = 0u, wc[4] = {0u, 0u, 0u, 0u}, wn[2] = {0u, 0u};
+    // the records are assembled in 32-bit words (static indices only, so that they stay in registers)
+    uint32_t w0 = 0u, wc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, wn[4] = {0u, 0u, 0u, 0u};
+    int rows = 0;
+    bool big = false;
     if (radius > 0) {
         int minx, miny, maxx, maxy;
         const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
@@ -241,8 +246,8 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
         SplatCull sc;
         sc.kind = 2;
         if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
-        const int rows = max(maxy - miny, 0);
-        bool big = rows > EMIT_ROWS;
+        rows = max(maxy - miny, 0);
+        big = rows > EMIT_ROWS;
 #pragma unroll
         for (int r = 0; r < EMIT_ROWS; ++r) {
             int c0 = 0, c1 = 0;
@@ -266,6 +271,11 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
     uint4* dst = reinterpret_cast<uint4*>(spans + g);      // layout of SpanRecord (little endian)
     dst[0] = make_uint4(w0, wc[0], wc[1], wc[2]);
     dst[1] = make_uint4(wc[3], wn[0], wn[1], 0u);
+    if (rows > 8 && !big) {
+        uint4* ext = reinterpret_cast<uint4*>(spans + N + g);
+        ext[0] = make_uint4(wc[4], wc[5], wc[6], wc[7]);
+        ext[1] = make_uint4(wn[2], wn[3], 0u, 0u);
+    }
 }
 
 // counts[order[i]] as int64: the input "array" of the scan over per-splat tile counts in depth order (no gather pass)
@@ -323,9 +333,15 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
         }
     }
     const uint32_t rec_rows = ra.x >> 16, rec_miny = ra.x & 0xFFFFu;
-    const uint32_t wc[4] = {ra.y, ra.z, ra.w, rb.x}, wn[2] = {rb.y, rb.z};
     const bool big = cnt > 0 && rec_rows == (uint32_t)SPAN_BIG;
-    // the few splats the record cannot describe (many tile rows, or a very wide row) recompute their spans from the inputs
+    uint4 ea = make_uint4(0u, 0u, 0u, 0u), eb = make_uint4(0u, 0u, 0u, 0u);      // rows 8..15 (second record), only when present
+    if (cnt > 0 && !big && rec_rows > 8u) {
+        const uint4* src = reinterpret_cast<const uint4*>(spans + N + g);
+        ea = src[0];
+        eb = src[1];
+    }
+    const uint32_t wc[8] = {ra.y, ra.z, ra.w, rb.x, ea.x, ea.y, ea.z, ea.w}, wn[4] = {rb.y, rb.z, eb.x, eb.y};
+    // the few splats the records cannot describe (more than 16 tile rows, or a very wide row) recompute their spans from the inputs
     SplatCull sc;
     sc.kind = 2;
     if (big) {
@@ -362,9 +378,9 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
         const int o = lo;
         if ((big_mask >> o) & 1ull) continue;      // emitted in phase B
         const int kk = k - s_start[w][o];
-        int r = 0;
+        int r = 0;                                  // last row whose prefix <= kk (empty rows share their successor's prefix)
 #pragma unroll
-        for (int q = 1; q < EMIT_ROWS; ++q) r += (kk >= (int)s_pre[w][o][q]) ? 1 : 0;
+        for (int step = EMIT_ROWS / 2; step > 0; step >>= 1) r += (kk >= (int)s_pre[w][o][r + step]) ? step : 0;
         const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
         const int ty = s_row0[w][o] + r;
         tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
@@ -497,6 +513,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     int rc = plan_bin(N, 0, w);
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total_count) return fail_ws("bin_count");
+    static_assert(GSPL_BIN_SPAN_BYTES == 2 * sizeof(SpanRecord), "spans = N primary + N extension records");
     char* ws = (char*)workspace;
     uint32_t* keys = (uint32_t*)(ws + w.keys_off);
     uint32_t* ids = (uint32_t*)(ws + w.ids_off);

@@ -169,10 +169,11 @@ int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids,
  *    gradients are unchanged, while the lists shrink by ~40 % (the 3-sigma square of the reference's
  *    rect is loose, the more so for low opacities).  Pass the SAME opacities the compositing call uses.
  *    spans: caller-owned scratch of GSPL_BIN_SPAN_BYTES per splat, written by gspl_bin_count (the reachable tile
- *    columns of each tile row of the splat) and read back, in depth order, by gspl_bin_emit_sort — one 32-byte
- *    line per splat instead of re-gathering means2d / radii / conics / opacities at random addresses.
+ *    columns of each tile row of the splat: N records for rows 0..7, then N records for rows 8..15 that only taller
+ *    splats touch) and read back, in depth order, by gspl_bin_emit_sort — one 32-byte line per splat instead of
+ *    re-gathering means2d / radii / conics / opacities at random addresses.
  * ---------------------------------------------------------------------------------------- */
-enum { GSPL_BIN_SPAN_BYTES = 32 };
+enum { GSPL_BIN_SPAN_BYTES = 64 };
 size_t gspl_bin_workspace_bytes(int N, int64_t n_isects);
 int gspl_bin_count(int N, int mode,
                    const float* means2d, const int32_t* radii, const float* depths,
