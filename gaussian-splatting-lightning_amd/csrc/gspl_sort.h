@@ -1,0 +1,45 @@
+// gspl_sort.h — stable LSD radix sort of the binning stage (host interface; kernels in sort.hip).
+//
+// The two sorts of a frame (1 M depth keys with splat ids; ~14 M (tile | rank) records) are small: a library sort spends
+// as long in its per-pass bookkeeping launches (two buffer fills per pass for the look-back state, a histogram kernel and
+// a scan kernel per sort: 18 extra launches, ~0.1 ms of a 1.3 ms training step) as in moving keys.  This sort keeps the
+// one-sweep structure (a single read and a single write of the data per pass, chained-scan look-back between tiles) and
+// strips the rest:
+//   * ONE header kernel per sort computes the digit histograms of every pass and clears the look-back states of every
+//     pass (or no kernel at all when the producer of the keys did both, see `RadixSort::prepared`);
+//   * one kernel per pass; tiles are handed out through an atomic ticket so a tile only ever waits for tiles that are
+//     already running, the per-tile state is one 32-bit word (2 flag bits | 30 count bits) moved with agent-scope
+//     relaxed atomics — coherent across the eight XCD L2s without cache write-backs, and self-describing, so no fences.
+// Sizes above 2^30 - 1 items do not fit the state word: callers fall back to rocPRIM there.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace gspl {
+
+static constexpr int RADIX_MAX_PASSES = 4;
+static constexpr int RADIX_BINS = 256;                 // row width of the histogram / look-back tables
+static constexpr int RADIX_TILE = 2048;                // items per tile (512 threads x 4)
+static constexpr size_t RADIX_MAX_ITEMS = (1u << 30) - 1u;
+
+struct RadixPlan {
+    int passes;
+    int shift[RADIX_MAX_PASSES];
+    int bits[RADIX_MAX_PASSES];
+    uint32_t n;
+    uint32_t ntiles;
+    // workspace layout (byte offsets): [hist: passes x 256 u32][tickets: 4 u32 + pad][states: passes x ntiles x 256 u32]
+    size_t hist_off, ticket_off, states_off, header_bytes, total_bytes;
+};
+
+// Plan a sort of key bits [begin_bit, end_bit).  digit_bits = widest digit (<= 8); passes = ceil(bits / digit_bits),
+// the bits are spread evenly over the passes.  Returns false if the request is not representable.
+bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, RadixPlan& plan);
+
+// Sort.  keys[0]/vals[0] hold the input; buffer 1 is scratch of the same size.  The sorted sequence ends in buffer
+// (plan.passes & 1).  vals may be nullptr (keys only).  `prepared`: the caller already zeroed the header
+// (plan.header_bytes at workspace + plan.hist_off), accumulated the histograms and cleared the states.
+int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
+int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
+
+}  // namespace gspl

@@ -732,6 +732,44 @@ class GaussianRasterizer(torch.nn.Module):
 
 
 # =============================================================================================
+# radix sort of the binning stage (exported for the parity tests)
+# =============================================================================================
+def _radix_sort(fn: str, keys: Tensor, vals, begin_bit: int, end_bit: int):
+    import ctypes
+    lib = L.lib()
+    n = keys.numel()
+    k0, k1 = keys.clone(), torch.empty_like(keys)
+    v0 = v1 = None
+    if vals is not None:
+        v0, v1 = vals.clone(), torch.empty_like(vals)
+    ws_bytes = lib.gspl_radix_sort_workspace_bytes(n, begin_bit, end_bit)
+    if ws_bytes == 0:
+        raise RuntimeError("gspl_radix_sort_workspace_bytes: unsupported size or bit range")
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=keys.device)
+    res = ctypes.c_int(-1)
+    with torch.cuda.device(keys.device):
+        if vals is not None:
+            L.call(fn, n, L.ptr(k0), L.ptr(k1), L.ptr(v0), L.ptr(v1), begin_bit, end_bit, ctypes.byref(res), L.ptr(ws), ws_bytes, L.stream())
+        else:
+            L.call(fn, n, L.ptr(k0), L.ptr(k1), begin_bit, end_bit, ctypes.byref(res), L.ptr(ws), ws_bytes, L.stream())
+    return ((k0, v0), (k1, v1))[res.value]
+
+
+def radix_sort_pairs(keys: Tensor, vals: Tensor, begin_bit: int = 0, end_bit: int = 32):
+    """Stable ascending sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit): the depth sort of
+    `bin_gaussians`, exposed for the parity tests.  keys/vals: int32 or uint32 tensors holding the bit patterns."""
+    assert keys.is_cuda and keys.dtype in (torch.int32, torch.uint32) and vals.dtype in (torch.int32, torch.uint32)
+    return _radix_sort("gspl_radix_sort_pairs_u32", keys.contiguous(), vals.contiguous(), begin_bit, end_bit)
+
+
+def radix_sort_keys64(keys: Tensor, begin_bit: int, end_bit: int) -> Tensor:
+    """Stable ascending sort of u64 records on key bits [begin_bit, end_bit) (at most 32 bits): the tile sort of
+    `bin_gaussians`.  keys: int64 tensor holding the bit patterns."""
+    assert keys.is_cuda and keys.dtype == torch.int64
+    return _radix_sort("gspl_radix_sort_keys_u64", keys.contiguous(), None, begin_bit, end_bit)[0]
+
+
+# =============================================================================================
 # simple_knn  (SURVEY.md §8f rank 1)
 # =============================================================================================
 def distCUDA2(points: Tensor) -> Tensor:

@@ -358,6 +358,23 @@ int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host a
                         float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 10. Stable LSD radix sort of the binning stage, exported for the parity tests.
+ *    The sorts inside gspl_bin_count (depth keys + splat ids, u32 pairs) and gspl_bin_emit_sort
+ *    ((tile | rank) records, u64 keys only) stand in for the cub::DeviceRadixSort::SortPairs calls
+ *    of the reference's native rasterizers (gsplat `isect_tiles` behind gsplat_v1_renderer.py:524-556,
+ *    the Inria rasterizer behind vanilla_renderer.py:111): stable, ascending on key bits
+ *    [begin_bit, end_bit); at most 32 selected bits (4 passes of <= 8 bits), at most 2^30-1 items.
+ *    Buffer 0 holds the input and is overwritten; buffer 1 is scratch of the same size; the sorted
+ *    sequence ends in buffer *result_buffer (0 or 1).
+ * ---------------------------------------------------------------------------------------- */
+size_t gspl_radix_sort_workspace_bytes(int64_t n, int begin_bit, int end_bit);
+int gspl_radix_sort_pairs_u32(int64_t n, uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1,
+                              int begin_bit, int end_bit, int* result_buffer /* host */,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int gspl_radix_sort_keys_u64(int64_t n, uint64_t* keys0, uint64_t* keys1, int begin_bit, int end_bit,
+                             int* result_buffer /* host */, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
