@@ -59,7 +59,7 @@ _SIGNATURES = {
     "gspl_loss_photometric_fwd": (c_int, [c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_loss_l1_ssim_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P]),
     "gspl_selective_adam": (c_int, [c_int, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, _P]),
-    "gspl_radix_sort_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "gspl_radix_sort_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "gspl_radix_sort_pairs_u32": (c_int, [c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "gspl_radix_sort_keys_u64": (c_int, [c_int64, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "gspl_knn_workspace_bytes": (c_size_t, [c_int]),

@@ -18,6 +18,8 @@
 #include "gspl_device.h"
 #include "gspl_host.h"
 #include <rocprim/rocprim.hpp>
+#include "gspl_sort.h"
+#include "gspl_sort_device.h"
 
 namespace gspl {
 
@@ -225,56 +227,73 @@ static_assert(sizeof(SpanRecord) == 32, "span record is one 32-byte line");
 static constexpr int EMIT_ROWS = 16;
 static constexpr uint16_t SPAN_BIG = 0xFFFFu;
 
-template <int MODE>
+// HEADER: the kernel also prepares the depth sort (gspl_sort_device.h): digit histograms of the keys it writes, look-back
+// states cleared.
+template <int MODE, bool HEADER>
 __global__ __launch_bounds__(256) void bin_keys_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     int tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, int32_t* __restrict__ counts,
-    SpanRecord* __restrict__ spans) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    int n = 0;
-    const int radius = radii[g];
-    // the records are assembled in 32-bit words (static indices only, so that they stay in registers)
-    uint32_t w0 = 0u, wc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, wn[4] = {0u, 0u, 0u, 0u};
-    int rows = 0;
-    bool big = false;
-    if (radius > 0) {
-        int minx, miny, maxx, maxy;
-        const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
-        tile_rect<MODE>(mx, my, radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
-        SplatCull sc;
-        sc.kind = 2;
-        if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
-        rows = max(maxy - miny, 0);
-        big = rows > EMIT_ROWS;
-#pragma unroll
-        for (int r = 0; r < EMIT_ROWS; ++r) {
-            int c0 = 0, c1 = 0;
-            if (r < rows) row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
-            const int w = c1 - c0;
-            n += w;
-            big = big || w > 255;
-            wc[r >> 1] |= (uint32_t)(c0 & 0xFFFF) << (16 * (r & 1));
-            wn[r >> 2] |= (uint32_t)(w & 0xFF) << (8 * (r & 3));
-        }
-        for (int r = EMIT_ROWS; r < rows; ++r) {
-            int c0, c1;
-            row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
-            n += c1 - c0;
-        }
-        w0 = (uint32_t)(miny & 0xFFFF) | ((big ? (uint32_t)SPAN_BIG : (uint32_t)rows) << 16);
+    SpanRecord* __restrict__ spans, RadixHeader hdr) {
+    __shared__ uint32_t s_hist[HEADER ? RADIX_MAX_PASSES * RADIX_BINS : 1];
+    if (HEADER) {
+        radix_hist_clear(s_hist);
+        __syncthreads();
     }
-    counts[g] = n;
-    ids[g] = (uint32_t)g;
-    keys[g] = n > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;      // splats without tiles sort to the end
-    uint4* dst = reinterpret_cast<uint4*>(spans + g);      // layout of SpanRecord (little endian)
-    dst[0] = make_uint4(w0, wc[0], wc[1], wc[2]);
-    dst[1] = make_uint4(wc[3], wn[0], wn[1], 0u);
-    if (rows > 8 && !big) {
-        uint4* ext = reinterpret_cast<uint4*>(spans + N + g);
-        ext[0] = make_uint4(wc[4], wc[5], wc[6], wc[7]);
-        ext[1] = make_uint4(wn[2], wn[3], 0u, 0u);
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = g < N;
+    uint32_t key = 0xFFFFFFFFu;
+    if (valid) {
+        int n = 0;
+        const int radius = radii[g];
+        // the records are assembled in 32-bit words (static indices only, so that they stay in registers)
+        uint32_t w0 = 0u, wc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, wn[4] = {0u, 0u, 0u, 0u};
+        int rows = 0;
+        bool big = false;
+        if (radius > 0) {
+            int minx, miny, maxx, maxy;
+            const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+            tile_rect<MODE>(mx, my, radius, tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+            SplatCull sc;
+            sc.kind = 2;
+            if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
+            rows = max(maxy - miny, 0);
+            big = rows > EMIT_ROWS;
+#pragma unroll
+            for (int r = 0; r < EMIT_ROWS; ++r) {
+                int c0 = 0, c1 = 0;
+                if (r < rows) row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
+                const int w = c1 - c0;
+                n += w;
+                big = big || w > 255;
+                wc[r >> 1] |= (uint32_t)(c0 & 0xFFFF) << (16 * (r & 1));
+                wn[r >> 2] |= (uint32_t)(w & 0xFF) << (8 * (r & 3));
+            }
+            for (int r = EMIT_ROWS; r < rows; ++r) {
+                int c0, c1;
+                row_columns<MODE>(sc, miny + r, tile_size, minx, maxx, c0, c1);
+                n += c1 - c0;
+            }
+            w0 = (uint32_t)(miny & 0xFFFF) | ((big ? (uint32_t)SPAN_BIG : (uint32_t)rows) << 16);
+        }
+        counts[g] = n;
+        ids[g] = (uint32_t)g;
+        key = n > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;      // splats without tiles sort to the end
+        keys[g] = key;
+        uint4* dst = reinterpret_cast<uint4*>(spans + g);      // layout of SpanRecord (little endian)
+        dst[0] = make_uint4(w0, wc[0], wc[1], wc[2]);
+        dst[1] = make_uint4(wc[3], wn[0], wn[1], 0u);
+        if (rows > 8 && !big) {
+            uint4* ext = reinterpret_cast<uint4*>(spans + N + g);
+            ext[0] = make_uint4(wc[4], wc[5], wc[6], wc[7]);
+            ext[1] = make_uint4(wn[2], wn[3], 0u, 0u);
+        }
+    }
+    if (HEADER) {
+        radix_hist_add<uint32_t>(s_hist, hdr, key, valid);
+        __syncthreads();
+        radix_hist_flush(s_hist, hdr);
+        radix_states_clear(hdr, (size_t)g, (size_t)gridDim.x * blockDim.x);
     }
 }
 
@@ -465,6 +484,7 @@ struct BinWorkspace {
     size_t keys_off, ids_off, keys2_off, counts_off, scan_tmp_off, scan_tmp_bytes, sort1_tmp_off, sort1_tmp_bytes;
     size_t tkeys_off, tvals_off, tkeys2_off, sort2_tmp_off, sort2_tmp_bytes;
     size_t total_count, total;
+    bool own_depth_sort;
 };
 
 static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
@@ -482,6 +502,13 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     w.keys_off = take(4 * n); w.ids_off = take(4 * n); w.keys2_off = take(4 * n);
     w.counts_off = take(4 * n);
     w.scan_tmp_bytes = scan_tmp; w.scan_tmp_off = take(scan_tmp);
+    // depth sort: own one-sweep sort (gspl_sort.h) up to 2^30-1 splats, rocPRIM beyond
+    RadixPlan dp;
+    w.own_depth_sort = radix_plan(n, 0, 32, 8, RADIX_TILE_U32, dp);
+#ifdef GSPL_ROCPRIM_DEPTH_SORT
+    w.own_depth_sort = false;
+#endif
+    if (w.own_depth_sort && dp.total_bytes > s1) s1 = dp.total_bytes;
     w.sort1_tmp_bytes = s1; w.sort1_tmp_off = take(s1);
     w.total_count = off;
     w.tkeys_off = take(8 * ni); w.tvals_off = w.tkeys_off; w.tkeys2_off = take(8 * ni);
@@ -521,15 +548,38 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     int32_t* counts = (int32_t*)(ws + w.counts_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
-    if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans);
-    else
-        hipLaunchKernelGGL(bin_keys_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans);
-    rc = check_launch("bin_keys");
-    if (rc != GSPL_OK) return rc;
     size_t tmp = w.sort1_tmp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs<DepthSortCfg>(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
-    if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
+    hipError_t e = hipSuccess;
+    if (w.own_depth_sort) {
+        // Own one-sweep sort, prepared by the key pass itself.  Four 8-bit passes: the sorted sequence ends where it
+        // started, so the key pass writes the ids straight into `order`.
+        RadixPlan dp;
+        radix_plan((size_t)N, 0, 32, 8, RADIX_TILE_U32, dp);
+        RadixHeader hdr;
+        radix_header_args(dp, ws + w.sort1_tmp_off, hdr);
+        e = hipMemsetAsync(ws + w.sort1_tmp_off + dp.hist_off, 0, dp.header_bytes, s);
+        if (e != hipSuccess) return check_hip(e, "bin_count: histogram clear");
+        if (mode == GSPL_MODE_GSPLAT)
+            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
+        else
+            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_INRIA, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
+        rc = check_launch("bin_keys");
+        if (rc != GSPL_OK) return rc;
+        uint32_t* const kbuf[2] = {keys, keys2};
+        uint32_t* const vbuf[2] = {(uint32_t*)order, ids};
+        rc = radix_sort_u32(dp, ws + w.sort1_tmp_off, kbuf, vbuf, true, s);
+        if (rc != GSPL_OK) return rc;
+    } else {
+        RadixHeader hdr = {};
+        if (mode == GSPL_MODE_GSPLAT)
+            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, false>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans, hdr);
+        else
+            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_INRIA, false>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans, hdr);
+        rc = check_launch("bin_keys");
+        if (rc != GSPL_OK) return rc;
+        e = rocprim::radix_sort_pairs<DepthSortCfg>(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
+        if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
+    }
     tmp = w.scan_tmp_bytes;
     e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp,
                                 rocprim::make_transform_iterator((const uint32_t*)order, GatherCount{counts}), cum_tiles, (size_t)N,

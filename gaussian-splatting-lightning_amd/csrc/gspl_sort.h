@@ -7,9 +7,12 @@
 // strips the rest:
 //   * ONE header kernel per sort computes the digit histograms of every pass and clears the look-back states of every
 //     pass (or no kernel at all when the producer of the keys did both, see `RadixSort::prepared`);
-//   * one kernel per pass; tiles are handed out through an atomic ticket so a tile only ever waits for tiles that are
-//     already running, the per-tile state is one 32-bit word (2 flag bits | 30 count bits) moved with agent-scope
-//     relaxed atomics — coherent across the eight XCD L2s without cache write-backs, and self-describing, so no fences.
+//   * one kernel per pass, launched with no more workgroups than the device keeps resident; workgroup b walks tiles
+//     b, b + grid, ... in increasing order, so a tile only ever waits for tiles owned by resident workgroups that reach
+//     them without waiting for it: no dispatch-order assumption and no ticket counter (a single-address atomic hands out
+//     ~60 M tickets/s on this part: 0.1 ms for the 6750 tiles of the tile sort);
+//   * the per-tile state is one 32-bit word (2 flag bits | 30 count bits) moved with agent-scope relaxed atomics —
+//     coherent across the eight XCD L2s without cache write-backs, and self-describing, so no fences.
 // Sizes above 2^30 - 1 items do not fit the state word: callers fall back to rocPRIM there.
 #pragma once
 #include <cstddef>
@@ -19,7 +22,15 @@ namespace gspl {
 
 static constexpr int RADIX_MAX_PASSES = 4;
 static constexpr int RADIX_BINS = 256;                 // row width of the histogram / look-back tables
-static constexpr int RADIX_TILE = 2048;                // items per tile (512 threads x 4)
+#ifndef GSPL_RS_TILE_U32
+#define GSPL_RS_TILE_U32 2048
+#endif
+#ifndef GSPL_RS_TILE_U64
+#define GSPL_RS_TILE_U64 4096
+#endif
+static constexpr int RADIX_TILE_U32 = GSPL_RS_TILE_U32;   // items per tile of the (u32 key, u32 value) sort: 512 threads x 4
+static constexpr int RADIX_TILE_U64 = GSPL_RS_TILE_U64;   // items per tile of the u64 keys-only sort: 512 threads x 8
+static constexpr int RADIX_HIST_COPIES = 8;             // copies of the global histogram (gspl_sort_device.h)
 static constexpr size_t RADIX_MAX_ITEMS = (1u << 30) - 1u;
 
 struct RadixPlan {
@@ -27,18 +38,24 @@ struct RadixPlan {
     int shift[RADIX_MAX_PASSES];
     int bits[RADIX_MAX_PASSES];
     uint32_t n;
+    uint32_t tile_items;
     uint32_t ntiles;
-    // workspace layout (byte offsets): [hist: passes x 256 u32][tickets: 4 u32 + pad][states: passes x ntiles x 256 u32]
-    size_t hist_off, ticket_off, states_off, header_bytes, total_bytes;
+    uint32_t ngroups;                                  // look-back groups (complete ones)
+    // workspace layout (byte offsets): [hist: 8 copies x 4 passes x 256 u32][states: passes x (ntiles + ngroups) x 256 u32]
+    size_t hist_off, states_off, header_bytes, total_bytes;
 };
 
 // Plan a sort of key bits [begin_bit, end_bit).  digit_bits = widest digit (<= 8); passes = ceil(bits / digit_bits),
 // the bits are spread evenly over the passes.  Returns false if the request is not representable.
-bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, RadixPlan& plan);
+bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_items, RadixPlan& plan);
 
 // Sort.  keys[0]/vals[0] hold the input; buffer 1 is scratch of the same size.  The sorted sequence ends in buffer
 // (plan.passes & 1).  vals may be nullptr (keys only).  `prepared`: the caller already zeroed the header
 // (plan.header_bytes at workspace + plan.hist_off), accumulated the histograms and cleared the states.
+// What a key-producing kernel needs to prepare a sort (struct RadixHeader of gspl_sort_device.h, filled on the host).
+struct RadixHeader;
+void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr);
+
 int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 

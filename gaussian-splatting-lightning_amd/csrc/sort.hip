@@ -5,37 +5,40 @@
 // `cub::DeviceRadixSort::SortPairs(point_list_keys...)` (call sites: reference gsplat_v1_renderer.py:524-556,
 // vanilla_renderer.py:111).  Ordering contract: stable, ascending on the selected key bits — identical to those.
 //
-// Pass kernel, per tile of 2048 items (8 waves x 4 rounds x 64 lanes, in memory order):
-//   1. ticket -> tile index; digit bases of the pass (exclusive scan of its 256-bin histogram)
-//   2. load; in-wave ranks by digit matching (one ballot per digit bit), per-wave digit counters in LDS
-//   3. counters -> tile histogram -> publish LOCAL|count per digit; exclusive scan -> first in-tile slot per digit
-//   4. permute the tile through LDS into digit order
-//   5. look-back per digit over the preceding tiles' state words (LOCAL: add and go on, GLOBAL: add and stop);
+// Pass kernel: a resident grid, workgroup b owns tiles b, b + grid, ... (8 waves; a tile = 512 x IPT items, held in
+// (wave, round, lane) = memory order).  Per tile:
+//   1. load; in-wave ranks by digit matching (one ballot per digit bit), per-wave digit counters in LDS
+//   2. counters -> tile histogram -> publish LOCAL|count per digit; exclusive scan -> first in-tile slot per digit
+//   3. permute the tile through LDS into digit order
+//   4. look-back per digit over the preceding tiles' state words (LOCAL: add and go on, GLOBAL: add and stop);
 //      publish GLOBAL|inclusive
-//   6. write out: consecutive lanes hold consecutive items of a digit run -> runs of consecutive addresses
+//   5. write out: consecutive lanes hold consecutive items of a digit run -> runs of consecutive addresses
 #include "gspl_device.h"
 #include "gspl_host.h"
 #include "gspl_sort.h"
+#include "gspl_sort_device.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace gspl {
 
 static constexpr int RS_WAVES = 8;
 static constexpr int RS_THREADS = RS_WAVES * 64;
-static constexpr int RS_IPT = RADIX_TILE / RS_THREADS;
-static_assert(RS_IPT * RS_THREADS == RADIX_TILE, "tile = threads x items per thread");
 
+#ifndef GSPL_RS_WINDOW
+#define GSPL_RS_WINDOW 8
+#endif
+static constexpr int RS_WINDOW = GSPL_RS_WINDOW;         // look-back state loads kept in flight per step
+#ifndef GSPL_RS_GROUP
+#define GSPL_RS_GROUP 16
+#endif
+static constexpr uint32_t RS_GROUP = GSPL_RS_GROUP;           // tiles per look-back group
 static constexpr uint32_t RS_FLAG_LOCAL = 1u << 30;
 static constexpr uint32_t RS_FLAG_GLOBAL = 2u << 30;
 static constexpr uint32_t RS_COUNT_MASK = (1u << 30) - 1u;
 
 __device__ __forceinline__ uint32_t state_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void state_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-struct RadixPassBits {
-    int passes;
-    int shift[RADIX_MAX_PASSES];
-    uint32_t mask[RADIX_MAX_PASSES];
-};
 
 // Exclusive scan of 256 LDS words (src -> dst) by the first wave, four words per lane.
 __device__ __forceinline__ void scan256_excl(const uint32_t* src, uint32_t* dst) {
@@ -53,31 +56,54 @@ __device__ __forceinline__ void scan256_excl(const uint32_t* src, uint32_t* dst)
     }
 }
 
-// Header kernel: digit histograms of every pass (LDS bins, one global atomic per non-empty bin and workgroup) and the
-// look-back states of every pass cleared.  `hist` must be zero on entry.
+// Header kernel, for sorts whose keys were not produced by one of our kernels: gspl_sort_device.h applied to an array.
 template <typename KeyT>
-__global__ __launch_bounds__(RS_THREADS) void radix_header_kernel(const KeyT* __restrict__ keys, uint32_t n, RadixPassBits pb,
-                                                                  uint32_t* __restrict__ hist, uint4* __restrict__ states, size_t state_vec4) {
-    __shared__ uint32_t h[RADIX_MAX_PASSES][RADIX_BINS];
+__global__ __launch_bounds__(RS_THREADS) void radix_header_kernel(const KeyT* __restrict__ keys, uint32_t n, RadixHeader hdr) {
+    __shared__ uint32_t h[RADIX_MAX_PASSES * RADIX_BINS];
     const int t = threadIdx.x;
-    for (int j = t; j < RADIX_MAX_PASSES * RADIX_BINS; j += RS_THREADS) (&h[0][0])[j] = 0u;
+    radix_hist_clear(h);
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * RS_THREADS;
-    for (size_t i = (size_t)blockIdx.x * RS_THREADS + t; i < n; i += stride) {
-        const KeyT k = keys[i];
-#pragma unroll
-        for (int p = 0; p < RADIX_MAX_PASSES; ++p)
-            if (p < pb.passes) atomicAdd(&h[p][(uint32_t)(k >> pb.shift[p]) & pb.mask[p]], 1u);
+    const size_t rounds = ((size_t)n + stride - 1) / stride;
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t i = r * stride + (size_t)blockIdx.x * RS_THREADS + t;
+        const bool valid = i < n;
+        radix_hist_add<KeyT>(h, hdr, valid ? keys[i] : (KeyT)0, valid);
     }
     __syncthreads();
-    for (int j = t; j < pb.passes * RADIX_BINS; j += RS_THREADS) {
-        const uint32_t c = (&h[0][0])[j];
-        if (c) atomicAdd(hist + j, c);
-    }
-    for (size_t j = (size_t)blockIdx.x * RS_THREADS + t; j < state_vec4; j += stride) states[j] = make_uint4(0u, 0u, 0u, 0u);
+    radix_hist_flush(h, hdr);
+    radix_states_clear(hdr, (size_t)blockIdx.x * RS_THREADS + t, stride);
 }
 
-template <typename KeyT, bool VALUES>
+// Walk the state rows `p`, p-1, ..., lo of one digit column: add LOCAL counts and go on, add a GLOBAL count and finish;
+// an unpublished row is polled.  RS_WINDOW rows are fetched per step (a state load is a round trip past the XCD L2).
+// Returns the first row not consumed (lo - 1 when the range is exhausted).
+__device__ __forceinline__ int walk_states(const uint32_t* __restrict__ rows, int t, int p, int lo, uint32_t& excl, bool& finished) {
+    uint32_t spins = 0u;
+    while (!finished && p >= lo) {
+        uint32_t s[RS_WINDOW];
+#pragma unroll
+        for (int q = 0; q < RS_WINDOW; ++q) s[q] = (p - q >= lo) ? state_load(rows + (size_t)(p - q) * RADIX_BINS + t) : 0u;
+        int adv = 0;
+        bool stop = false;
+#pragma unroll
+        for (int q = 0; q < RS_WINDOW; ++q) {
+            const uint32_t flag = s[q] >> 30;
+            if (!stop) {
+                if (flag == 0u) stop = true;                      // not published yet (or past the range): re-read from here
+                else { excl += s[q] & RS_COUNT_MASK; ++adv; if (flag == 2u) { stop = true; finished = true; } }
+            }
+        }
+        p -= adv;
+        if (adv == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) __builtin_trap();          // a predecessor never published: fail loudly, do not hang
+        }
+    }
+    return p;
+}
+
+template <typename KeyT, bool VALUES, int IPT>
 struct RadixShared {
     uint32_t wcnt[RS_WAVES][RADIX_BINS];      // per-wave digit counters, then exclusive prefix over the waves
     uint32_t histo[RADIX_BINS];               // the pass's global histogram
@@ -85,125 +111,141 @@ struct RadixShared {
     uint32_t tilecnt[RADIX_BINS];             // the tile's digit histogram
     uint32_t dstart[RADIX_BINS];              // first in-tile slot of each digit
     uint32_t gbase[RADIX_BINS];               // global position of in-tile slot 0 as seen by each digit (modular)
-    KeyT xkey[RADIX_TILE];
-    uint32_t xval[VALUES ? RADIX_TILE : 1];
-    uint32_t tile;
+    KeyT xkey[RS_THREADS * IPT];
+    uint32_t xval[VALUES ? RS_THREADS * IPT : 1];
 };
 
-template <typename KeyT, bool VALUES>
+template <typename KeyT, bool VALUES, int IPT>
 __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                                int shift, int nbits, const uint32_t* __restrict__ hist,
-                                                                uint32_t* __restrict__ ticket, uint32_t* __restrict__ states) {
-    __shared__ RadixShared<KeyT, VALUES> sh;
+                                                                uint32_t ntiles, int shift, int nbits, const uint32_t* __restrict__ hist,
+                                                                uint32_t* __restrict__ states, uint32_t* __restrict__ gstates) {
+    constexpr uint32_t TILE = RS_THREADS * IPT;
+    __shared__ RadixShared<KeyT, VALUES, IPT> sh;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const uint32_t mask = (1u << nbits) - 1u;
     const int nd = 1 << nbits;
-    // ---- 1: ticket, digit bases --------------------------------------------------------------------------------
-    if (t == 0) sh.tile = atomicAdd(ticket, 1u);
-    if (t < RADIX_BINS) sh.histo[t] = (t < nd) ? hist[t] : 0u;
+    // The first tile's loads go out before anything else; the pass's histogram (sum of the copies) follows them and its
+    // exclusive scan (= the digit bases) rides on the first tile's barriers.  Later tiles are prefetched one ahead.
+    KeyT key[IPT], key_next[IPT];
+    uint32_t val[IPT], val_next[IPT], rk[IPT];
+    auto load_tile = [&](uint32_t tl, KeyT (&k)[IPT], uint32_t (&v)[IPT]) {
+        const uint32_t b0 = tl * TILE;
+        const uint32_t tn = tl < ntiles ? min(TILE, n - b0) : 0u;
 #pragma unroll
-    for (int k = l; k < RADIX_BINS; k += 64) sh.wcnt[w][k] = 0u;
-    __syncthreads();
-    const uint32_t tile = sh.tile;
-    const uint32_t base = tile * (uint32_t)RADIX_TILE;
-    const uint32_t tile_n = min((uint32_t)RADIX_TILE, n - base);
-    scan256_excl(sh.histo, sh.dbase);
-    // ---- 2: load and rank (wave w owns items [w*256, w*256+256) of the tile, 64 per round) ------------------------
-    KeyT key[RS_IPT];
-    uint32_t val[RS_IPT], rk[RS_IPT];
-#pragma unroll
-    for (int r = 0; r < RS_IPT; ++r) {
-        const uint32_t slot = (uint32_t)(w * (64 * RS_IPT) + r * 64 + l);
-        const bool valid = slot < tile_n;
-        key[r] = valid ? keys_in[base + slot] : (KeyT)0;
-        val[r] = 0u;
-        if (VALUES) val[r] = valid ? vals_in[base + slot] : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < RS_IPT; ++r) {
-        const uint32_t slot = (uint32_t)(w * (64 * RS_IPT) + r * 64 + l);
-        const bool valid = slot < tile_n;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-        unsigned long long peers = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(valid && bit);
-            peers &= bit ? bal : ~bal;
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t slot = (uint32_t)(w * (64 * IPT) + r * 64 + l);
+            const bool valid = slot < tn;
+            k[r] = valid ? keys_in[b0 + slot] : (KeyT)0;
+            v[r] = 0u;
+            if (VALUES) v[r] = valid ? vals_in[b0 + slot] : 0u;
         }
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(peers);
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
-        uint32_t old = 0u;
-        if (valid && below == 0u) { old = sh.wcnt[w][d]; sh.wcnt[w][d] = old + cnt; }
-        const int leader = valid ? (int)__builtin_ctzll(peers) : l;
-        old = __shfl(old, leader);
-        rk[r] = old + below;
+    };
+    load_tile(blockIdx.x, key, val);
+    if (t < RADIX_BINS) {
+        uint32_t c = 0u;
+        if (t < nd) {
+#pragma unroll
+            for (int k = 0; k < RADIX_HIST_COPIES; ++k) c += hist[k * (RADIX_MAX_PASSES * RADIX_BINS) + t];
+        }
+        sh.histo[t] = c;
+    }
+    bool first = true;
+
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * TILE;
+        const uint32_t tile_n = min(TILE, n - base);
+        // ---- 1: rank (wave w owns slots [w*64*IPT, (w+1)*64*IPT) of the tile, 64 per round) ------------------------------
+#pragma unroll
+        for (int k = l; k < RADIX_BINS; k += 64) sh.wcnt[w][k] = 0u;
         __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // ---- 3: tile histogram, publish LOCAL, in-tile digit starts ------------------------------------------------------
-    uint32_t my_count = 0u;
-    if (t < nd) {
-        uint32_t run = 0u;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k) { const uint32_t c = sh.wcnt[k][t]; sh.wcnt[k][t] = run; run += c; }
-        my_count = run;
-        state_store(states + (size_t)tile * RADIX_BINS + t, (tile == 0u ? RS_FLAG_GLOBAL : RS_FLAG_LOCAL) | run);
-    }
-    if (t < RADIX_BINS) sh.tilecnt[t] = my_count;
-    __syncthreads();
-    scan256_excl(sh.tilecnt, sh.dstart);
-    __syncthreads();
-    // ---- 4: permute through LDS ------------------------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < RS_IPT; ++r) {
-        const uint32_t slot = (uint32_t)(w * (64 * RS_IPT) + r * 64 + l);
-        if (slot < tile_n) {
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t slot = (uint32_t)(w * (64 * IPT) + r * 64 + l);
+            const bool valid = slot < tile_n;
             const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
-            const uint32_t pos = sh.dstart[d] + sh.wcnt[w][d] + rk[r];
-            sh.xkey[pos] = key[r];
-            if (VALUES) sh.xval[pos] = val[r];
-        }
-    }
-    // ---- 5: look-back --------------------------------------------------------------------------------------------------
-    if (t < nd) {
-        uint32_t excl = 0u;
-        if (tile > 0u) {
-            uint32_t p = tile - 1u;
-            uint32_t spins = 0u;
-            while (true) {
-                const uint32_t s = state_load(states + (size_t)p * RADIX_BINS + t);
-                const uint32_t flag = s >> 30;
-                if (flag == 0u) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) __builtin_trap();      // a predecessor never published: fail loudly, do not hang
-                    continue;
-                }
-                excl += s & RS_COUNT_MASK;
-                if (flag == 2u) break;
-                --p;                                                    // tile 0 always publishes GLOBAL: p never passes it
+            unsigned long long peers = __ballot(valid);
+            for (int b = 0; b < nbits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bal = __ballot(valid && bit);
+                peers &= bit ? bal : ~bal;
             }
-            state_store(states + (size_t)tile * RADIX_BINS + t, RS_FLAG_GLOBAL | (excl + my_count));
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(peers);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            uint32_t old = 0u;
+            if (valid && below == 0u) { old = sh.wcnt[w][d]; sh.wcnt[w][d] = old + cnt; }
+            const int leader = valid ? (int)__builtin_ctzll(peers) : l;
+            old = __shfl(old, leader);
+            rk[r] = old + below;
+            __builtin_amdgcn_wave_barrier();
         }
-        sh.gbase[t] = sh.dbase[t] + excl - sh.dstart[t];
-    }
-    __syncthreads();
-    // ---- 6: write out ------------------------------------------------------------------------------------------------
+        __syncthreads();
+        // ---- 2: tile histogram, publish LOCAL, in-tile digit starts ------------------------------------------------------
+        uint32_t my_count = 0u;
+        if (t < nd) {
+            uint32_t run = 0u;
 #pragma unroll
-    for (int r = 0; r < RS_IPT; ++r) {
-        const uint32_t i = (uint32_t)(r * RS_THREADS + t);
-        if (i < tile_n) {
-            const KeyT k = sh.xkey[i];
-            const uint32_t d = (uint32_t)(k >> shift) & mask;
-            const uint32_t gpos = sh.gbase[d] + i;
-            keys_out[gpos] = k;
-            if (VALUES) vals_out[gpos] = sh.xval[i];
+            for (int k = 0; k < RS_WAVES; ++k) { const uint32_t c = sh.wcnt[k][t]; sh.wcnt[k][t] = run; run += c; }
+            my_count = run;
+            state_store(states + (size_t)tile * RADIX_BINS + t, (tile == 0u ? RS_FLAG_GLOBAL : RS_FLAG_LOCAL) | run);
         }
+        if (t < RADIX_BINS) sh.tilecnt[t] = my_count;
+        __syncthreads();
+        scan256_excl(sh.tilecnt, sh.dstart);
+        if (first) scan256_excl(sh.histo, sh.dbase);
+        first = false;
+        __syncthreads();
+        // ---- 3: permute through LDS ------------------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t slot = (uint32_t)(w * (64 * IPT) + r * 64 + l);
+            if (slot < tile_n) {
+                const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+                const uint32_t pos = sh.dstart[d] + sh.wcnt[w][d] + rk[r];
+                sh.xkey[pos] = key[r];
+                if (VALUES) sh.xval[pos] = val[r];
+            }
+        }
+        load_tile(tile + gridDim.x, key_next, val_next);        // in flight during the look-back and the write-out
+        // ---- 4: look-back ------------------------------------------------------------------------------------------------
+        // The resident workgroups run in near lock-step, so a tile's predecessors are mostly LOCAL and a tile-by-tile walk
+        // would cover ~grid/2 of them.  The last tile of every RS_GROUP tiles (the "closer") also publishes the group's
+        // aggregate; a walk crosses its own group tile by tile and everything older group by group.
+        if (t < nd) {
+            uint32_t excl = 0u;
+            if (tile > 0u) {
+                bool finished = false;
+                int p = (int)tile - 1;
+                const bool closer = ((tile + 1u) % RS_GROUP) == 0u;
+                if (((uint32_t)(p + 1) % RS_GROUP) != 0u) p = walk_states(states, t, p, (p / RS_GROUP) * RS_GROUP, excl, finished);
+                if (closer) state_store(gstates + (size_t)(tile / RS_GROUP) * RADIX_BINS + t, (finished ? RS_FLAG_GLOBAL : RS_FLAG_LOCAL) | (excl + my_count));
+                if (!finished) walk_states(gstates, t, (p + 1) / RS_GROUP - 1, 0, excl, finished);
+                state_store(states + (size_t)tile * RADIX_BINS + t, RS_FLAG_GLOBAL | (excl + my_count));
+                if (closer) state_store(gstates + (size_t)(tile / RS_GROUP) * RADIX_BINS + t, RS_FLAG_GLOBAL | (excl + my_count));
+            }
+            sh.gbase[t] = sh.dbase[t] + excl - sh.dstart[t];
+        }
+        __syncthreads();
+        // ---- 5: write out ------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) {
+            const uint32_t i = (uint32_t)(r * RS_THREADS + t);
+            if (i < tile_n) {
+                const KeyT k = sh.xkey[i];
+                const uint32_t d = (uint32_t)(k >> shift) & mask;
+                const uint32_t gpos = sh.gbase[d] + i;
+                keys_out[gpos] = k;
+                if (VALUES) vals_out[gpos] = sh.xval[i];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < IPT; ++r) { key[r] = key_next[r]; val[r] = val_next[r]; }
+        __syncthreads();
     }
 }
 
-bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, RadixPlan& plan) {
-    if (n > RADIX_MAX_ITEMS || begin_bit < 0 || end_bit <= begin_bit || digit_bits < 1 || digit_bits > 8) return false;
+bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_items, RadixPlan& plan) {
+    if (n > RADIX_MAX_ITEMS || begin_bit < 0 || end_bit <= begin_bit || digit_bits < 1 || digit_bits > 8 || tile_items <= 0) return false;
     const int bits = end_bit - begin_bit;
     const int passes = (bits + digit_bits - 1) / digit_bits;
     if (passes > RADIX_MAX_PASSES) return false;
@@ -218,66 +260,95 @@ bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, RadixPlan&
     }
     for (int p = passes; p < RADIX_MAX_PASSES; ++p) { plan.shift[p] = 0; plan.bits[p] = 0; }
     plan.n = (uint32_t)n;
-    plan.ntiles = (uint32_t)((n + RADIX_TILE - 1) / RADIX_TILE);
+    plan.tile_items = (uint32_t)tile_items;
+    plan.ntiles = (uint32_t)((n + tile_items - 1) / tile_items);
     plan.hist_off = 0;
-    plan.ticket_off = (size_t)RADIX_MAX_PASSES * RADIX_BINS * sizeof(uint32_t);
-    plan.header_bytes = plan.ticket_off + 64;
+    plan.header_bytes = (size_t)RADIX_HIST_COPIES * RADIX_MAX_PASSES * RADIX_BINS * sizeof(uint32_t);
     plan.states_off = plan.header_bytes;
-    plan.total_bytes = plan.states_off + (size_t)passes * (plan.ntiles > 0 ? plan.ntiles : 1) * RADIX_BINS * sizeof(uint32_t);
+    plan.ngroups = plan.ntiles / RS_GROUP;                 // only complete groups are ever walked over
+    plan.total_bytes = plan.states_off + (size_t)passes * ((size_t)plan.ntiles + plan.ngroups + 1) * RADIX_BINS * sizeof(uint32_t);
     return true;
 }
 
-template <typename KeyT>
+// Grid bound of the persistent pass kernels: workgroups the device is SURE to keep resident at once.  The occupancy API
+// is exact for most shapes (tools/micro/residency_probe.hip) but a kernel sitting on a register-file boundary (64 VGPRs =
+// "8 waves per SIMD") was observed to get one wave per SIMD less than promised, and a grid that is not co-resident
+// dead-locks the look-back: one workgroup per CU is taken off the promise (never below one per CU, which always fits).
+template <typename Kernel>
+static unsigned resident_blocks(Kernel kernel) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RS_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
+    (void)hipGetLastError();
+    if (per_cu > 1) --per_cu;
+    if (const char* cap = getenv("GSPL_SORT_MAX_PER_CU")) { const int c = atoi(cap); if (c >= 1 && c < per_cu) per_cu = c; }
+    if (getenv("GSPL_SORT_DEBUG")) fprintf(stderr, "[gspl sort] resident blocks per CU %d, CUs %d\n", per_cu, cus);
+    return (unsigned)per_cu * (unsigned)cus;
+}
+
+template <typename KeyT, bool VALUES, int IPT>
+static int launch_pass(const RadixPlan& plan, int p, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout, const uint32_t* hist,
+                       uint32_t* states, uint32_t* gstates, hipStream_t s) {
+    static unsigned resident = 0;             // same value on every device of a node; a benign race at worst
+    if (resident == 0) resident = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT>);
+    const unsigned grid = plan.ntiles < resident ? plan.ntiles : resident;
+    hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT>), dim3(grid), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, plan.n, plan.ntiles,
+                       plan.shift[p], plan.bits[p], hist, states, gstates);
+    return check_launch("radix_sort(pass)");
+}
+
+void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr) {
+    char* ws = (char*)workspace;
+    hdr.hist = (uint32_t*)(ws + plan.hist_off);
+    hdr.states = (uint4*)(ws + plan.states_off);
+    hdr.state_vec4 = (uint32_t)((size_t)plan.passes * ((size_t)plan.ntiles + plan.ngroups) * RADIX_BINS / 4);
+    hdr.passes = plan.passes;
+    for (int p = 0; p < RADIX_MAX_PASSES; ++p) { hdr.shift[p] = plan.shift[p]; hdr.mask[p] = plan.bits[p] ? ((1u << plan.bits[p]) - 1u) : 0u; }
+}
+
+template <typename KeyT, int IPT>
 static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
     if (plan.n == 0) return GSPL_OK;
+    if (plan.tile_items != (uint32_t)(RS_THREADS * IPT)) return fail_arg("radix_sort: plan made for another tile size");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     uint32_t* hist = (uint32_t*)(ws + plan.hist_off);
-    uint32_t* tickets = (uint32_t*)(ws + plan.ticket_off);
     uint32_t* states = (uint32_t*)(ws + plan.states_off);
-    const size_t pass_words = (size_t)plan.ntiles * RADIX_BINS;
+    const size_t pass_words = ((size_t)plan.ntiles + plan.ngroups) * RADIX_BINS;      // tile rows, then group rows
     if (!prepared) {
         hipError_t e = hipMemsetAsync(ws + plan.hist_off, 0, plan.header_bytes, s);
         if (e != hipSuccess) return check_hip(e, "radix_sort: header clear");
-        RadixPassBits pb;
-        pb.passes = plan.passes;
-        for (int p = 0; p < RADIX_MAX_PASSES; ++p) { pb.shift[p] = plan.shift[p]; pb.mask[p] = plan.bits[p] ? ((1u << plan.bits[p]) - 1u) : 0u; }
+        RadixHeader hdr;
+        radix_header_args(plan, workspace, hdr);
         const size_t want = ((size_t)plan.n + RS_THREADS * 4 - 1) / (RS_THREADS * 4);
         const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
-        hipLaunchKernelGGL(radix_header_kernel<KeyT>, dim3(grid ? grid : 1), dim3(RS_THREADS), 0, s, (const KeyT*)keys[0], plan.n, pb, hist,
-                           (uint4*)states, (size_t)plan.passes * pass_words / 4);
+        hipLaunchKernelGGL(radix_header_kernel<KeyT>, dim3(grid ? grid : 1), dim3(RS_THREADS), 0, s, (const KeyT*)keys[0], plan.n, hdr);
         int rc = check_launch("radix_sort(header)");
         if (rc != GSPL_OK) return rc;
     }
     for (int p = 0; p < plan.passes; ++p) {
-        const KeyT* kin = keys[p & 1];
-        KeyT* kout = keys[(p + 1) & 1];
-        if (vals) {
-            hipLaunchKernelGGL((radix_pass_kernel<KeyT, true>), dim3(plan.ntiles), dim3(RS_THREADS), 0, s, kin, (const uint32_t*)vals[p & 1], kout,
-                               vals[(p + 1) & 1], plan.n, plan.shift[p], plan.bits[p], hist + p * RADIX_BINS, tickets + p, states + p * pass_words);
-        } else {
-            hipLaunchKernelGGL((radix_pass_kernel<KeyT, false>), dim3(plan.ntiles), dim3(RS_THREADS), 0, s, kin, (const uint32_t*)nullptr, kout,
-                               (uint32_t*)nullptr, plan.n, plan.shift[p], plan.bits[p], hist + p * RADIX_BINS, tickets + p, states + p * pass_words);
-        }
-        int rc = check_launch("radix_sort(pass)");
+        int rc;
+        if (vals) rc = launch_pass<KeyT, true, IPT>(plan, p, keys[p & 1], vals[p & 1], keys[(p + 1) & 1], vals[(p + 1) & 1], hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, s);
+        else rc = launch_pass<KeyT, false, IPT>(plan, p, keys[p & 1], nullptr, keys[(p + 1) & 1], nullptr, hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, s);
         if (rc != GSPL_OK) return rc;
     }
     return GSPL_OK;
 }
 
 int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
-    return radix_sort_impl<uint32_t>(plan, workspace, keys, vals, prepared, stream);
+    return radix_sort_impl<uint32_t, RADIX_TILE_U32 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream);
 }
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
-    return radix_sort_impl<uint64_t>(plan, workspace, keys, vals, prepared, stream);
+    return radix_sort_impl<uint64_t, RADIX_TILE_U64 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream);
 }
 
 }  // namespace gspl
 
 // ---- C-ABI (declared in include/gspl_hip.h) ---------------------------------------------------------------------------
-extern "C" size_t gspl_radix_sort_workspace_bytes(int64_t n, int begin_bit, int end_bit) {
+extern "C" size_t gspl_radix_sort_workspace_bytes(int64_t n, int key_bytes, int begin_bit, int end_bit) {
     gspl::RadixPlan plan;
-    if (n < 0 || !gspl::radix_plan((size_t)n, begin_bit, end_bit, 8, plan)) return 0;
+    if (n < 0 || (key_bytes != 4 && key_bytes != 8)) return 0;
+    if (!gspl::radix_plan((size_t)n, begin_bit, end_bit, 8, key_bytes == 4 ? gspl::RADIX_TILE_U32 : gspl::RADIX_TILE_U64, plan)) return 0;
     return plan.total_bytes;
 }
 
@@ -286,7 +357,10 @@ static int sort_args(int64_t n, int key_bits, int begin_bit, int end_bit, const 
     using namespace gspl;
     if (n < 0 || begin_bit < 0 || end_bit > key_bits || end_bit <= begin_bit || !result_buffer) return fail_arg(who);
     if ((size_t)n > RADIX_MAX_ITEMS) { set_error(who, "more than 2^30-1 items"); return GSPL_ERR_UNSUPPORTED; }
-    if (!radix_plan((size_t)n, begin_bit, end_bit, 8, plan)) return fail_arg(who);
+    if (!radix_plan((size_t)n, begin_bit, end_bit, 8, key_bits == 32 ? RADIX_TILE_U32 : RADIX_TILE_U64, plan)) {
+        set_error(who, "more than 32 key bits selected");
+        return GSPL_ERR_UNSUPPORTED;
+    }
     *result_buffer = plan.passes & 1;
     if (n == 0) return GSPL_OK;
     if (!k0 || !k1 || !ws) return fail_arg(who);

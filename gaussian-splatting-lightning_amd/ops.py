@@ -742,7 +742,7 @@ def _radix_sort(fn: str, keys: Tensor, vals, begin_bit: int, end_bit: int):
     v0 = v1 = None
     if vals is not None:
         v0, v1 = vals.clone(), torch.empty_like(vals)
-    ws_bytes = lib.gspl_radix_sort_workspace_bytes(n, begin_bit, end_bit)
+    ws_bytes = lib.gspl_radix_sort_workspace_bytes(n, keys.element_size(), begin_bit, end_bit)
     if ws_bytes == 0:
         raise RuntimeError("gspl_radix_sort_workspace_bytes: unsupported size or bit range")
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=keys.device)

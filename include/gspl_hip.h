@@ -368,7 +368,7 @@ int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host a
  *    Buffer 0 holds the input and is overwritten; buffer 1 is scratch of the same size; the sorted
  *    sequence ends in buffer *result_buffer (0 or 1).
  * ---------------------------------------------------------------------------------------- */
-size_t gspl_radix_sort_workspace_bytes(int64_t n, int begin_bit, int end_bit);
+size_t gspl_radix_sort_workspace_bytes(int64_t n, int key_bytes /* 4 or 8 */, int begin_bit, int end_bit);
 int gspl_radix_sort_pairs_u32(int64_t n, uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1,
                               int begin_bit, int end_bit, int* result_buffer /* host */,
                               void* workspace, size_t workspace_bytes, void* stream);

@@ -8,12 +8,15 @@ src=$root/gaussian-splatting-lightning_amd/csrc
 out=$root/gaussian-splatting-lightning_amd/variants
 mkdir -p $out/obj_$name
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
-for f in projection sh binning composite inria knn loss adam; do
+all="projection sh binning composite inria knn loss adam sort"
+# ONLY="sort binning" recompiles just those files and takes the other objects from the regular build (csrc/build)
+for f in $all; do
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $f "; then cp $src/build/$f.o $out/obj_$name/$f.o; continue; fi
   /opt/rocm/bin/hipcc $flags "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
 done
-/opt/rocm/bin/hipcc $flags "$@" -x hip -c $src/api.cpp -o $out/obj_$name/api.o &
+if [ -n "$ONLY" ]; then cp $src/build/api.o $out/obj_$name/api.o; else /opt/rocm/bin/hipcc $flags "$@" -x hip -c $src/api.cpp -o $out/obj_$name/api.o & fi
 wait
-for f in projection sh binning composite inria knn loss adam api; do test -f $out/obj_$name/$f.o || { echo "build failed: $f"; exit 1; }; done
+for f in $all api; do test -f $out/obj_$name/$f.o || { echo "build failed: $f"; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libgspl_hip_$name.so $out/obj_$name/*.o
 rm -rf $out/obj_$name
 echo $out/libgspl_hip_$name.so
