@@ -360,13 +360,14 @@ int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host a
 
 /* ------------------------------------------------------------------------------------------
  * 10. Stable LSD radix sort of the binning stage, exported for the parity tests.
- *    The sorts inside gspl_bin_count (depth keys + splat ids, u32 pairs) and gspl_bin_emit_sort
- *    ((tile | rank) records, u64 keys only) stand in for the cub::DeviceRadixSort::SortPairs calls
- *    of the reference's native rasterizers (gsplat `isect_tiles` behind gsplat_v1_renderer.py:524-556,
- *    the Inria rasterizer behind vanilla_renderer.py:111): stable, ascending on key bits
- *    [begin_bit, end_bit); at most 32 selected bits (4 passes of <= 8 bits), at most 2^30-1 items.
- *    Buffer 0 holds the input and is overwritten; buffer 1 is scratch of the same size; the sorted
- *    sequence ends in buffer *result_buffer (0 or 1).
+ *    The depth sort inside gspl_bin_count (depth keys + splat ids, u32 pairs, prepared by the key pass
+ *    itself) runs on this one-sweep sort; the u64 keys-only entry point is the same kernel at the record
+ *    width of the tile sort (which currently stays on rocPRIM: DESIGN.md §4).  Both stand in for the
+ *    cub::DeviceRadixSort::SortPairs calls of the reference's native rasterizers (gsplat `isect_tiles`
+ *    behind gsplat_v1_renderer.py:524-556, the Inria rasterizer behind vanilla_renderer.py:111): stable,
+ *    ascending on key bits [begin_bit, end_bit); at most 32 selected bits (4 passes of <= 8 bits), at most
+ *    2^30-1 items.  Buffer 0 holds the input and is overwritten; buffer 1 is scratch of the same size; the
+ *    sorted sequence ends in buffer *result_buffer (0 or 1).
  * ---------------------------------------------------------------------------------------- */
 size_t gspl_radix_sort_workspace_bytes(int64_t n, int key_bytes /* 4 or 8 */, int begin_bit, int end_bit);
 int gspl_radix_sort_pairs_u32(int64_t n, uint32_t* keys0, uint32_t* keys1, uint32_t* vals0, uint32_t* vals1,

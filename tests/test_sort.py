@@ -30,7 +30,7 @@ def _keys_u32(rng, n, kind):
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 2047, 2048, 2049, 4096, 70_001, 1_000_000])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 2047, 2048, 2049, 4096, 70_001, 1_000_000, 3_300_001])      # the last: several tiles per workgroup
 @pytest.mark.parametrize("kind", ["uniform", "few", "depths"])
 def test_pairs_u32_full_key(n, kind):
     import gspl_amd  # noqa: F401
