@@ -52,6 +52,8 @@ def parse():
     p.add_argument("--optimizer", default="none", choices=["none", "fused-adam", "selective-adam", "torch-adam"],
                    help="optionally put an optimizer step inside the timed step (single-GPU study; the multi-GPU protocol of "
                         "north_star exchanges densification statistics only, so the default step has none)")
+    p.add_argument("--stage-times", action="store_true",
+                   help="time EVERY C-ABI call with events (stages_ms); default: only the compositing kernels the roofline needs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="auto", help="workload name for the CPU baseline leg, or 'auto'")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (code-path test on one GPU)")
@@ -59,7 +61,15 @@ def parse():
     return p.parse_args()
 
 
+def _mark():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
+    """One training step (forward, loss, backward).  With state["marks"] = [] the step leaves three events per call
+    (start, before backward, after backward) for the fwd_ms / bwd_ms of the bench line."""
     import gspl_amd  # noqa: F401
     from gspl_amd import ops
     m, s, q, o, c = tensors
@@ -81,10 +91,17 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
         def step():
             for t in tensors:
                 t.grad = None
+            marks = state.get("marks")
+            if marks is not None:
+                marks.append(_mark())
             screen = torch.zeros_like(m, requires_grad=True)
             render, radii = rast(means3D=m, means2D=screen, opacities=o, shs=c, scales=s, rotations=q)
             loss = loss_fn(render)
+            if marks is not None:
+                marks.append(_mark())
             loss.backward()
+            if marks is not None:
+                marks.append(_mark())
             state["vs_grad"], state["radii"], state["loss"] = screen.grad, radii, loss
             state["grad_scale"] = None
             return state
@@ -96,6 +113,9 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
         def step():
             for t in tensors:
                 t.grad = None
+            marks = state.get("marks")
+            if marks is not None:
+                marks.append(_mark())
             xys, depths, radii, conics, comp, tiles, _ = ops.project_gaussians(
                 m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
             xys.retain_grad()
@@ -106,10 +126,15 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
             img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
                                           isects=ops.bin_gaussians_end(pending))
             loss = loss_fn(img.permute(2, 0, 1))
+            if marks is not None:
+                marks.append(_mark())
             loss.backward()
+            if marks is not None:
+                marks.append(_mark())
             state["vs_grad"], state["radii"], state["loss"] = xys.grad, radii, loss
             state["grad_scale"] = grad_scale
             return state
+    step.state = state
     return step
 
 
@@ -260,7 +285,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.profile_start()
+    step.state["marks"] = []
+    _lib.profile_start(None if args.stage_times else ("gspl_composite_bwd_packed", "gspl_composite_bwd", "gspl_composite_fwd"))
     t0 = time.perf_counter()
     for k in range(args.steps):
         st = full_step(force_reduce=(k == args.steps - 1))
@@ -269,6 +295,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop()
+    marks = step.state.pop("marks")
+    phase_fwd = sum(marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)) / args.steps
+    phase_bwd = sum(marks[i + 1].elapsed_time(marks[i + 2]) for i in range(0, len(marks), 3)) / args.steps
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -317,8 +346,9 @@ def main():
                                + ("" if args.optimizer == "none" else " + " + args.optimizer + " step"),
                        "parallelism": f"replicated Gaussians, {world} camera(s)/step, all-reduce of densification stats only"},
             "stages_ms": stages,
-            "fwd_ms": round(sum(v for k, v in stages.items() if "_bwd" not in k), 4),
-            "bwd_ms": round(sum(v for k, v in stages.items() if "_bwd" in k), 4),
+            # device time between the events at the start of the step, before loss.backward() and after it
+            "fwd_ms": round(phase_fwd, 4),
+            "bwd_ms": round(phase_bwd, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -131,11 +131,14 @@ def lib():
 # Optional per-call device timing (bench.py): a list that receives (name, start_event, end_event).
 # Events are recorded on torch's current stream, which is the stream every kernel is launched on.
 _PROFILE = None
+_PROFILE_NAMES = None
 
 
-def profile_start():
-    global _PROFILE
+def profile_start(names=None):
+    """Time C-ABI calls with events on the current stream; `names`: only these entry points (None: all)."""
+    global _PROFILE, _PROFILE_NAMES
     _PROFILE = []
+    _PROFILE_NAMES = None if names is None else frozenset(names)
 
 
 def profile_stop():
@@ -152,7 +155,7 @@ def profile_stop():
 def call(name: str, *args):
     """Invoke one C-ABI entry point and raise on a non-zero status."""
     fn = getattr(lib(), name)
-    if _PROFILE is not None:
+    if _PROFILE is not None and (_PROFILE_NAMES is None or name in _PROFILE_NAMES):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
@@ -182,5 +185,14 @@ def ptr(t, dtype=None, offset_bytes: int = 0):
     return c_void_p(t.data_ptr() + offset_bytes)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw handle of torch's current stream on the current device.  `torch.cuda.current_stream().cuda_stream` costs ~10 us
+    of Python per call (device-index plumbing, a Stream object) and every op wrapper needs it: the C accessors do the
+    same in well under a microsecond."""
+    if _raw_stream is not None and _raw_device is not None:
+        return c_void_p(_raw_stream(_raw_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
