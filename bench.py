@@ -140,16 +140,10 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
 
 def densification_stats(state, accum, denom, max_radii):
     """What VanillaDensityControllerImpl.update_states accumulates
-    (internal/density_controllers/vanilla_density_controller.py:101-123)."""
-    g = state["vs_grad"][:, :2]
-    if state["grad_scale"] is not None:
-        g = g * state["grad_scale"]
-    radii = state["radii"]
-    # a Gaussian that is not visible has an exactly zero screen-space gradient, so the masked accumulation of the reference
-    # (`accum[visible] += norm`, vanilla_density_controller.py:117-123) equals the unmasked one
-    accum.add_(torch.linalg.vector_norm(g, dim=-1))
-    denom.add_(radii > 0)
-    torch.maximum(max_radii, radii, out=max_radii)
+    (internal/density_controllers/vanilla_density_controller.py:101-123), on the fused kernel the package ships for it
+    (gspl_amd.density.HipDensityStatsMixin): masked max of the radii, masked sum of the scaled gradient norms, masked count."""
+    from gspl_amd.density import update_densification_stats
+    update_densification_stats(state["vs_grad"], None, state["radii"], accum, denom, max_radii, scale=state["grad_scale"])
 
 
 def cpu_baseline(workload_name, api):
@@ -257,7 +251,7 @@ def main():
     N = wl["n"]
     accum = torch.zeros(N, device=dev)
     denom = torch.zeros(N, device=dev)
-    max_radii = torch.zeros(N, dtype=torch.int32, device=dev)
+    max_radii = torch.zeros(N, device=dev)                       # float, as the reference's buffer (vanilla_density_controller.py:61)
 
     from gspl_amd import distributed as gdist
     DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)

@@ -376,6 +376,24 @@ int gspl_radix_sort_pairs_u32(int64_t n, uint32_t* keys0, uint32_t* keys1, uint3
 int gspl_radix_sort_keys_u64(int64_t n, uint64_t* keys0, uint64_t* keys1, int begin_bit, int end_bit,
                              int* result_buffer /* host */, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 11. Densification statistics of the density controller, one launch.
+ *    Replaces the PyTorch lines of `VanillaDensityControllerImpl.update_states` /
+ *    `_add_densification_stats` (internal/density_controllers/vanilla_density_controller.py:101-123).
+ *    For every Gaussian n with visible[n] != 0 (visible == NULL: radii[n] > 0):
+ *        max_radii[n] = max(max_radii[n], radii[n])                     (skipped when max_radii == NULL)
+ *        accum[n]    += | (grad[n,0] * scale_x, grad[n,1] * scale_y) |_2
+ *        denom[n]    += 1
+ *    grad [N, grad_stride] f32 (the first two columns are read: `viewspace_points.grad` or `.absgrad`);
+ *    scale: scale_dev (device float[2], e.g. the renderers' `viewspace_points_grad_scale`) when not NULL,
+ *    else the two host floats (1, 1 for "no scale"); radii as int32 or float32 (one of them, or neither
+ *    when a mask is given and max_radii is NULL); accum, denom, max_radii [N] f32, updated in place.
+ * ---------------------------------------------------------------------------------------- */
+int gspl_densify_stats(int N, const float* grad, int grad_stride, float scale_x, float scale_y,
+                       const float* scale_dev /*nullable*/, const uint8_t* visible /*nullable*/,
+                       const int32_t* radii_i32 /*nullable*/, const float* radii_f32 /*nullable*/,
+                       float* accum, float* denom, float* max_radii /*nullable*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
