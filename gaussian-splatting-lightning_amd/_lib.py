@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -79,7 +79,7 @@ _SIGNATURES = {
                                           _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_float, c_float, c_float,
-                                          _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                          _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _LIB = None

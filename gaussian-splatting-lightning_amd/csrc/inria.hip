@@ -134,9 +134,11 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     const int32_t* __restrict__ radii,
     const float* __restrict__ v_means2d, const float* __restrict__ v_conics, int gs2, int gs3,
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
-    float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc) {
+    float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc,
+    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
+    if (v_opac_dst) v_opac_dst[g] = v_opac_src[(int64_t)g * gs2];
     float vp[3] = {0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
     float G6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ndc[2] = {0.f, 0.f};
@@ -254,9 +256,10 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                                          const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
                                          float* v_means, float* v_scales, float* v_quats,
                                          float* v_cov3d_precomp, float* v_shs, float* v_colors_precomp,
-                                         float* v_means2d_ndc, void* stream) {
+                                         float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, void* stream) {
     using namespace gspl;
     if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
+    if (v_opacities && (!v_opacities_packed || grad_stride <= 0)) return fail_arg("inria_preprocess_bwd: v_opacities needs the packed gradient buffer");
     if (N == 0) return GSPL_OK;
     if (!means || !cov3d || !viewmatrix || !projmatrix || !radii || !v_means2d || !v_conics || !v_colors || !v_means || !v_means2d_ndc)
         return fail_arg("inria_preprocess_bwd: NULL required pointer");
@@ -286,10 +289,10 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
     if (accum)
         hipLaunchKernelGGL(inria_preprocess_bwd_kernel<true>, dim3(grid), dim3(256), 0, s,
                            N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
-                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
+                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities);
     else
         hipLaunchKernelGGL(inria_preprocess_bwd_kernel<false>, dim3(grid), dim3(256), 0, s,
                            N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
-                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc);
+                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities);
     return check_launch("inria_preprocess_bwd");
 }

@@ -92,6 +92,7 @@ class _ProjectFn(torch.autograd.Function):
             L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(tiles), L.stream())
         ctx.save_for_backward(means, scales, quats, viewmats, Ks, radii)
         ctx.cfg = (int(width), int(height), float(scale_modifier), float(eps2d), bool(calc_compensations))
+        ctx.set_materialize_grads(False)      # unused outputs (radii, tiles, often depths) arrive as None, not as zero tensors
         ctx.mark_non_differentiable(radii)
         outs = [radii, means2d, depths, conics]
         outs.append(comps if comps is not None else torch.empty(0, device=dev))
@@ -667,6 +668,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                               radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids)
         ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
                    float(s.scale_modifier), colors_precomp is not None, opacities.shape)
+        ctx.set_materialize_grads(False)      # the integer `radii` output would otherwise get a zero "gradient" tensor per step
         ctx.mark_non_differentiable(radii)
         ctx.means2D_ref = means2D       # the caller's screen-space tensor: `.has_hit_any_pixels` is attached to it in backward
         return out, radii
@@ -691,7 +693,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                 L.ptr(v_out), None, L.ptr(packed), RS, 0, L.ptr(hit), L.stream())
             if hit is not None and ctx.means2D_ref is not None:
                 ctx.means2D_ref.has_hit_any_pixels = hit.bool()
-        v_opac = packed[:, 5]
+        v_opac = torch.empty((N,), dtype=torch.float32, device=dev)      # dense copy of the packed column (written below)
         v_means = torch.empty((N, 3), dtype=torch.float32, device=dev)
         v_ndc = torch.empty((N, 3), dtype=torch.float32, device=dev)
         use_cov = cov3D_precomp is not None
@@ -706,7 +708,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                 L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tanfovx, tanfovy, scale_modifier,
                 L.ptr(radii), L.ptr(clamped), L.ptr(packed), L.ptr(packed, offset_bytes=8), L.ptr(packed, offset_bytes=24), RS,
                 L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_cp), L.ptr(v_ndc),
-                L.stream())
+                L.ptr(packed, offset_bytes=20), L.ptr(v_opac), L.stream())
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings
         return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
 

@@ -292,6 +292,9 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               float* v_means, float* v_scales /*nullable*/, float* v_quats /*nullable*/,
                               float* v_cov3d_precomp /*nullable*/, float* v_shs /*nullable*/,
                               float* v_colors_precomp /*nullable*/, float* v_means2d_ndc,
+                              const float* v_opacities_packed /*nullable: the opacity column of the packed buffer */,
+                              float* v_opacities /*nullable: [N], receives that column densely (the optimizer's
+                                                   gradient is then a contiguous tensor, not a strided view) */,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
