@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, int tile_size, int tile_w, int tile_h,
-    uint64_t* __restrict__ tile_keys) {
+    uint64_t* __restrict__ tile_keys, int64_t capacity) {
     __shared__ int s_start[4][65];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_row0[4][64];
@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
         for (int step = EMIT_ROWS / 2; step > 0; step >>= 1) r += (kk >= (int)s_pre[w][o][r + step]) ? step : 0;
         const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
         const int ty = s_row0[w][o] + r;
-        tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
+        if (wave_base + k < capacity)      // a speculative launch may have guessed the list length too low (the host redoes it)
+            tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
     }
     (void)any_mask;
     // ---- phase B: splats spanning many tile rows, one at a time, lanes over rows ---------------------------
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
             const int n = c1 - c0;
             const int pre = wave_excl_scan(n, l);
             for (int tx = c0; tx < c1; ++tx)
-                tile_keys[out + pre + (tx - c0)] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | og;
+                if (out + pre + (tx - c0) < capacity)
+                    tile_keys[out + pre + (tx - c0)] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | og;
             out += __shfl(pre + n, 63);
         }
     }
@@ -587,45 +589,75 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     return check_hip(e, "bin_count: inclusive_scan");
 }
 
+// Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has
+// room for: it may be a GUESS of the list length, launched before the host knows the real one — records past it are
+// dropped, and the caller repeats the call with the real length when the guess was too low.
+extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
+                             const float* conics, const float* opacities,
+                             const int32_t* order, const int64_t* cum_tiles, const void* spans,
+                             int tile_size, int tile_w, int tile_h, int64_t capacity,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gspl;
+    if (N < 0 || capacity < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_emit: bad sizes");
+    if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_emit: bad mode");
+    if (N == 0 || capacity == 0) return GSPL_OK;
+    if (capacity > 0x7fffffffll) return fail_arg("bin_emit: more than 2^31-1 intersections");
+    if (!means2d || !radii || !order || !cum_tiles || !spans || !workspace) return fail_arg("bin_emit: NULL required pointer");
+    BinWorkspace w;
+    int rc = plan_bin(N, capacity, w);
+    if (rc != GSPL_OK) return rc;
+    if (workspace_bytes < w.total) return fail_ws("bin_emit");
+    uint64_t* tkeys = (uint64_t*)((char*)workspace + w.tkeys_off);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (N + 255) / 256;
+    if (mode == GSPL_MODE_GSPLAT)
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys, capacity);
+    else
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys, capacity);
+    return check_launch("bin_emit");
+}
+
+// Sort half: the first n_isects (<= capacity) records of the workspace gspl_bin_emit filled -> flatten_ids, offsets.
+extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
+                             int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gspl;
+    if (N < 0 || n_isects < 0 || capacity < n_isects || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_sort: bad sizes");
+    if (!offsets) return fail_arg("bin_sort: NULL offsets");
+    const int n_tiles = tile_w * tile_h;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0 || n_isects == 0) {
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, n_tiles, 0, offsets);
+        return check_launch("bin_sort(fill)");
+    }
+    if (capacity > 0x7fffffffll) return fail_arg("bin_sort: more than 2^31-1 intersections");
+    if (!flatten_ids || !workspace) return fail_arg("bin_sort: NULL required pointer");
+    BinWorkspace w;
+    int rc = plan_bin(N, capacity, w);
+    if (rc != GSPL_OK) return rc;
+    if (workspace_bytes < w.total) return fail_ws("bin_sort");
+    char* ws = (char*)workspace;
+    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
+    uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
+    size_t tmp = w.sort2_tmp_bytes;
+    const int bits = key_bits(n_tiles) - 32;
+    hipError_t e = rocprim::radix_sort_keys<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, (size_t)n_isects, 32,
+                                            32 + (bits > 0 ? bits : 1), s);
+    if (e != hipSuccess) return check_hip(e, "bin_sort: tile sort");
+    const int64_t g2 = (n_isects + 255) / 256;
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint64_t*)tkeys2, n_tiles, offsets, flatten_ids);
+    return check_launch("bin_offsets");
+}
+
 extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const int32_t* radii,
                                   const float* conics, const float* opacities,
                                   const int32_t* order, const int64_t* cum_tiles, const void* spans,
                                   int tile_size, int tile_w, int tile_h, int64_t n_isects,
                                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
-    using namespace gspl;
-    if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_emit_sort: bad sizes");
-    if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_emit_sort: bad mode");
-    if (!offsets) return fail_arg("bin_emit_sort: NULL offsets");
-    const int n_tiles = tile_w * tile_h;
-    hipStream_t s = (hipStream_t)stream;
-    if (N == 0 || n_isects == 0) {
-        hipLaunchKernelGGL(fill_i32_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, s, n_tiles, 0, offsets);
-        return check_launch("bin_emit_sort(fill)");
-    }
-    if (n_isects > 0x7fffffffll) return fail_arg("bin_emit_sort: more than 2^31-1 intersections");
-    if (!means2d || !radii || !order || !cum_tiles || !spans || !flatten_ids || !workspace) return fail_arg("bin_emit_sort: NULL required pointer");
-    BinWorkspace w;
-    int rc = plan_bin(N, n_isects, w);
+    if (n_isects < 0) return gspl::fail_arg("bin_emit_sort: bad sizes");
+    int rc = gspl_bin_emit(N, mode, means2d, radii, conics, opacities, order, cum_tiles, spans, tile_size, tile_w, tile_h, n_isects,
+                           workspace, workspace_bytes, stream);
     if (rc != GSPL_OK) return rc;
-    if (workspace_bytes < w.total) return fail_ws("bin_emit_sort");
-    char* ws = (char*)workspace;
-    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
-    uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
-    const int grid = (N + 255) / 256;
-    if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys);
-    else
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys);
-    rc = check_launch("bin_emit");
-    if (rc != GSPL_OK) return rc;
-    size_t tmp = w.sort2_tmp_bytes;
-    const int bits = key_bits(n_tiles) - 32;
-    hipError_t e = rocprim::radix_sort_keys<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, (size_t)n_isects, 32,
-                                            32 + (bits > 0 ? bits : 1), s);
-    if (e != hipSuccess) return check_hip(e, "bin_emit_sort: tile sort");
-    const int64_t g2 = (n_isects + 255) / 256;
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint64_t*)tkeys2, n_tiles, offsets, flatten_ids);
-    return check_launch("bin_offsets");
+    return gspl_bin_sort(N, tile_w, tile_h, n_isects, n_isects, flatten_ids, offsets, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t gspl_isect_workspace_bytes(int N, int64_t n_isects) {

@@ -15,6 +15,7 @@ All arithmetic happens in libgspl_hip.so; nothing here falls back to PyTorch mat
 """
 from __future__ import annotations
 
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -507,10 +508,12 @@ class _PendingBins:
     """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
     __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "spans", "offsets", "tile_w", "tile_h",
-                 "block_width", "host_count", "event", "dev")
+                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes")
 
 
 _PINNED_WORDS: list = []      # free list of pinned int64 words for the count read-back
+_LAST_ISECTS: dict = {}       # (device, tile grid) -> list length of the last frame: the guess of the speculative emission
+SPECULATIVE_EMIT = os.environ.get("GSPL_SPECULATIVE_EMIT", "1") != "0"
 
 
 def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, img_width: int, block_width: int = 16,
@@ -534,7 +537,8 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     if conics is not None and opacities is not None:
         p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
     p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
-    p.order = p.cum = p.spans = p.host_count = p.event = None
+    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = None
+    p.capacity = p.ws2_bytes = 0
     if N > 0:
         p.order = torch.empty((N,), dtype=torch.int32, device=dev)
         p.cum = torch.empty((N,), dtype=torch.int64, device=dev)
@@ -550,11 +554,27 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
         p.host_count.copy_(p.cum[-1:], non_blocking=True)
         p.event = torch.cuda.Event()
         p.event.record()
+        # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of
+        # the list length (the last frame's, plus a margin) and runs while the host waits for the real number; a guess
+        # that turns out too low costs one repeated emission in `bin_gaussians_end`.
+        guess = _LAST_ISECTS.get((dev.index, p.tile_w, p.tile_h), 0)
+        if SPECULATIVE_EMIT and guess > 0:
+            p.capacity = int(guess * 1.25) + 65536
+            p.ws2_bytes = lib.gspl_bin_workspace_bytes(N, p.capacity)
+            if p.ws2_bytes == 0:
+                raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
+            p.ws2 = torch.empty((p.ws2_bytes,), dtype=torch.uint8, device=dev)
+            _emit(p)
     return p
 
 
+def _emit(p: "_PendingBins"):
+    L.call("gspl_bin_emit", p.N, p.mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(p.cull_c), L.ptr(p.cull_o), L.ptr(p.order), L.ptr(p.cum),
+           L.ptr(p.spans), p.block_width, p.tile_w, p.tile_h, p.capacity, L.ptr(p.ws2), p.ws2_bytes, L.stream())
+
+
 def bin_gaussians_end(p: _PendingBins):
-    """Second half: waits for the count, then emits and sorts the (tile, Gaussian) lists.
+    """Second half: waits for the count, then (emits and) sorts the (tile, Gaussian) lists.
     Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
     lib = L.lib()
     n_isects = 0
@@ -562,13 +582,17 @@ def bin_gaussians_end(p: _PendingBins):
         p.event.synchronize()
         n_isects = int(p.host_count[0])
         _PINNED_WORDS.append(p.host_count)
+        _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
     N, dev = p.N, p.dev
     flat = torch.empty((n_isects,), dtype=torch.int32, device=dev)
-    ws_bytes = lib.gspl_bin_workspace_bytes(max(N, 1), n_isects) if n_isects > 0 else 0
-    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
-    L.call("gspl_bin_emit_sort", N, p.mode, L.ptr(p.means2d) if N else None, L.ptr(p.radii) if N else None,
-           L.ptr(p.cull_c), L.ptr(p.cull_o), L.ptr(p.order), L.ptr(p.cum), L.ptr(p.spans), p.block_width, p.tile_w, p.tile_h, n_isects,
-           L.ptr(flat) if n_isects else None, L.ptr(p.offsets), L.ptr(ws), ws_bytes, L.stream())
+    if n_isects > 0 and (p.ws2 is None or p.capacity < n_isects):
+        p.capacity = n_isects
+        p.ws2_bytes = lib.gspl_bin_workspace_bytes(N, n_isects)
+        p.ws2 = torch.empty((p.ws2_bytes,), dtype=torch.uint8, device=dev)
+        _emit(p)
+    L.call("gspl_bin_sort", N, p.tile_w, p.tile_h, n_isects, max(p.capacity, n_isects), L.ptr(flat) if n_isects else None, L.ptr(p.offsets),
+           L.ptr(p.ws2) if n_isects else None, p.ws2_bytes if n_isects else 0, L.stream())
+    p.ws2 = None
     return flat, p.offsets
 
 

@@ -188,6 +188,17 @@ int gspl_bin_emit_sort(int N, int mode,
                        int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int32_t* flatten_ids, int32_t* offsets,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The two halves of gspl_bin_emit_sort, so that the emission can be launched SPECULATIVELY while the host still waits
+ * for the list length: `capacity` (>= the length, if the guess is good) sizes the workspace
+ * (gspl_bin_workspace_bytes(N, capacity)); records past it are dropped.  gspl_bin_sort then takes the real
+ * n_isects <= capacity; when the guess was too low the caller repeats gspl_bin_emit with capacity = n_isects. */
+int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
+                  const float* conics /*nullable*/, const float* opacities /*nullable*/,
+                  const int32_t* order, const int64_t* cum_tiles, const void* spans,
+                  int tile_size, int tile_w, int tile_h, int64_t capacity,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
+                  int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Tile compositing, forward.

@@ -220,6 +220,23 @@ def test_binning_two_level_ties_and_empty(hip):
     assert flat.numel() == 0 and offs.numel() == ((W + 15) // 16) * ((H + 15) // 16) and int(offs.abs().sum()) == 0
 
 
+def test_speculative_emission_recovers_from_a_low_guess(hip):
+    """`bin_gaussians` launches the emit kernel with room for the LAST frame's list length before it knows this frame's
+    (ops.bin_gaussians_begin).  A frame with far more intersections than the last one must still give the exact lists
+    (the emission is repeated), and so must a frame with far fewer."""
+    d = _dev()
+    W, H = 320, 240
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    res_small, _, _, _ = _projected_scene(300, W, H, 300.0, seed=11, scale_mul=1.0)
+    res_big, _, _, _ = _projected_scene(6000, W, H, 300.0, seed=12, scale_mul=6.0)
+    for res in (res_small, res_big, res_small, res_big):
+        xys, depths, radii = res[0], res[1], res[2]
+        _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, xys, radii, depths, W, H)
+        flat, offs = hip.bin_gaussians(xys.to(d), depths.to(d), radii.to(d), H, W, 16)
+        assert np.array_equal(flat.cpu().numpy(), flat_ref) and np.array_equal(offs.cpu().numpy(), offs_ref)
+    assert hip._LAST_ISECTS[(torch.device(d).index, tw, th)] == flat_ref.shape[0]
+
+
 @pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
 def test_tile_culling_is_lossless(hip, mode):
     """Exact ellipse-vs-tile culling in the list-only binning path: shorter lists, every tile's list an
