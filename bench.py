@@ -94,7 +94,7 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
             marks = state.get("marks")
             if marks is not None:
                 marks.append(_mark())
-            screen = torch.zeros_like(m, requires_grad=True)
+            screen = torch.empty_like(m).requires_grad_(True)      # gradient carrier, as HipVanillaRenderer creates it (values unused)
             render, radii = rast(means3D=m, means2D=screen, opacities=o, shs=c, scales=s, rotations=q)
             loss = loss_fn(render)
             if marks is not None:

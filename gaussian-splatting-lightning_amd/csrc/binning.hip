@@ -485,7 +485,7 @@ using TileSortCfg = rocprim::radix_sort_config<
 struct BinWorkspace {
     size_t keys_off, ids_off, keys2_off, counts_off, scan_tmp_off, scan_tmp_bytes, sort1_tmp_off, sort1_tmp_bytes;
     size_t tkeys_off, tvals_off, tkeys2_off, sort2_tmp_off, sort2_tmp_bytes;
-    size_t total_count, total;
+    size_t total_count, total, scan_states_off;
     bool own_depth_sort;
 };
 
@@ -510,7 +510,13 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
 #ifdef GSPL_ROCPRIM_DEPTH_SORT
     w.own_depth_sort = false;
 #endif
-    if (w.own_depth_sort && dp.total_bytes > s1) s1 = dp.total_bytes;
+    // ... followed by the state words of the one-launch scan of the counts (cleared by the key pass with the sort's rows)
+    w.scan_states_off = 0;
+    if (w.own_depth_sort) {
+        w.scan_states_off = dp.total_bytes;
+        const size_t need = dp.total_bytes + scan_state_bytes(n);
+        if (need > s1) s1 = need;
+    }
     w.sort1_tmp_bytes = s1; w.sort1_tmp_off = take(s1);
     w.total_count = off;
     w.tkeys_off = take(8 * ni); w.tvals_off = w.tkeys_off; w.tkeys2_off = take(8 * ni);
@@ -559,6 +565,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
         radix_plan((size_t)N, 0, 32, 8, RADIX_TILE_U32, dp);
         RadixHeader hdr;
         radix_header_args(dp, ws + w.sort1_tmp_off, hdr);
+        hdr.state_vec4 = (uint32_t)((dp.total_bytes - dp.states_off + scan_state_bytes((size_t)N)) / 16);      // + the scan's words
         e = hipMemsetAsync(ws + w.sort1_tmp_off + dp.hist_off, 0, dp.header_bytes, s);
         if (e != hipSuccess) return check_hip(e, "bin_count: histogram clear");
         if (mode == GSPL_MODE_GSPLAT)
@@ -582,6 +589,8 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
         e = rocprim::radix_sort_pairs<DepthSortCfg>(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
         if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
     }
+    if (w.own_depth_sort)
+        return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_tmp_off + w.scan_states_off, s);
     tmp = w.scan_tmp_bytes;
     e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp,
                                 rocprim::make_transform_iterator((const uint32_t*)order, GatherCount{counts}), cum_tiles, (size_t)N,

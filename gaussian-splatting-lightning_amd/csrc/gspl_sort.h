@@ -61,4 +61,11 @@ void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr)
 int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 
+// Inclusive scan of counts[order[i]] (int32 -> int64) in ONE launch: the same chained look-back as the sort passes (one
+// 64-bit state word per tile of SCAN_TILE items; a wave inspects 64 predecessors per step).  `states`: scan_state_bytes(n)
+// bytes, zero on entry (16-byte aligned; the key pass clears them together with the sort's rows).
+static constexpr int SCAN_TILE = 2048;
+size_t scan_state_bytes(size_t n);
+int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, void* stream);
+
 }  // namespace gspl

@@ -342,6 +342,95 @@ int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[
     return radix_sort_impl<uint64_t, RADIX_TILE_U64 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream);
 }
 
+
+// ---- scan of the tile counts in depth order -------------------------------------------------------------------------------
+static constexpr unsigned long long SC_FLAG_LOCAL = 1ull << 62;
+static constexpr unsigned long long SC_FLAG_GLOBAL = 2ull << 62;
+static constexpr unsigned long long SC_VALUE_MASK = (1ull << 62) - 1ull;
+static constexpr int SC_IPT = SCAN_TILE / RS_THREADS;
+
+__global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
+                                                                 int64_t* __restrict__ cum, uint32_t n, uint32_t ntiles,
+                                                                 unsigned long long* __restrict__ states) {
+    __shared__ unsigned long long s_wave[RS_WAVES];
+    __shared__ unsigned long long s_excl;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t first = tile * (uint32_t)SCAN_TILE + (uint32_t)t * SC_IPT;       // SC_IPT consecutive items per thread
+        unsigned long long v[SC_IPT], mine = 0ull;
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) {
+            const uint32_t i = first + k;
+            v[k] = i < n ? (unsigned long long)(uint32_t)counts[order[i]] : 0ull;
+            mine += v[k];
+        }
+        unsigned long long incl = mine;                                                   // scan of the thread totals in the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long up = __shfl_up(incl, d);
+            if (l >= d) incl += up;
+        }
+        if (l == 63) s_wave[w] = incl;
+        __syncthreads();
+        unsigned long long wave_off = 0ull, total = 0ull;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) { const unsigned long long c = s_wave[k]; if (k < w) wave_off += c; total += c; }
+        if (w == 0) {
+            // publish the tile's aggregate, then look back: lane j inspects tile p - j
+            if (l == 0) __hip_atomic_store(states + tile, (tile == 0u ? SC_FLAG_GLOBAL : SC_FLAG_LOCAL) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long excl = 0ull;
+            if (tile > 0u) {
+                int p = (int)tile - 1;
+                uint32_t spins = 0u;
+                while (true) {
+                    const int idx = p - l;
+                    const unsigned long long sv = idx >= 0 ? __hip_atomic_load(states + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_FLAG_GLOBAL;
+                    const unsigned flag = (unsigned)(sv >> 62);
+                    const unsigned long long glob = __ballot(flag == 2u), empty = __ballot(flag == 0u);
+                    const int fg = glob ? (int)__builtin_ctzll(glob) : 64, fe = empty ? (int)__builtin_ctzll(empty) : 64;
+                    const int take = fe < fg ? fe : (fg < 64 ? fg + 1 : 64);              // lanes [0, take) are consumed
+                    unsigned long long part = l < take ? (sv & SC_VALUE_MASK) : 0ull;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+                    excl += part;
+                    if (fg < fe) break;
+                    p -= take;
+                    if (take == 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 24)) __builtin_trap();                       // a predecessor never published: fail loudly
+                    }
+                }
+                if (l == 0) __hip_atomic_store(states + tile, SC_FLAG_GLOBAL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (l == 0) s_excl = excl;
+        }
+        __syncthreads();
+        unsigned long long run = s_excl + wave_off + (incl - mine);
+#pragma unroll
+        for (int k = 0; k < SC_IPT; ++k) {
+            run += v[k];
+            const uint32_t i = first + k;
+            if (i < n) cum[i] = (int64_t)run;
+        }
+        __syncthreads();
+    }
+}
+
+size_t scan_state_bytes(size_t n) {
+    const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    return ((tiles ? tiles : 1) * sizeof(unsigned long long) + 15) / 16 * 16;
+}
+
+int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, void* stream) {
+    if (n == 0) return GSPL_OK;
+    static unsigned safe = 0;
+    if (safe == 0) safe = resident_blocks(scan_gather_kernel);
+    const unsigned ntiles = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(scan_gather_kernel, dim3(ntiles < safe ? ntiles : safe), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum, (uint32_t)n,
+                       ntiles, (unsigned long long*)states);
+    return check_launch("scan_gathered_counts");
+}
+
 }  // namespace gspl
 
 // ---- C-ABI (declared in include/gspl_hip.h) ---------------------------------------------------------------------------

@@ -52,7 +52,10 @@ class HipVanillaRenderer(Renderer):
             override_color = depth.repeat(1, 3)
 
         means3D = pc.get_xyz
-        screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=bg_color.device) + 0
+        # The screen-space tensor only CARRIES the 2D-mean gradient back to the density controller; its values are never read
+        # (reference: `zeros_like(...) + 0`, vanilla_renderer.py:55-56 — a fill and an add per frame).  A leaf accepts
+        # `retain_grad()` and receives `.grad` just the same.
+        screenspace_points = torch.empty_like(means3D, dtype=means3D.dtype, device=bg_color.device).requires_grad_(True)
         settings = self._settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree)
         rasterizer = ops.GaussianRasterizer(raster_settings=settings)
 
@@ -91,7 +94,7 @@ class HipVanillaRenderer(Renderer):
             assert features is None
         if cov3D_precomp is not None:
             assert scales is None and rotations is None
-        screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=means3D.device)
+        screenspace_points = torch.empty_like(means3D, dtype=means3D.dtype, device=means3D.device).requires_grad_(True)
         settings = HipVanillaRenderer._settings(viewpoint_camera, bg_color, scaling_modifier, active_sh_degree)
         rendered_image, radii = ops.GaussianRasterizer(raster_settings=settings)(
             means3D=means3D, means2D=screenspace_points, shs=features, colors_precomp=colors_precomp,
