@@ -949,6 +949,89 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
     return check_launch("composite_bwd");
 }
 
+// ---- per-splat statistics of a compositing pass (no image) -----------------------------------------------------------------------
+// What LightGaussian-style pruning and Taming-3DGS-style densification scores read from a rasterization (reference call sites:
+// internal/renderers/gsplat_hit_pixel_count_renderer.py:34-44 -> gsplat fork `hit_pixel_count`;
+// internal/density_controllers/taming_3dgs_density_controller.py:429-439 -> gsplat fork `rasterize_to_weights`; both kernels are
+// un-vendored, the sums are restated from the published methods).  Same traversal and the same discrete rules as
+// composite_fwd_kernel (alpha >= 1/255, stop when the transmittance would fall below 1e-4); for every splat g, summed over the
+// pixels p it contributes to:  count += 1, opacity += opacity[g], alpha += alpha, visibility += alpha T,
+// weighted += w[p] alpha T, dist += |p - mean[g]|.  One wave per 8x8 quadrant, one candidate at a time, wave reduction, one
+// atomic per (quadrant, splat, quantity).  A statistics pass, run once per pruning / scoring event: not tuned.
+template <int MODE>
+__global__ __launch_bounds__(64) void composite_scores_kernel(
+    int n_tiles, int tile_w, int width, int height, int64_t n_isects,
+    const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ opacities,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids, const float* __restrict__ pixel_weights,
+    int32_t* __restrict__ count, float* __restrict__ opacity_sum, float* __restrict__ alpha_sum, float* __restrict__ vis_sum,
+    float* __restrict__ weighted_sum, float* __restrict__ dist_sum) {
+    using TR = ModeTraits<MODE>;
+    __shared__ float s_x[64], s_y[64], s_ha[64], s_b[64], s_hc[64], s_op[64];
+    __shared__ int s_g[64];
+    const int unit = blockIdx.x;
+    const int tile = unit >> 2, w = unit & 3, l = threadIdx.x;
+    const int px = (tile % tile_w) * TILE + (w & 1) * 8 + (l & 7);
+    const int py = (tile / tile_w) * TILE + (w >> 1) * 8 + (l >> 3);
+    const bool inside = (px < width) && (py < height);
+    const float pxf = (float)px + TR::kPixelCentre, pyf = (float)py + TR::kPixelCentre;
+    const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
+    const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
+    const float wpx = (pixel_weights && inside) ? pixel_weights[(int64_t)py * width + px] : 0.f;
+    int start, end;
+    tile_range(tile, n_tiles, n_isects, offsets, start, end);
+    float T = 1.f;
+    bool done = !inside;
+    for (int base = start; base < end && !__all(done); base += 64) {
+        const int i = base + l;
+        bool cand = false;
+        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
+        int g = 0;
+        if (i < end) {
+            g = flatten_ids[i];
+            ca = conics[g * 3 + 0]; cb = conics[g * 3 + 1]; cc = conics[g * 3 + 2]; op = opacities[g];
+            mx = means2d[g * 2 + 0]; my = means2d[g * 2 + 1];
+            cand = box_reachable(mx, my, ca, cb, cc, op, qx0, qx1, qy0, qy1);
+        }
+        const unsigned long long mask = __ballot(cand);
+        const int ncand = __builtin_popcountll(mask);
+        const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        __builtin_amdgcn_wave_barrier();
+        if (cand) { s_x[slot] = mx; s_y[slot] = my; s_ha[slot] = 0.5f * ca; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op; s_g[slot] = g; }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < ncand; ++k) {
+            const float dx = s_x[k] - pxf, dy = s_y[k] - pyf, o = s_op[k];
+            const float sigma = s_ha[k] * dx * dx + s_hc[k] * dy * dy + s_b[k] * dx * dy;
+            const float alpha = fminf(TR::kAlphaMax, o * __expf(-sigma));
+            const bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
+            const float next_T = T * (1.f - alpha);
+            const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));
+            const bool contrib = valid && !stop;
+            const unsigned long long hit = __ballot(contrib);
+            if (hit) {
+                float a = contrib ? alpha : 0.f, v = contrib ? alpha * T : 0.f;
+                float wv = v * wpx, ds = contrib ? sqrtf(dx * dx + dy * dy) : 0.f;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    a += __shfl_xor(a, d); v += __shfl_xor(v, d); wv += __shfl_xor(wv, d); ds += __shfl_xor(ds, d);
+                }
+                if (l == 0) {
+                    const int gk = s_g[k];
+                    const int c = __builtin_popcountll(hit);
+                    if (count) atomicAdd(count + gk, c);
+                    if (opacity_sum) atomicAdd(opacity_sum + gk, (float)c * o);
+                    if (alpha_sum) atomicAdd(alpha_sum + gk, a);
+                    if (vis_sum) atomicAdd(vis_sum + gk, v);
+                    if (weighted_sum) atomicAdd(weighted_sum + gk, wv);
+                    if (dist_sum) atomicAdd(dist_sum + gk, ds);
+                }
+            }
+            T = contrib ? next_T : T;
+            done = done || stop;
+            if (__all(done)) break;
+        }
+    }
+}
+
 static int check_common(int N, int64_t n_isects, int D, int mode, int layout, int width, int height,
                         int tile_size, int tile_w, int tile_h, const char* who) {
     if (N < 0 || n_isects < 0 || width <= 0 || height <= 0) return fail_arg(who);
@@ -1078,3 +1161,26 @@ extern "C" int gspl_debug_pair_stats(unsigned long long* out4, int reset) {
     return 0;
 }
 #endif
+
+extern "C" int gspl_composite_scores(int N, int64_t n_isects, int mode,
+                                     const float* means2d, const float* conics, const float* opacities,
+                                     int width, int height, int tile_size, int tile_w, int tile_h,
+                                     const int32_t* offsets, const int32_t* flatten_ids, const float* pixel_weights,
+                                     int32_t* count, float* opacity_sum, float* alpha_sum, float* visibility_sum,
+                                     float* weighted_sum, float* dist_sum, void* stream) {
+    using namespace gspl;
+    int rc = check_common(N, n_isects, 1, mode, GSPL_LAYOUT_HWC, width, height, tile_size, tile_w, tile_h, "composite_scores: bad argument");
+    if (rc != GSPL_OK) return rc;
+    if (N == 0 || n_isects == 0) return GSPL_OK;
+    if (!means2d || !conics || !opacities || !offsets || !flatten_ids) return fail_arg("composite_scores: NULL required pointer");
+    if (weighted_sum && !pixel_weights) return fail_arg("composite_scores: weighted_sum needs pixel_weights");
+    const int n_tiles = tile_w * tile_h;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == GSPL_MODE_GSPLAT)
+        hipLaunchKernelGGL(composite_scores_kernel<GSPL_MODE_GSPLAT>, dim3(4 * n_tiles), dim3(64), 0, s, n_tiles, tile_w, width, height, n_isects, means2d, conics,
+                           opacities, offsets, flatten_ids, pixel_weights, count, opacity_sum, alpha_sum, visibility_sum, weighted_sum, dist_sum);
+    else
+        hipLaunchKernelGGL(composite_scores_kernel<GSPL_MODE_INRIA>, dim3(4 * n_tiles), dim3(64), 0, s, n_tiles, tile_w, width, height, n_isects, means2d, conics,
+                           opacities, offsets, flatten_ids, pixel_weights, count, opacity_sum, alpha_sum, visibility_sum, weighted_sum, dist_sum);
+    return check_launch("composite_scores");
+}

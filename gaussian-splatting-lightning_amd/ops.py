@@ -469,6 +469,60 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     return out[None], alphas[None, ..., None]
 
 
+@torch.no_grad()
+def composite_scores(means2d: Tensor, conics: Tensor, opacities: Tensor, image_width: int, image_height: int, tile_size: int,
+                     isect_offsets: Tensor, flatten_ids: Tensor, pixel_weights: Optional[Tensor] = None,
+                     mode: int = L.GSPL_MODE_GSPLAT, with_dist: bool = False):
+    """Per-splat sums over the pixels each splat contributes to (`gspl_composite_scores`): returns
+    (count [N] i32, opacity_sum, alpha_sum, visibility_sum (= sum of blending weights alpha*T), weighted_sum
+    (= sum of pixel_weights * alpha * T, None without pixel_weights), dist_sum (None unless with_dist)), all [N] f32."""
+    if tile_size != 16:
+        raise NotImplementedError("tile_size 16 only")
+    m2 = _f32c(means2d.detach()).reshape(-1, 2)
+    con = _f32c(conics.detach()).reshape(-1, 3)
+    op = _f32c(opacities.detach()).reshape(-1)
+    N, dev = m2.shape[0], m2.device
+    offs = isect_offsets.reshape(-1).to(torch.int32).contiguous()
+    flat = flatten_ids.to(torch.int32).contiguous()
+    tile_w, tile_h = (image_width + 15) // 16, (image_height + 15) // 16
+    assert offs.numel() == tile_w * tile_h
+    count = torch.zeros((N,), dtype=torch.int32, device=dev)
+    sums = torch.zeros((5, N), dtype=torch.float32, device=dev)
+    pw = None
+    if pixel_weights is not None:
+        pw = _f32c(pixel_weights.detach()).reshape(image_height, image_width)
+    n_isects = flat.shape[0]
+    if N > 0 and n_isects > 0:
+        with torch.cuda.device(dev):
+            L.call("gspl_composite_scores", N, n_isects, mode, L.ptr(m2), L.ptr(con), L.ptr(op), image_width, image_height, 16, tile_w, tile_h,
+                   L.ptr(offs), L.ptr(flat), L.ptr(pw), L.ptr(count), L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(sums[2]),
+                   L.ptr(sums[3]) if pw is not None else None, L.ptr(sums[4]) if with_dist else None, L.stream())
+    return count, sums[0], sums[1], sums[2], (sums[3] if pw is not None else None), (sums[4] if with_dist else None)
+
+
+def hit_pixel_count(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor, opacities: Tensor,
+                    img_height: int, img_width: int, block_width: int = 16):
+    """Signature of the gsplat fork's `hit_pixel_count` as the reference calls it
+    (internal/renderers/gsplat_hit_pixel_count_renderer.py:34-44): returns (count [N] i32, opacity_score, alpha_score,
+    visibility_score [N] f32) of one view — the number of pixels a splat is composited into and the sums of its opacity,
+    alpha and blending weight alpha*T over them (LightGaussian's importance terms; restated, parity unpinned)."""
+    flat, offsets = bin_gaussians(xys, depths, radii, img_height, img_width, block_width, conics=conics, opacities=opacities)
+    count, o_sum, a_sum, v_sum, _, _ = composite_scores(xys, conics, opacities, img_width, img_height, block_width, offsets, flat)
+    return count, o_sum, a_sum, v_sum
+
+
+def rasterize_to_weights(means2d: Tensor, conics: Tensor, opacities: Tensor, image_width: int, image_height: int, tile_size: int,
+                         isect_offsets: Tensor, flatten_ids: Tensor, pixel_weights: Tensor):
+    """Signature of the gsplat fork's `rasterize_to_weights` as the reference calls it
+    (internal/density_controllers/taming_3dgs_density_controller.py:429-439): batched inputs ([1,N,..], pixel_weights
+    [1,H,W]); returns (accum_weights, reverse_counts, blend_weights, dist_accum), each [1,N] f32: per splat, over the pixels
+    it contributes to, the sum of pixel_weight * alpha * T, the number of pixels, the sum of alpha * T and the sum of the
+    pixel-to-centre distances (Taming-3DGS score terms; restated from the paper's description, parity unpinned)."""
+    count, _, _, v_sum, w_sum, d_sum = composite_scores(means2d, conics, opacities, image_width, image_height, tile_size, isect_offsets,
+                                                        flatten_ids, pixel_weights=pixel_weights, with_dist=True)
+    return w_sum[None], count.float()[None], v_sum[None], d_sum[None]
+
+
 class _side_stream:
     """`with _side_stream(dev) as s:` runs the enclosed launches on a per-device side stream that first waits for everything
     already enqueued on the current stream; `s.join()` makes the current stream wait for them.  Set GSPL_SIDE_STREAM=0 to

@@ -408,6 +408,26 @@ int gspl_densify_stats(int N, const float* grad, int grad_stride, float scale_x,
                        const int32_t* radii_i32 /*nullable*/, const float* radii_f32 /*nullable*/,
                        float* accum, float* denom, float* max_radii /*nullable*/, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 12. Per-splat statistics of a compositing pass (hit-pixel count / rasterize_to_weights).
+ *    What LightGaussian pruning (internal/utils/light_gaussian.py:37-50 through
+ *    internal/renderers/gsplat_hit_pixel_count_renderer.py:34-44 -> gsplat fork `hit_pixel_count`) and the
+ *    Taming-3DGS / GNS scores (internal/density_controllers/taming_3dgs_density_controller.py:429-439 ->
+ *    gsplat fork `rasterize_to_weights`) read.  Both kernels are un-vendored; the sums are restated from the
+ *    published methods (PARITY UNPINNED).  Traversal and discrete rules of gspl_composite_fwd; for every splat g,
+ *    over the pixels p it contributes to (alpha >= 1/255, before the pixel saturates), ADDED to the arrays:
+ *        count[g] += 1;  opacity_sum[g] += opacities[g];  alpha_sum[g] += alpha;  visibility_sum[g] += alpha T;
+ *        weighted_sum[g] += pixel_weights[p] alpha T;  dist_sum[g] += |p - means2d[g]|
+ *    Any output may be NULL; pixel_weights [H,W] f32 is needed for weighted_sum only.  Outputs [N], zeroed by
+ *    the caller (several cameras accumulate into the same arrays).
+ * ---------------------------------------------------------------------------------------- */
+int gspl_composite_scores(int N, int64_t n_isects, int mode,
+                          const float* means2d, const float* conics, const float* opacities,
+                          int width, int height, int tile_size, int tile_w, int tile_h,
+                          const int32_t* offsets, const int32_t* flatten_ids, const float* pixel_weights /*nullable*/,
+                          int32_t* count, float* opacity_sum, float* alpha_sum, float* visibility_sum,
+                          float* weighted_sum, float* dist_sum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
