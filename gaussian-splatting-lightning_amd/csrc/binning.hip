@@ -590,7 +590,12 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
         if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
     }
     if (w.own_depth_sort)
-        return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_tmp_off + w.scan_states_off, s);
+    {
+        RadixPlan dp;
+        radix_plan((size_t)N, 0, 32, 8, RADIX_TILE_U32, dp);
+        return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_tmp_off + w.scan_states_off,
+                                    (uint32_t*)(ws + w.sort1_tmp_off + dp.ticket_off) + RADIX_MAX_PASSES, s);
+    }
     tmp = w.scan_tmp_bytes;
     e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp,
                                 rocprim::make_transform_iterator((const uint32_t*)order, GatherCount{counts}), cum_tiles, (size_t)N,

@@ -7,12 +7,13 @@
 // strips the rest:
 //   * ONE header kernel per sort computes the digit histograms of every pass and clears the look-back states of every
 //     pass (or no kernel at all when the producer of the keys did both, see `RadixSort::prepared`);
-//   * one kernel per pass, launched with no more workgroups than the device keeps resident; workgroup b walks tiles
-//     b, b + grid, ... in increasing order, so a tile only ever waits for tiles owned by resident workgroups that reach
-//     them without waiting for it: no dispatch-order assumption and no ticket counter.  (Tickets were measured: a
-//     single-address atomic hands out ~60 M/s on this part, i.e. 8 us of queueing per pass for the 489 tiles of the
-//     1 M-splat depth sort and more than the whole pass for small tiles; drawing several consecutive tiles per ticket
-//     serialises the look-back chain instead — a batch's first tile waits for the previous batch's LAST tile.)
+//   * one kernel per pass.  When all tiles fit the device at once (the 1 M-splat depth sort: 489 tiles) every workgroup takes
+//     the tile of its index — a tile only waits for lower tiles, so a co-resident grid needs no ordering at all and no
+//     counter (a single-address atomic hands out ~60 M tickets/s on this part: 8 us of queueing per pass for 489 tiles).
+//     Larger sorts draw their tiles from a counter, one per draw: every tile below a drawn one then belongs to a running
+//     workgroup, whatever the dispatch order, the residency or the other kernels on the device.  (Measured and dropped:
+//     a resident grid looping over tiles b, b + grid, ... dead-locks as soon as several processes share the GPU;
+//     several consecutive tiles per draw serialise the look-back — a batch's first tile waits for the previous batch's LAST.)
 //   * the per-tile state is one 32-bit word (2 flag bits | 30 count bits) moved with agent-scope relaxed atomics —
 //     coherent across the eight XCD L2s without cache write-backs, and self-describing, so no fences.
 // Sizes above 2^30 - 1 items do not fit the state word: callers fall back to rocPRIM there.
@@ -43,8 +44,8 @@ struct RadixPlan {
     uint32_t tile_items;
     uint32_t ntiles;
     uint32_t ngroups;                                  // look-back groups (complete ones)
-    // workspace layout (byte offsets): [hist: 8 copies x 4 passes x 256 u32][states: passes x (ntiles + ngroups) x 256 u32]
-    size_t hist_off, states_off, header_bytes, total_bytes;
+    // workspace layout (byte offsets): [hist: 8 copies x 4 passes x 256 u32][tile counters: 16 u32][states: passes x (ntiles + ngroups) x 256 u32]
+    size_t hist_off, ticket_off, states_off, header_bytes, total_bytes;
 };
 
 // Plan a sort of key bits [begin_bit, end_bit).  digit_bits = widest digit (<= 8); passes = ceil(bits / digit_bits),
@@ -66,6 +67,7 @@ int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[
 // bytes, zero on entry (16-byte aligned; the key pass clears them together with the sort's rows).
 static constexpr int SCAN_TILE = 2048;
 size_t scan_state_bytes(size_t n);
-int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, void* stream);
+int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket /* zero on entry */,
+                         void* stream);
 
 }  // namespace gspl

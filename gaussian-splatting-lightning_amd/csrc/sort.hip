@@ -5,8 +5,8 @@
 // `cub::DeviceRadixSort::SortPairs(point_list_keys...)` (call sites: reference gsplat_v1_renderer.py:524-556,
 // vanilla_renderer.py:111).  Ordering contract: stable, ascending on the selected key bits — identical to those.
 //
-// Pass kernel: a resident grid, workgroup b owns tiles b, b + grid, ... (8 waves; a tile = 512 x IPT items, held in
-// (wave, round, lane) = memory order).  Per tile:
+// Pass kernel (8 waves; a tile = 512 x IPT items, held in (wave, round, lane) = memory order); one tile per workgroup when the
+// grid is certainly co-resident, tiles drawn from a counter otherwise (see radix_pass_kernel).  Per tile:
 //   1. load; in-wave ranks by digit matching (one ballot per digit bit), per-wave digit counters in LDS
 //   2. counters -> tile histogram -> publish LOCAL|count per digit; exclusive scan -> first in-tile slot per digit
 //   3. permute the tile through LDS into digit order
@@ -115,11 +115,22 @@ struct RadixShared {
     uint32_t xval[VALUES ? RS_THREADS * IPT : 1];
 };
 
-template <typename KeyT, bool VALUES, int IPT>
+// TICKET = false: one tile per workgroup (tile = blockIdx.x).  A tile waits for lower tiles only, so the launch makes progress
+//   whenever the lowest unfinished tile is resident: always when the whole grid is co-resident (the launcher checks that it
+//   fits a device that is otherwise idle), and under contention as long as workgroups start in index order (observed;
+//   not promised — the look-back traps after 2^24 polls instead of hanging).  No counter, no queueing: the fast path of
+//   the 1 M-splat depth sort.
+// TICKET = true: workgroups draw tiles from a counter until it runs out, so every tile below a drawn one belongs to a
+//   RUNNING workgroup whatever the dispatch order, the residency or the other kernels on the device (a resident grid
+//   looping over tiles b, b + grid, ... was measured to dead-lock when three processes shared the GPU: resident
+//   workgroups waited for tiles of workgroups that could not start).  The draw for the next tile is issued a tile ahead; a
+//   single-address atomic is served at ~60 M/s, which bounds this mode at ~16 ns per tile.
+template <typename KeyT, bool VALUES, int IPT, bool TICKET>
 __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                 uint32_t ntiles, int shift, int nbits, const uint32_t* __restrict__ hist,
-                                                                uint32_t* __restrict__ states, uint32_t* __restrict__ gstates) {
+                                                                uint32_t* __restrict__ states, uint32_t* __restrict__ gstates,
+                                                                uint32_t* __restrict__ ticket) {
     constexpr uint32_t TILE = RS_THREADS * IPT;
     __shared__ RadixShared<KeyT, VALUES, IPT> sh;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -141,7 +152,14 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
             if (VALUES) v[r] = valid ? vals_in[b0 + slot] : 0u;
         }
     };
-    load_tile(blockIdx.x, key, val);
+    __shared__ uint32_t s_tile;
+    uint32_t tile = blockIdx.x;
+    if (TICKET) {
+        if (t == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        tile = s_tile;
+    }
+    load_tile(tile, key, val);
     if (t < RADIX_BINS) {
         uint32_t c = 0u;
         if (t < nd) {
@@ -152,8 +170,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
     }
     bool first = true;
 
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    while (tile < ntiles) {
         const uint32_t base = tile * TILE;
+        uint32_t drawn = 0u;
+        if (TICKET && t == 0) drawn = atomicAdd(ticket, 1u);      // next tile; the value is needed after the third barrier
         const uint32_t tile_n = min(TILE, n - base);
         // ---- 1: rank (wave w owns slots [w*64*IPT, (w+1)*64*IPT) of the tile, 64 per round) ------------------------------
 #pragma unroll
@@ -194,6 +214,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
         scan256_excl(sh.tilecnt, sh.dstart);
         if (first) scan256_excl(sh.histo, sh.dbase);
         first = false;
+        if (TICKET && t == 0) s_tile = drawn;
         __syncthreads();
         // ---- 3: permute through LDS ------------------------------------------------------------------------------------
 #pragma unroll
@@ -206,7 +227,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
                 if (VALUES) sh.xval[pos] = val[r];
             }
         }
-        load_tile(tile + gridDim.x, key_next, val_next);        // in flight during the look-back and the write-out
+        const uint32_t next_tile = TICKET ? s_tile : ntiles;        // (no ticket: one tile per workgroup)
+        load_tile(next_tile, key_next, val_next);                   // in flight during the look-back and the write-out
         // ---- 4: look-back ------------------------------------------------------------------------------------------------
         // The resident workgroups run in near lock-step, so a tile's predecessors are mostly LOCAL and a tile-by-tile walk
         // would cover ~grid/2 of them.  The last tile of every RS_GROUP tiles (the "closer") also publishes the group's
@@ -240,6 +262,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
         }
 #pragma unroll
         for (int r = 0; r < IPT; ++r) { key[r] = key_next[r]; val[r] = val_next[r]; }
+        tile = next_tile;
         __syncthreads();
     }
 }
@@ -263,7 +286,8 @@ bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_i
     plan.tile_items = (uint32_t)tile_items;
     plan.ntiles = (uint32_t)((n + tile_items - 1) / tile_items);
     plan.hist_off = 0;
-    plan.header_bytes = (size_t)RADIX_HIST_COPIES * RADIX_MAX_PASSES * RADIX_BINS * sizeof(uint32_t);
+    plan.ticket_off = (size_t)RADIX_HIST_COPIES * RADIX_MAX_PASSES * RADIX_BINS * sizeof(uint32_t);
+    plan.header_bytes = plan.ticket_off + 64;               // one tile counter per pass (+ one for a scan that shares the header)
     plan.states_off = plan.header_bytes;
     plan.ngroups = plan.ntiles / RS_GROUP;                 // only complete groups are ever walked over
     plan.total_bytes = plan.states_off + (size_t)passes * ((size_t)plan.ntiles + plan.ngroups + 1) * RADIX_BINS * sizeof(uint32_t);
@@ -275,12 +299,12 @@ bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_i
 // "8 waves per SIMD") was observed to get one wave per SIMD less than promised, and a grid that is not co-resident
 // dead-locks the look-back: one workgroup per CU is taken off the promise (never below one per CU, which always fits).
 template <typename Kernel>
-static unsigned resident_blocks(Kernel kernel) {
+static unsigned resident_blocks(Kernel kernel, bool certain = true) {
     int per_cu = 0, dev = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RS_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
     (void)hipGetLastError();
-    if (per_cu > 1) --per_cu;
+    if (certain && per_cu > 1) --per_cu;
     if (const char* cap = getenv("GSPL_SORT_MAX_PER_CU")) { const int c = atoi(cap); if (c >= 1 && c < per_cu) per_cu = c; }
     if (getenv("GSPL_SORT_DEBUG")) fprintf(stderr, "[gspl sort] resident blocks per CU %d, CUs %d\n", per_cu, cus);
     return (unsigned)per_cu * (unsigned)cus;
@@ -288,12 +312,18 @@ static unsigned resident_blocks(Kernel kernel) {
 
 template <typename KeyT, bool VALUES, int IPT>
 static int launch_pass(const RadixPlan& plan, int p, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout, const uint32_t* hist,
-                       uint32_t* states, uint32_t* gstates, hipStream_t s) {
-    static unsigned resident = 0;             // same value on every device of a node; a benign race at worst
-    if (resident == 0) resident = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT>);
-    const unsigned grid = plan.ntiles < resident ? plan.ntiles : resident;
-    hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT>), dim3(grid), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, plan.n, plan.ntiles,
-                       plan.shift[p], plan.bits[p], hist, states, gstates);
+                       uint32_t* states, uint32_t* gstates, uint32_t* ticket, hipStream_t s) {
+    static unsigned safe = 0, full = 0;       // same values on every device of a node; a benign race at worst
+    if (safe == 0) {
+        full = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT, true>, false);
+        safe = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT, false>, true);
+    }
+    if (plan.ntiles <= safe && !getenv("GSPL_SORT_FORCE_TICKET"))
+        hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT, false>), dim3(plan.ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, plan.n,
+                           plan.ntiles, plan.shift[p], plan.bits[p], hist, states, gstates, ticket);
+    else
+        hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT, true>), dim3(plan.ntiles < full ? plan.ntiles : full), dim3(RS_THREADS), 0, s, kin, vin,
+                           kout, vout, plan.n, plan.ntiles, plan.shift[p], plan.bits[p], hist, states, gstates, ticket);
     return check_launch("radix_sort(pass)");
 }
 
@@ -328,8 +358,8 @@ static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const k
     }
     for (int p = 0; p < plan.passes; ++p) {
         int rc;
-        if (vals) rc = launch_pass<KeyT, true, IPT>(plan, p, keys[p & 1], vals[p & 1], keys[(p + 1) & 1], vals[(p + 1) & 1], hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, s);
-        else rc = launch_pass<KeyT, false, IPT>(plan, p, keys[p & 1], nullptr, keys[(p + 1) & 1], nullptr, hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, s);
+        if (vals) rc = launch_pass<KeyT, true, IPT>(plan, p, keys[p & 1], vals[p & 1], keys[(p + 1) & 1], vals[(p + 1) & 1], hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, (uint32_t*)(ws + plan.ticket_off) + p, s);
+        else rc = launch_pass<KeyT, false, IPT>(plan, p, keys[p & 1], nullptr, keys[(p + 1) & 1], nullptr, hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, (uint32_t*)(ws + plan.ticket_off) + p, s);
         if (rc != GSPL_OK) return rc;
     }
     return GSPL_OK;
@@ -349,13 +379,22 @@ static constexpr unsigned long long SC_FLAG_GLOBAL = 2ull << 62;
 static constexpr unsigned long long SC_VALUE_MASK = (1ull << 62) - 1ull;
 static constexpr int SC_IPT = SCAN_TILE / RS_THREADS;
 
+template <bool TICKET>      // as radix_pass_kernel: one tile per workgroup, or tiles drawn from a counter
 __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
                                                                  int64_t* __restrict__ cum, uint32_t n, uint32_t ntiles,
-                                                                 unsigned long long* __restrict__ states) {
+                                                                 unsigned long long* __restrict__ states, uint32_t* __restrict__ ticket) {
     __shared__ unsigned long long s_wave[RS_WAVES];
     __shared__ unsigned long long s_excl;
+    __shared__ uint32_t s_tile;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    while (true) {
+        uint32_t tile = blockIdx.x;
+        if (TICKET) {
+            if (t == 0) s_tile = atomicAdd(ticket, 1u);
+            __syncthreads();
+            tile = s_tile;
+        }
+        if (tile >= ntiles) break;
         const uint32_t first = tile * (uint32_t)SCAN_TILE + (uint32_t)t * SC_IPT;       // SC_IPT consecutive items per thread
         unsigned long long v[SC_IPT], mine = 0ull;
 #pragma unroll
@@ -413,6 +452,7 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
             if (i < n) cum[i] = (int64_t)run;
         }
         __syncthreads();
+        if (!TICKET) break;
     }
 }
 
@@ -421,13 +461,20 @@ size_t scan_state_bytes(size_t n) {
     return ((tiles ? tiles : 1) * sizeof(unsigned long long) + 15) / 16 * 16;
 }
 
-int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, void* stream) {
+int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket, void* stream) {
     if (n == 0) return GSPL_OK;
-    static unsigned safe = 0;
-    if (safe == 0) safe = resident_blocks(scan_gather_kernel);
+    static unsigned safe = 0, full = 0;
+    if (safe == 0) {
+        full = resident_blocks(scan_gather_kernel<true>, false);
+        safe = resident_blocks(scan_gather_kernel<false>, true);
+    }
     const unsigned ntiles = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(scan_gather_kernel, dim3(ntiles < safe ? ntiles : safe), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum, (uint32_t)n,
-                       ntiles, (unsigned long long*)states);
+    if (ntiles <= safe && !getenv("GSPL_SORT_FORCE_TICKET"))
+        hipLaunchKernelGGL(scan_gather_kernel<false>, dim3(ntiles), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum, (uint32_t)n, ntiles,
+                           (unsigned long long*)states, ticket);
+    else
+        hipLaunchKernelGGL(scan_gather_kernel<true>, dim3(ntiles < full ? ntiles : full), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum,
+                           (uint32_t)n, ntiles, (unsigned long long*)states, ticket);
     return check_launch("scan_gathered_counts");
 }
 
