@@ -166,3 +166,43 @@ def test_distributed_renderer_world1_matches_v1():
         assert_close_scaled(a.grad.cpu().numpy(), b.grad.cpu().numpy(), 2e-5, "grad", frac_ok=0.999)
     xys = out["projection_results_list"][0][1]
     assert xys.grad is not None and xys.grad.shape == (params[0].shape[0], 2)
+
+
+def test_concurrent_streams_are_reentrant():
+    """The viewer situation (SURVEY §8b threads/streams): several host threads, each on its own stream, render concurrently
+    under no_grad.  Every frame must equal the single-thread frame bit for bit (scratch is per call; the look-back sort and
+    scan kernels of concurrent frames share the device)."""
+    import threading
+    import gspl_amd  # noqa: F401
+    from gspl_amd import ops, synthetic
+    wl = synthetic.WORKLOADS["S-800-100k"]
+    cam = synthetic.camera(wl["width"], wl["height"], wl["fx"], distance=4.0)
+    m, s_, q, o, c = [t.to(DEV) for t in synthetic.scene(wl["n"], seed=42)]
+    settings = ops.GaussianRasterizationSettings(
+        image_height=wl["height"], image_width=wl["width"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=DEV),
+        scale_modifier=1.0, viewmatrix=cam["world_to_camera"].to(DEV), projmatrix=cam["full_projection"].to(DEV), sh_degree=3,
+        campos=cam["camera_center"].to(DEV))
+    rast = ops.GaussianRasterizer(settings)
+
+    def frame():
+        with torch.no_grad():
+            return rast(means3D=m, means2D=torch.empty_like(m), opacities=o, shs=c, scales=s_, rotations=q)[0]
+
+    ref = frame().clone()
+    torch.cuda.synchronize()
+    bad = []
+
+    def worker():
+        st = torch.cuda.Stream(device=DEV)
+        with torch.cuda.stream(st):
+            for _ in range(12):
+                if not torch.equal(frame(), ref):
+                    bad.append(1)
+            st.synchronize()
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad
