@@ -276,6 +276,12 @@ def main():
 
     for _ in range(args.warmup):
         full_step(force_reduce=True)
+    # Host hygiene: a full (generation-2) pass of Python's cyclic GC walks every object torch has imported — 30-40 ms during
+    # which no kernel is launched, once every ~130 steps (seen as one 38 ms step in GSPL_BENCH_DUMP=1 runs).  Freezing what
+    # exists after warm-up keeps later collections to the objects of the steps themselves.
+    import gc
+    gc.collect()
+    gc.freeze()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -292,6 +298,15 @@ def main():
     marks = step.state.pop("marks")
     phase_fwd = sum(marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)) / args.steps
     phase_bwd = sum(marks[i + 1].elapsed_time(marks[i + 2]) for i in range(0, len(marks), 3)) / args.steps
+    if os.environ.get("GSPL_BENCH_DUMP") and rank == 0:
+        # per-step device times, for hunting outliers: step span = start of step i to start of step i+1
+        starts = marks[0::3]
+        spans = [starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1)]
+        fw = [marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)]
+        srt = sorted(spans)
+        print("step spans ms: median %.3f p90 %.3f p99 %.3f max %.3f; outliers (>2x median): %s" % (
+            srt[len(srt) // 2], srt[int(len(srt) * 0.9)], srt[int(len(srt) * 0.99)], srt[-1],
+            [(i, round(x, 2), round(fw[i], 2)) for i, x in enumerate(spans) if x > 2 * srt[len(srt) // 2]][:40]), file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
