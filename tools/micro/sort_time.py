@@ -44,7 +44,7 @@ def main():
     tc = time_call(lambda: k0.copy_(k_src))
     print(f"depth sort  {n} u32 pairs, 32 bits: {time_call(depth) - tc:8.1f} us   (torch.sort: {time_call(lambda: torch.sort(k_src)):8.1f} us)")
 
-    ni = 13_818_945
+    ni = int(os.environ.get("SORT_NI", "13818945"))
     tile = torch.randint(0, 8160, (ni,), device=DEV, dtype=torch.int64)
     rec = (tile << 32) | torch.arange(ni, device=DEV, dtype=torch.int64)
     r0, r1 = rec.clone(), torch.empty_like(rec)
