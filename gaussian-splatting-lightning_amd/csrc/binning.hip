@@ -99,6 +99,12 @@ __global__ __launch_bounds__(256) void isect_offsets_kernel(
     }
 }
 
+__global__ void fill_i64_kernel(int64_t* p, int64_t v) { *p = v; }
+__global__ __launch_bounds__(256) void bin_big_list_kernel(int N, const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ big_list, unsigned long long* __restrict__ n_big) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && counts[order[i]] < 0) big_list[atomicAdd(n_big, 1ull)] = i;
+}
 __global__ void fill_i32_kernel(int n, int32_t v, int32_t* __restrict__ p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
             }
             w0 = (uint32_t)(miny & 0xFFFF) | ((big ? (uint32_t)SPAN_BIG : (uint32_t)rows) << 16);
         }
-        counts[g] = n;
+        // bit 31 tags the splats the emission leaves to bin_emit_big_kernel (the scan of the counts ranks them on its way)
+        counts[g] = n | ((big && n > 0) ? (int)0x80000000 : 0);
         ids[g] = (uint32_t)g;
         key = n > 0 ? __float_as_uint(depths[g]) : 0xFFFFFFFFu;      // splats without tiles sort to the end
         keys[g] = key;
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
 // counts[order[i]] as int64: the input "array" of the scan over per-splat tile counts in depth order (no gather pass)
 struct GatherCount {
     const int32_t* counts;
-    __device__ int64_t operator()(uint32_t g) const { return (int64_t)counts[g]; }
+    __device__ int64_t operator()(uint32_t g) const { return (int64_t)(counts[g] & 0x7fffffff); }
 };
 
 // Load-balanced emission.  A lane-per-splat loop would let every lane write its own run of records (8 B stores 30-60 B
@@ -322,112 +329,129 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
-    const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, int tile_size, int tile_w, int tile_h,
-    uint64_t* __restrict__ tile_keys, int64_t capacity) {
+    const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, const int32_t* __restrict__ big_list,
+    int tile_size, int tile_w, int tile_h, uint64_t* __restrict__ tile_keys, int64_t capacity) {
     __shared__ int s_start[4][65];
+    __shared__ int s_out[4][64];
     __shared__ uint32_t s_gid[4][64];
     __shared__ int s_row0[4][64];
     __shared__ uint16_t s_c0[4][64][EMIT_ROWS];
     __shared__ uint16_t s_pre[4][64][EMIT_ROWS + 1];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int i = blockIdx.x * 256 + t;
     const int wave_first = blockIdx.x * 256 + w * 64;
-    if (wave_first >= N) return;
-    const int64_t wave_base = (wave_first == 0) ? 0 : cum_sorted[wave_first - 1];
-    const int wave_last = min(N, wave_first + 64) - 1;
-    const int total = (int)(cum_sorted[wave_last] - wave_base);
-    if (total == 0) return;
-
-    int g = 0, cnt = 0, start = total, minx = 0, miny = 0, maxx = 0, maxy = 0;
-    uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = make_uint4(0u, 0u, 0u, 0u);      // the splat's SpanRecord as eight words
-    if (i < N) {
-        const int64_t off = (i == 0) ? 0 : cum_sorted[i - 1];
-        start = (int)(off - wave_base);
-        cnt = (int)(cum_sorted[i] - off);
-        g = (int)order[i];
-        if (cnt > 0) {
-            const uint4* src = reinterpret_cast<const uint4*>(spans + g);
-            ra = src[0];
-            rb = src[1];
+    // ---- phase A: the wave's 64 splats, except the big ones ----------------------------------------------------------------
+    if (wave_first < N) {
+        const int64_t wave_base = (wave_first == 0) ? 0 : cum_sorted[wave_first - 1];
+        int g = 0, cnt = 0, start = 0;
+        uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = make_uint4(0u, 0u, 0u, 0u);      // the splat's SpanRecord as eight words
+        if (i < N) {
+            const int64_t off = (i == 0) ? 0 : cum_sorted[i - 1];
+            start = (int)(off - wave_base);
+            cnt = (int)(cum_sorted[i] - off);
+            g = (int)order[i];
+            if (cnt > 0) {
+                const uint4* src = reinterpret_cast<const uint4*>(spans + g);
+                ra = src[0];
+                rb = src[1];
+            }
+        }
+        const uint32_t rec_rows = ra.x >> 16, rec_miny = ra.x & 0xFFFFu;
+        // splats the records cannot describe (more than EMIT_ROWS tile rows, or a very wide row) are emitted in phase B:
+        // their slots are taken out of the range the lanes walk (a screen-filling splat has thousands)
+        const bool big = cnt > 0 && rec_rows == (uint32_t)SPAN_BIG;
+        uint4 ea = make_uint4(0u, 0u, 0u, 0u), eb = make_uint4(0u, 0u, 0u, 0u);      // rows 8..15 (second record), only when present
+        if (cnt > 0 && !big && rec_rows > 8u) {
+            const uint4* src = reinterpret_cast<const uint4*>(spans + N + g);
+            ea = src[0];
+            eb = src[1];
+        }
+        const uint32_t wc[8] = {ra.y, ra.z, ra.w, rb.x, ea.x, ea.y, ea.z, ea.w}, wn[4] = {rb.y, rb.z, eb.x, eb.y};
+        const int cnt_small = big ? 0 : cnt;
+        const int start_small = wave_excl_scan(cnt_small, l);
+        const int total = __shfl(start_small + cnt_small, 63);
+        s_start[w][l] = start_small;
+        if (l == 0) s_start[w][64] = total;
+        s_out[w][l] = start;
+        s_gid[w][l] = (uint32_t)g;
+        s_row0[w][l] = (int)rec_miny;
+        if (cnt_small > 0) {
+            int acc = 0;
+#pragma unroll
+            for (int r = 0; r < EMIT_ROWS; ++r) {
+                s_c0[w][l][r] = (uint16_t)(wc[r >> 1] >> (16 * (r & 1)));
+                s_pre[w][l][r] = (uint16_t)acc;
+                acc += (int)((wn[r >> 2] >> (8 * (r & 3))) & 0xFFu);
+            }
+            s_pre[w][l][EMIT_ROWS] = (uint16_t)acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // every output slot of the wave's (small) range, owners found by binary search
+        for (int k = l; k < total; k += 64) {
+            int lo = 0, hi = 63;                       // largest o with s_start[o] <= k and a non-empty segment after it
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_start[w][mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            // lo may point at an empty segment sharing the start: the owner is the LAST lane with start <= k, which the
+            // search returns because empty segments before the owner have start == owner's start and come earlier
+            const int o = lo;
+            const int kk = k - s_start[w][o];
+            int r = 0;                                  // last row whose prefix <= kk (empty rows share their successor's prefix)
+#pragma unroll
+            for (int step = EMIT_ROWS / 2; step > 0; step >>= 1) r += (kk >= (int)s_pre[w][o][r + step]) ? step : 0;
+            const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
+            const int ty = s_row0[w][o] + r;
+            const int64_t out = wave_base + s_out[w][o] + kk;
+            if (out < capacity)      // a speculative launch may have guessed the list length too low (the host redoes it)
+                tile_keys[out] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
         }
     }
-    const uint32_t rec_rows = ra.x >> 16, rec_miny = ra.x & 0xFFFFu;
-    const bool big = cnt > 0 && rec_rows == (uint32_t)SPAN_BIG;
-    uint4 ea = make_uint4(0u, 0u, 0u, 0u), eb = make_uint4(0u, 0u, 0u, 0u);      // rows 8..15 (second record), only when present
-    if (cnt > 0 && !big && rec_rows > 8u) {
-        const uint4* src = reinterpret_cast<const uint4*>(spans + N + g);
-        ea = src[0];
-        eb = src[1];
-    }
-    const uint32_t wc[8] = {ra.y, ra.z, ra.w, rb.x, ea.x, ea.y, ea.z, ea.w}, wn[4] = {rb.y, rb.z, eb.x, eb.y};
-    // the few splats the records cannot describe (more than 16 tile rows, or a very wide row) recompute their spans from the inputs
-    SplatCull sc;
-    sc.kind = 2;
-    if (big) {
+    // ---- phase B: the big splats of the whole frame, dealt out to the workgroups -------------------------------------------
+    // (close-up splats are consecutive in depth order: left to their own waves, a few waves would emit up to 64
+    // screen-filling splats one after the other.)  `big_list` / cum_sorted[N]: their depth-order indices and number, ranked
+    // by the scan of the counts.  All 256 threads work on one splat: rows in chunks of 256 (one per thread: exact column
+    // span, scan), then every output slot of the chunk by one thread (row by binary search in the chunk's prefix).
+    const int n_big = (int)cum_sorted[N];
+    if ((int)blockIdx.x >= n_big) return;              // uniform per workgroup
+    __shared__ int s_bpre[257];
+    __shared__ int s_bc0[256];
+    __shared__ int s_bwave[4];
+    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const int bi = big_list[b];
+        const int g = (int)order[bi];
+        int64_t out = (bi == 0) ? 0 : cum_sorted[bi - 1];
+        int minx, miny, maxx, maxy;
         const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
         tile_rect<MODE>(mx, my, radii[g], tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
+        SplatCull sc;
+        sc.kind = 2;
         if (conics) sc = make_cull(mx, my, conics[g * 3 + 0], conics[g * 3 + 1], conics[g * 3 + 2], opacities[g]);
-    }
-    s_start[w][l] = start;
-    if (l == 0) s_start[w][64] = total;
-    s_gid[w][l] = (uint32_t)g;
-    s_row0[w][l] = big ? miny : (int)rec_miny;
-    if (cnt > 0 && !big) {
-        int acc = 0;
-#pragma unroll
-        for (int r = 0; r < EMIT_ROWS; ++r) {
-            s_c0[w][l][r] = (uint16_t)(wc[r >> 1] >> (16 * (r & 1)));
-            s_pre[w][l][r] = (uint16_t)acc;
-            acc += (int)((wn[r >> 2] >> (8 * (r & 3))) & 0xFFu);
-        }
-        s_pre[w][l][EMIT_ROWS] = (uint16_t)acc;
-    }
-    const unsigned long long big_mask = __ballot(big);
-    const unsigned long long any_mask = __ballot(cnt > 0);
-    // ---- phase A: every output slot of the wave's range, owners found by binary search -----------------------
-    for (int k = l; k < total; k += 64) {
-        int lo = 0, hi = 63;                       // largest o with s_start[o] <= k and a non-empty segment after it
-#pragma unroll
-        for (int step = 0; step < 6; ++step) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_start[w][mid] <= k) lo = mid; else hi = mid - 1;
-        }
-        // lo may point at an empty segment sharing the start: the owner is the LAST lane with start <= k, which the
-        // search returns because empty segments before the owner have start == owner's start and come earlier
-        const int o = lo;
-        if ((big_mask >> o) & 1ull) continue;      // emitted in phase B
-        const int kk = k - s_start[w][o];
-        int r = 0;                                  // last row whose prefix <= kk (empty rows share their successor's prefix)
-#pragma unroll
-        for (int step = EMIT_ROWS / 2; step > 0; step >>= 1) r += (kk >= (int)s_pre[w][o][r + step]) ? step : 0;
-        const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
-        const int ty = s_row0[w][o] + r;
-        if (wave_base + k < capacity)      // a speculative launch may have guessed the list length too low (the host redoes it)
-            tile_keys[wave_base + k] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
-    }
-    (void)any_mask;
-    // ---- phase B: splats spanning many tile rows, one at a time, lanes over rows ---------------------------
-    unsigned long long m = big_mask;
-    while (m) {
-        const int o = (int)__builtin_ctzll(m);
-        m &= m - 1;
-        SplatCull so;
-        so.mx = __shfl(sc.mx, o); so.my = __shfl(sc.my, o); so.a = __shfl(sc.a, o); so.b = __shfl(sc.b, o);
-        so.det = __shfl(sc.det, o); so.two_tau_a = __shfl(sc.two_tau_a, o); so.inv_a = __shfl(sc.inv_a, o);
-        so.hx = __shfl(sc.hx, o); so.hy = __shfl(sc.hy, o); so.dys = __shfl(sc.dys, o); so.kind = __shfl(sc.kind, o);
-        const int ominx = __shfl(minx, o), omaxx = __shfl(maxx, o), ominy = __shfl(miny, o), omaxy = __shfl(maxy, o);
-        const uint32_t og = (uint32_t)__shfl(g, o);
-        int64_t out = wave_base + __shfl(start, o);
-        for (int rbase = ominy; rbase < omaxy; rbase += 64) {
-            const int ty = rbase + l;
+        for (int rbase = miny; rbase < maxy; rbase += 256) {
+            const int ty = rbase + t;
             int c0 = 0, c1 = 0;
-            if (ty < omaxy) row_columns<MODE>(so, ty, tile_size, ominx, omaxx, c0, c1);
+            if (ty < maxy) row_columns<MODE>(sc, ty, tile_size, minx, maxx, c0, c1);
             const int n = c1 - c0;
             const int pre = wave_excl_scan(n, l);
-            for (int tx = c0; tx < c1; ++tx)
-                if (out + pre + (tx - c0) < capacity)
-                    tile_keys[out + pre + (tx - c0)] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | og;
-            out += __shfl(pre + n, 63);
+            __syncthreads();                           // the previous chunk (or phase A) is done with the shared arrays
+            if (l == 63) s_bwave[w] = pre + n;
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int c = s_bwave[k]; if (k < w) woff += c; total += c; }
+            s_bpre[t] = woff + pre;
+            s_bc0[t] = c0;
+            if (t == 0) s_bpre[256] = total;
+            __syncthreads();
+            for (int k = t; k < total; k += 256) {
+                int r = 0;
+#pragma unroll
+                for (int step = 128; step > 0; step >>= 1) r += (k >= s_bpre[r + step]) ? step : 0;
+                const int tx = s_bc0[r] + k - s_bpre[r];
+                if (out + k < capacity) tile_keys[out + k] = ((uint64_t)(uint32_t)((rbase + r) * tile_w + tx) << 32) | (uint32_t)g;
+            }
+            out += total;
         }
     }
 }
@@ -536,12 +560,13 @@ extern "C" size_t gspl_bin_workspace_bytes(int N, int64_t n_isects) {
 extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
                               const float* conics, const float* opacities,
                               int tile_size, int tile_w, int tile_h,
-                              int32_t* order, int64_t* cum_tiles, void* spans, void* workspace, size_t workspace_bytes, void* stream) {
+                              int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, void* workspace, size_t workspace_bytes,
+                              void* stream) {
     using namespace gspl;
     if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_count: bad sizes");
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_count: bad mode");
     if (N == 0) return GSPL_OK;
-    if (!means2d || !radii || !depths || !order || !cum_tiles || !spans || !workspace) return fail_arg("bin_count: NULL required pointer");
+    if (!means2d || !radii || !depths || !order || !cum_tiles || !big_list || !spans || !workspace) return fail_arg("bin_count: NULL required pointer");
     if (tile_w > 65535 || tile_h > 65535) { set_error("bin_count", "more than 65535 tile rows or columns"); return GSPL_ERR_UNSUPPORTED; }
     if ((conics == nullptr) != (opacities == nullptr)) return fail_arg("bin_count: conics and opacities go together");
     BinWorkspace w;
@@ -593,14 +618,20 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     {
         RadixPlan dp;
         radix_plan((size_t)N, 0, 32, 8, RADIX_TILE_U32, dp);
+        // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte
+        // read-back gives the host both numbers
         return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_tmp_off + w.scan_states_off,
-                                    (uint32_t*)(ws + w.sort1_tmp_off + dp.ticket_off) + RADIX_MAX_PASSES, s);
+                                    (uint32_t*)(ws + w.sort1_tmp_off + dp.ticket_off) + RADIX_MAX_PASSES, big_list, s);
     }
     tmp = w.scan_tmp_bytes;
     e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp,
                                 rocprim::make_transform_iterator((const uint32_t*)order, GatherCount{counts}), cum_tiles, (size_t)N,
                                 rocprim::plus<int64_t>(), s);
-    return check_hip(e, "bin_count: inclusive_scan");
+    if (e != hipSuccess) return check_hip(e, "bin_count: inclusive_scan");
+    // big splats of this (library scan) path: listed in any order — each finds its output range through cum_tiles
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(1), 0, s, cum_tiles + N, (int64_t)0);
+    hipLaunchKernelGGL(bin_big_list_kernel, dim3(grid), dim3(256), 0, s, N, (const uint32_t*)order, counts, big_list, (unsigned long long*)(cum_tiles + N));
+    return check_launch("bin_count(big list)");
 }
 
 // Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has
@@ -608,7 +639,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
 // dropped, and the caller repeats the call with the real length when the guess was too low.
 extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                              const float* conics, const float* opacities,
-                             const int32_t* order, const int64_t* cum_tiles, const void* spans,
+                             const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
                              int tile_size, int tile_w, int tile_h, int64_t capacity,
                              void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gspl;
@@ -616,7 +647,7 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_emit: bad mode");
     if (N == 0 || capacity == 0) return GSPL_OK;
     if (capacity > 0x7fffffffll) return fail_arg("bin_emit: more than 2^31-1 intersections");
-    if (!means2d || !radii || !order || !cum_tiles || !spans || !workspace) return fail_arg("bin_emit: NULL required pointer");
+    if (!means2d || !radii || !order || !cum_tiles || !big_list || !spans || !workspace) return fail_arg("bin_emit: NULL required pointer");
     BinWorkspace w;
     int rc = plan_bin(N, capacity, w);
     if (rc != GSPL_OK) return rc;
@@ -625,9 +656,9 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys, capacity);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity);
     else
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, tile_size, tile_w, tile_h, tkeys, capacity);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity);
     return check_launch("bin_emit");
 }
 
@@ -664,11 +695,11 @@ extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, in
 
 extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const int32_t* radii,
                                   const float* conics, const float* opacities,
-                                  const int32_t* order, const int64_t* cum_tiles, const void* spans,
+                                  const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
                                   int tile_size, int tile_w, int tile_h, int64_t n_isects,
                                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
     if (n_isects < 0) return gspl::fail_arg("bin_emit_sort: bad sizes");
-    int rc = gspl_bin_emit(N, mode, means2d, radii, conics, opacities, order, cum_tiles, spans, tile_size, tile_w, tile_h, n_isects,
+    int rc = gspl_bin_emit(N, mode, means2d, radii, conics, opacities, order, cum_tiles, big_list, spans, tile_size, tile_w, tile_h, n_isects,
                            workspace, workspace_bytes, stream);
     if (rc != GSPL_OK) return rc;
     return gspl_bin_sort(N, tile_w, tile_h, n_isects, n_isects, flatten_ids, offsets, workspace, workspace_bytes, stream);

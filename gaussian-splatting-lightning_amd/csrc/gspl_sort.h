@@ -67,7 +67,9 @@ int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[
 // bytes, zero on entry (16-byte aligned; the key pass clears them together with the sort's rows).
 static constexpr int SCAN_TILE = 2048;
 size_t scan_state_bytes(size_t n);
+// Counts with bit 31 set are TAGGED: the bit is not part of the count, and with `tagged_list` (nullable) the scan also writes
+// the positions i of the tagged items in order to tagged_list[0..) and their number to cum[n] (cum then has n + 1 entries).
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket /* zero on entry */,
-                         void* stream);
+                         int32_t* tagged_list, void* stream);
 
 }  // namespace gspl

@@ -382,7 +382,8 @@ static constexpr int SC_IPT = SCAN_TILE / RS_THREADS;
 template <bool TICKET>      // as radix_pass_kernel: one tile per workgroup, or tiles drawn from a counter
 __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
                                                                  int64_t* __restrict__ cum, uint32_t n, uint32_t ntiles,
-                                                                 unsigned long long* __restrict__ states, uint32_t* __restrict__ ticket) {
+                                                                 unsigned long long* __restrict__ states, uint32_t* __restrict__ ticket,
+                                                                 int32_t* __restrict__ tagged_list) {
     __shared__ unsigned long long s_wave[RS_WAVES];
     __shared__ unsigned long long s_excl;
     __shared__ uint32_t s_tile;
@@ -400,7 +401,10 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
 #pragma unroll
         for (int k = 0; k < SC_IPT; ++k) {
             const uint32_t i = first + k;
-            v[k] = i < n ? (unsigned long long)(uint32_t)counts[order[i]] : 0ull;
+            // bit 31 of a count tags the item: the tagged items are ranked along the way (their number rides in bits 40.. of
+            // the scanned value; the counts themselves add up to < 2^31)
+            const uint32_t c = i < n ? (uint32_t)counts[order[i]] : 0u;
+            v[k] = (unsigned long long)(c & 0x7fffffffu) | ((unsigned long long)(c >> 31) << 40);
             mine += v[k];
         }
         unsigned long long incl = mine;                                                   // scan of the thread totals in the wave
@@ -449,7 +453,13 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
         for (int k = 0; k < SC_IPT; ++k) {
             run += v[k];
             const uint32_t i = first + k;
-            if (i < n) cum[i] = (int64_t)run;
+            if (i < n) {
+                cum[i] = (int64_t)(run & ((1ull << 40) - 1ull));
+                if (tagged_list) {
+                    if (v[k] >> 40) tagged_list[(run >> 40) - 1ull] = (int32_t)i;
+                    if (i == n - 1u) cum[n] = (int64_t)(run >> 40);      // how many are tagged
+                }
+            }
         }
         __syncthreads();
         if (!TICKET) break;
@@ -461,7 +471,8 @@ size_t scan_state_bytes(size_t n) {
     return ((tiles ? tiles : 1) * sizeof(unsigned long long) + 15) / 16 * 16;
 }
 
-int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket, void* stream) {
+int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket,
+                         int32_t* tagged_list, void* stream) {
     if (n == 0) return GSPL_OK;
     static unsigned safe = 0, full = 0;
     if (safe == 0) {
@@ -471,10 +482,10 @@ int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* 
     const unsigned ntiles = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
     if (ntiles <= safe && !getenv("GSPL_SORT_FORCE_TICKET"))
         hipLaunchKernelGGL(scan_gather_kernel<false>, dim3(ntiles), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum, (uint32_t)n, ntiles,
-                           (unsigned long long*)states, ticket);
+                           (unsigned long long*)states, ticket, tagged_list);
     else
         hipLaunchKernelGGL(scan_gather_kernel<true>, dim3(ntiles < full ? ntiles : full), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum,
-                           (uint32_t)n, ntiles, (unsigned long long*)states, ticket);
+                           (uint32_t)n, ntiles, (unsigned long long*)states, ticket, tagged_list);
     return check_launch("scan_gathered_counts");
 }
 

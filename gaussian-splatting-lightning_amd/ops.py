@@ -562,7 +562,7 @@ class _PendingBins:
     """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
     __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "spans", "offsets", "tile_w", "tile_h",
-                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes")
+                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes", "big_list")
 
 
 _PINNED_WORDS: list = []      # free list of pinned int64 words for the count read-back
@@ -591,21 +591,23 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     if conics is not None and opacities is not None:
         p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
     p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
-    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = None
+    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = p.big_list = None
     p.capacity = p.ws2_bytes = 0
     if N > 0:
         p.order = torch.empty((N,), dtype=torch.int32, device=dev)
-        p.cum = torch.empty((N,), dtype=torch.int64, device=dev)
+        p.cum = torch.empty((N + 1,), dtype=torch.int64, device=dev)      # scan [N] + the number of big splats
+        p.big_list = torch.empty((N,), dtype=torch.int32, device=dev)     # depth-order indices of the splats taller than 16 tile rows
         p.spans = torch.empty((N, L.GSPL_BIN_SPAN_BYTES // 4), dtype=torch.int32, device=dev)
         ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
         if ws_bytes == 0:
             raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
-               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.spans), L.ptr(ws), ws_bytes, L.stream())
+               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.big_list), L.ptr(p.spans), L.ptr(ws), ws_bytes,
+               L.stream())
         # the one host read-back of the pipeline (sizes the sort buffers)
         p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((1,), dtype=torch.int64).pin_memory()
-        p.host_count.copy_(p.cum[-1:], non_blocking=True)
+        p.host_count.copy_(p.cum[N - 1:N], non_blocking=True)
         p.event = torch.cuda.Event()
         p.event.record()
         # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of
@@ -624,7 +626,7 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
 
 def _emit(p: "_PendingBins"):
     L.call("gspl_bin_emit", p.N, p.mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(p.cull_c), L.ptr(p.cull_o), L.ptr(p.order), L.ptr(p.cum),
-           L.ptr(p.spans), p.block_width, p.tile_w, p.tile_h, p.capacity, L.ptr(p.ws2), p.ws2_bytes, L.stream())
+           L.ptr(p.big_list), L.ptr(p.spans), p.block_width, p.tile_w, p.tile_h, p.capacity, L.ptr(p.ws2), p.ws2_bytes, L.stream())
 
 
 def bin_gaussians_end(p: _PendingBins):

@@ -179,12 +179,18 @@ int gspl_bin_count(int N, int mode,
                    const float* means2d, const int32_t* radii, const float* depths,
                    const float* conics /*nullable*/, const float* opacities /*nullable*/,
                    int tile_size, int tile_w, int tile_h,
-                   int32_t* order, int64_t* cum_tiles, void* spans /* GSPL_BIN_SPAN_BYTES * N, 16-byte aligned */,
+                   int32_t* order, int64_t* cum_tiles /* [N + 1]: inclusive scan of the tile counts in depth order, then
+                                                         n_big = the number of splats spanning more than 16 tile rows
+                                                         (radius > ~128 px: close-ups, sky blobs) or with a very wide row */,
+                   int32_t* big_list /* [N]: the depth-order indices of those splats (n_big entries, ranked by the scan);
+                                        the emission deals them out to its workgroups instead of leaving up to 64
+                                        consecutive screen-filling splats to one wave */,
+                   void* spans /* GSPL_BIN_SPAN_BYTES * N, 16-byte aligned */,
                    void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_emit_sort(int N, int mode,
                        const float* means2d, const int32_t* radii,
                        const float* conics /*nullable*/, const float* opacities /*nullable*/,
-                       const int32_t* order, const int64_t* cum_tiles, const void* spans,
+                       const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
                        int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int32_t* flatten_ids, int32_t* offsets,
                        void* workspace, size_t workspace_bytes, void* stream);
@@ -194,7 +200,7 @@ int gspl_bin_emit_sort(int N, int mode,
  * n_isects <= capacity; when the guess was too low the caller repeats gspl_bin_emit with capacity = n_isects. */
 int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                   const float* conics /*nullable*/, const float* opacities /*nullable*/,
-                  const int32_t* order, const int64_t* cum_tiles, const void* spans,
+                  const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
                   int tile_size, int tile_w, int tile_h, int64_t capacity,
                   void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,

@@ -238,6 +238,39 @@ def test_speculative_emission_recovers_from_a_low_guess(hip):
 
 
 @pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
+def test_binning_big_splats(hip, mode):
+    """Splats taller than 16 tile rows (radius > 128 px) are ranked by the scan of the counts and dealt out to the workgroups
+    of the emit kernel (phase B): lists must stay bit-exact with screen-filling splats mixed in (consecutive in depth, as
+    close-ups are), with and without the ellipse culling."""
+    d = _dev()
+    W, H = 640, 400                              # 40 x 25 tiles
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([W, H])
+    radii = torch.randint(1, 40, (n,), generator=g, dtype=torch.int32)
+    depths = torch.rand(n, generator=g) * 5 + 1
+    near = torch.argsort(depths)[:150]           # the 150 nearest splats are huge
+    radii[near] = torch.randint(140, 900, (150,), generator=g, dtype=torch.int32)
+    _, _, flat_ref, offs_ref = O.isect_tiles(mode, xy, radii, depths, W, H)
+    flat, offs = hip.bin_gaussians(xy.to(d), depths.to(d), radii.to(d), H, W, 16, mode=mode)
+    assert np.array_equal(flat.cpu().numpy(), flat_ref) and np.array_equal(offs.cpu().numpy(), offs_ref)
+    # with culling: isotropic conics sized so that the alpha >= 1/255 ellipse is well inside the 3-sigma radius
+    sig = radii.float() / 3.0
+    conics = torch.stack([1 / sig ** 2, torch.zeros(n), 1 / sig ** 2], 1)
+    opac = torch.full((n,), 0.9)
+    flat_c, offs_c = hip.bin_gaussians(xy.to(d), depths.to(d), radii.to(d), H, W, 16, mode=mode, conics=conics.to(d), opacities=opac.to(d))
+    full = set(zip(np.repeat(np.arange(offs_ref.size), np.diff(np.append(offs_ref, flat_ref.size))).tolist(), flat_ref.tolist()))
+    fc, oc = flat_c.cpu().numpy(), offs_c.cpu().numpy()
+    culled = list(zip(np.repeat(np.arange(oc.size), np.diff(np.append(oc, fc.size))).tolist(), fc.tolist()))
+    assert 0 < len(culled) < len(full) and set(culled) <= full          # a subset of the rect lists, tile by tile
+    # depth order inside every tile is kept
+    dn = depths.numpy()
+    for t in range(0, oc.size, 97):
+        seg = fc[oc[t]:(oc[t + 1] if t + 1 < oc.size else fc.size)]
+        assert np.all(np.diff(dn[seg]) >= 0)
+
+
+@pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
 def test_tile_culling_is_lossless(hip, mode):
     """Exact ellipse-vs-tile culling in the list-only binning path: shorter lists, every tile's list an
     order-preserving subsequence of the un-culled one, bit-identical image, same gradients."""
