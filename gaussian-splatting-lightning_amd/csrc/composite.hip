@@ -113,6 +113,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 static constexpr int FCHUNK = 64;
 static constexpr int FLIST = FCHUNK + 2;      // room for the odd-count padding entry
 
+#ifdef GSPL_COUNT_PAIRS
+// instrumentation build only (tools/micro/pair_stats.py).  Backward: [0] half-tile candidates, [1] valid pixel pairs, [2] candidates
+// with any valid pixel, [3] ... touching both quadrants.  Forward: [4] staging rounds (64 list entries each, per quadrant wave),
+// [5] candidates that passed the box test, [6] two-candidate iterations executed.
+__device__ unsigned long long g_pair_stats[8];
+#endif
+
 template <int D, int MODE, bool CHW>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
@@ -168,6 +175,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             }
             const unsigned long long mask = __ballot(cand);
             const int ncand = __builtin_popcountll(mask);
+#ifdef GSPL_COUNT_PAIRS
+            if (l == 0) { atomicAdd(&g_pair_stats[4], 1ull); atomicAdd(&g_pair_stats[5], (unsigned long long)ncand); }
+#endif
             if (ncand == 0) continue;
             // compaction: candidate k of the round goes to slot k (k = number of candidates in lower lanes)
             const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -214,6 +224,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
                     last = contrib ? pos[e] : last;
                     done = done || stop;
                 }
+#ifdef GSPL_COUNT_PAIRS
+                if (l == 0) atomicAdd(&g_pair_stats[6], 1ull);
+#endif
                 if (__all(done)) { all_done = true; break; }
             }
             if (all_done) break;
@@ -595,9 +608,6 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
 // Pixels that do not take a splat (alpha < 1/255, behind their last contributor, outside the image) run with
 // alpha = 0, which leaves T, R and the emitted (fac, sp) exactly neutral (1/(1-0) = 1), so no exec masking is needed.
 // Phase 2: lane = (slot s of P2_SLOTS, column c of the half tile's 16), 8 rows per lane, row_sum (16-lane DPP) finish.
-#ifdef GSPL_COUNT_PAIRS
-__device__ unsigned long long g_pair_stats[4];      // instrumentation build only: candidates, valid pixel pairs, candidates with any valid pixel
-#endif
 #ifndef GSPL_BWD2_CHUNK
 #define GSPL_BWD2_CHUNK 64
 #endif
@@ -1150,12 +1160,12 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
 }
 
 #ifdef GSPL_COUNT_PAIRS
-// instrumentation build only: copy (and optionally reset) the pair counters of composite_bwd2_kernel
-extern "C" int gspl_debug_pair_stats(unsigned long long* out4, int reset) {
+// instrumentation build only: copy (and optionally reset) the counters of the compositing kernels
+extern "C" int gspl_debug_pair_stats(unsigned long long* out8, int reset) {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(gspl::g_pair_stats), 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(gspl::g_pair_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     if (reset) {
-        unsigned long long z[4] = {0, 0, 0, 0};
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(gspl::g_pair_stats), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
