@@ -528,9 +528,11 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
     w.keys_off = take(4 * n); w.ids_off = take(4 * n); w.keys2_off = take(4 * n);
     w.counts_off = take(4 * n);
     w.scan_tmp_bytes = scan_tmp; w.scan_tmp_off = take(scan_tmp);
-    // depth sort: own one-sweep sort (gspl_sort.h) up to 2^30-1 splats, rocPRIM beyond
+    // depth sort: own one-sweep sort (gspl_sort.h) or rocPRIM
     RadixPlan dp;
-    w.own_depth_sort = radix_plan(n, 0, 32, 8, RADIX_TILE_U32, dp);
+    // own sort + scan while all tiles fit the device at once (~1 M splats); beyond, tiles would be drawn from a counter and the
+    // library's larger tiles win (measured at 6 M splats: 137 us per pass and a 132 us scan against ~100 and ~50)
+    w.own_depth_sort = radix_plan(n, 0, 32, 8, RADIX_TILE_U32, dp) && radix_sort_u32_is_single_wave_of_tiles(n);
 #ifdef GSPL_ROCPRIM_DEPTH_SORT
     w.own_depth_sort = false;
 #endif

@@ -365,6 +365,12 @@ static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const k
     return GSPL_OK;
 }
 
+bool radix_sort_u32_is_single_wave_of_tiles(size_t n) {
+    static unsigned safe = 0;
+    if (safe == 0) safe = resident_blocks(radix_pass_kernel<uint32_t, true, RADIX_TILE_U32 / RS_THREADS, false>, true);
+    return (n + RADIX_TILE_U32 - 1) / RADIX_TILE_U32 <= safe && !getenv("GSPL_SORT_FORCE_TICKET");
+}
+
 int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
     return radix_sort_impl<uint32_t, RADIX_TILE_U32 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream);
 }

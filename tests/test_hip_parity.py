@@ -270,6 +270,26 @@ def test_binning_big_splats(hip, mode):
         assert np.all(np.diff(dn[seg]) >= 0)
 
 
+def test_binning_above_one_million_splats(hip):
+    """Above ~1 M splats the depth sort and the scan of the counts run on the library path (binning.hip: plan_bin); big splats
+    are then listed by their own small kernel.  The two-level lists must equal those of the independent 64-bit (tile | depth)
+    sort behind `isect_tiles` (itself checked against the oracle at small sizes)."""
+    d = _dev()
+    W, H = 640, 400
+    n = 1_200_000
+    g = torch.Generator().manual_seed(8)
+    xy = (torch.rand(n, 2, generator=g) * torch.tensor([W, H])).to(d)
+    radii = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
+    radii[:50] = torch.randint(150, 700, (50,), generator=g, dtype=torch.int32)      # a few screen-filling ones
+    radii = radii.to(d)
+    depths = (torch.rand(n, generator=g) * 9 + 0.5).to(d)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    _, ids, flat_ref = hip.isect_tiles(xy[None], radii[None], depths[None], 16, tw, th)
+    offs_ref = hip.isect_offset_encode(ids, 1, tw, th).reshape(-1)
+    flat, offs = hip.bin_gaussians(xy, depths, radii, H, W, 16)
+    assert torch.equal(flat, flat_ref) and torch.equal(offs, offs_ref)
+
+
 @pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
 def test_tile_culling_is_lossless(hip, mode):
     """Exact ellipse-vs-tile culling in the list-only binning path: shorter lists, every tile's list an
