@@ -327,6 +327,52 @@ def test_tile_culling_is_lossless(hip, mode):
     assert np.abs(out1.cpu().numpy() - out_ref)[frag == 0].max() <= 1e-5
 
 
+@pytest.mark.parametrize("seed,wh", [(1, (640, 400)), (2, (333, 211)), (3, (1000, 48)), (4, (48, 700))])
+def test_culling_is_lossless_with_every_span_class(hip, seed, wh):
+    """The emit kernel has three classes of splats — up to 8 tile rows (one span record), 9-16 rows (extension record) and
+    taller or very wide ones (ranked by the scan, emitted in phase B) — and anisotropic, rotated footprints exercise the
+    per-row column spans.  Whatever the mix: un-culled lists bit-exact against the oracle, culled lists order-preserving
+    subsequences, and compositing the culled lists gives the bit-identical image."""
+    W, H = wh
+    d = _dev()
+    g = torch.Generator().manual_seed(seed)
+    n = 3000
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([W * 1.2, H * 1.2]) - torch.tensor([W * 0.1, H * 0.1])      # some off-screen centres
+    # standard deviations along the principal axes (pixels) from three scales, random orientation
+    cls = torch.randint(0, 3, (n,), generator=g)
+    s_major = torch.where(cls == 0, torch.rand(n, generator=g) * 12 + 0.5, torch.where(cls == 1, torch.rand(n, generator=g) * 30 + 25,
+                                                                                            torch.rand(n, generator=g) * 250 + 60))
+    s_minor = s_major * (torch.rand(n, generator=g) * 0.9 + 0.1)
+    th = torch.rand(n, generator=g) * 3.14159
+    cx, sx = torch.cos(th), torch.sin(th)
+    cov_a = cx * cx * s_major ** 2 + sx * sx * s_minor ** 2
+    cov_b = cx * sx * (s_major ** 2 - s_minor ** 2)
+    cov_c = sx * sx * s_major ** 2 + cx * cx * s_minor ** 2
+    det = cov_a * cov_c - cov_b * cov_b
+    conics = torch.stack([cov_c / det, -cov_b / det, cov_a / det], 1)
+    radii = torch.ceil(3 * s_major).to(torch.int32)
+    depths = torch.rand(n, generator=g) * 8 + 0.2
+    opac = torch.rand(n, generator=g) * 0.98 + 0.01
+    colors = torch.rand(n, 3, generator=g)
+    _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, xy, radii, depths, W, H)
+    c = lambda t: t.contiguous().to(d)
+    flat0, offs0 = hip.bin_gaussians(c(xy), c(depths), c(radii), H, W, 16)
+    assert np.array_equal(flat0.cpu().numpy(), flat_ref) and np.array_equal(offs0.cpu().numpy(), offs_ref)
+    flat1, offs1 = hip.bin_gaussians(c(xy), c(depths), c(radii), H, W, 16, conics=c(conics), opacities=c(opac))
+    assert flat1.numel() < flat0.numel()
+    f0, f1, o0, o1 = flat0.cpu().numpy(), flat1.cpu().numpy(), offs0.cpu().numpy(), offs1.cpu().numpy()
+    nt = o0.shape[0]
+    for t in range(nt):
+        a = f0[o0[t]:(o0[t + 1] if t + 1 < nt else len(f0))]
+        b = f1[o1[t]:(o1[t + 1] if t + 1 < nt else len(f1))]
+        it = iter(a.tolist())
+        assert all(any(x == y for y in it) for x in b.tolist()), "culled list is not a subsequence"
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    out0, a0, T0, l0 = hip_composite_fwd(O.MODE_GSPLAT, c(xy), c(conics), c(colors), c(opac), c(bg), W, H, offs0, flat0)
+    out1, a1, T1, l1 = hip_composite_fwd(O.MODE_GSPLAT, c(xy), c(conics), c(colors), c(opac), c(bg), W, H, offs1, flat1)
+    assert torch.equal(out0, out1) and torch.equal(T0, T1)
+
+
 def test_binning_empty_inputs(hip):
     d = _dev()
     tiles, ids, flat = hip.isect_tiles(torch.zeros(1, 7, 2, device=d), torch.zeros(1, 7, dtype=torch.int32, device=d),
