@@ -327,8 +327,9 @@ def test_tile_culling_is_lossless(hip, mode):
     assert np.abs(out1.cpu().numpy() - out_ref)[frag == 0].max() <= 1e-5
 
 
+@pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
 @pytest.mark.parametrize("seed,wh", [(1, (640, 400)), (2, (333, 211)), (3, (1000, 48)), (4, (48, 700))])
-def test_culling_is_lossless_with_every_span_class(hip, seed, wh):
+def test_culling_is_lossless_with_every_span_class(hip, seed, wh, mode):
     """The emit kernel has three classes of splats — up to 8 tile rows (one span record), 9-16 rows (extension record) and
     taller or very wide ones (ranked by the scan, emitted in phase B) — and anisotropic, rotated footprints exercise the
     per-row column spans.  Whatever the mix: un-culled lists bit-exact against the oracle, culled lists order-preserving
@@ -354,11 +355,11 @@ def test_culling_is_lossless_with_every_span_class(hip, seed, wh):
     depths = torch.rand(n, generator=g) * 8 + 0.2
     opac = torch.rand(n, generator=g) * 0.98 + 0.01
     colors = torch.rand(n, 3, generator=g)
-    _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, xy, radii, depths, W, H)
+    _, _, flat_ref, offs_ref = O.isect_tiles(mode, xy, radii, depths, W, H)
     c = lambda t: t.contiguous().to(d)
-    flat0, offs0 = hip.bin_gaussians(c(xy), c(depths), c(radii), H, W, 16)
+    flat0, offs0 = hip.bin_gaussians(c(xy), c(depths), c(radii), H, W, 16, mode=mode)
     assert np.array_equal(flat0.cpu().numpy(), flat_ref) and np.array_equal(offs0.cpu().numpy(), offs_ref)
-    flat1, offs1 = hip.bin_gaussians(c(xy), c(depths), c(radii), H, W, 16, conics=c(conics), opacities=c(opac))
+    flat1, offs1 = hip.bin_gaussians(c(xy), c(depths), c(radii), H, W, 16, mode=mode, conics=c(conics), opacities=c(opac))
     assert flat1.numel() < flat0.numel()
     f0, f1, o0, o1 = flat0.cpu().numpy(), flat1.cpu().numpy(), offs0.cpu().numpy(), offs1.cpu().numpy()
     nt = o0.shape[0]
@@ -368,8 +369,8 @@ def test_culling_is_lossless_with_every_span_class(hip, seed, wh):
         it = iter(a.tolist())
         assert all(any(x == y for y in it) for x in b.tolist()), "culled list is not a subsequence"
     bg = torch.tensor([0.1, 0.2, 0.3])
-    out0, a0, T0, l0 = hip_composite_fwd(O.MODE_GSPLAT, c(xy), c(conics), c(colors), c(opac), c(bg), W, H, offs0, flat0)
-    out1, a1, T1, l1 = hip_composite_fwd(O.MODE_GSPLAT, c(xy), c(conics), c(colors), c(opac), c(bg), W, H, offs1, flat1)
+    out0, a0, T0, l0 = hip_composite_fwd(mode, c(xy), c(conics), c(colors), c(opac), c(bg), W, H, offs0, flat0)
+    out1, a1, T1, l1 = hip_composite_fwd(mode, c(xy), c(conics), c(colors), c(opac), c(bg), W, H, offs1, flat1)
     assert torch.equal(out0, out1) and torch.equal(T0, T1)
 
 
