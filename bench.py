@@ -124,8 +124,8 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
             pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, 16, conics=conics, opacities=opac)
             rgbs = ops.sh_view_colors(3, m, center, c, None, radii > 0)
             img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
-                                          isects=ops.bin_gaussians_end(pending))
-            loss = loss_fn(img.permute(2, 0, 1))
+                                          isects=ops.bin_gaussians_end(pending), channels_first=True)
+            loss = loss_fn(img)
             if marks is not None:
                 marks.append(_mark())
             loss.backward()

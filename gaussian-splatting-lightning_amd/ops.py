@@ -454,16 +454,18 @@ def _composite(means2d, conics, colors, opacities, backgrounds, width, height, t
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
                         image_width: int, image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
                         backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
-                        absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+                        absgrad: bool = False, channels_first: bool = False) -> Tuple[Tensor, Tensor]:
     """gsplat signature as the reference calls it (gsplat_v1_renderer.py:588-601): means2d [N,2] (or [1,N,2]),
     conics [1,N,3], colors [1,N,D], opacities [1,N], isect_offsets [1,th,tw], backgrounds [1,D].
-    Returns (colors [1,H,W,D], alphas [1,H,W,1]).  With absgrad=True, backward sets `means2d.absgrad`."""
+    Returns (colors [1,H,W,D], alphas [1,H,W,1]).  With absgrad=True, backward sets `means2d.absgrad`.
+    channels_first (extension): colors come out as [1,D,H,W] straight from the kernel (see `rasterize_gaussians`)."""
     if packed or masks is not None:
         raise NotImplementedError("packed / masks are not used by the reference")
     m2 = means2d if means2d.dim() == 2 else means2d.squeeze(0)
     out, alphas = _composite(m2, conics.reshape(-1, 3), colors.reshape(-1, colors.shape[-1]), opacities.reshape(-1),
                              None if backgrounds is None else backgrounds.reshape(-1), image_width, image_height, tile_size,
-                             isect_offsets.reshape(-1), flatten_ids, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_HWC)
+                             isect_offsets.reshape(-1), flatten_ids, absgrad, L.GSPL_MODE_GSPLAT,
+                             L.GSPL_LAYOUT_CHW if channels_first else L.GSPL_LAYOUT_HWC)
     if absgrad and m2 is not means2d:
         raise ValueError("absgrad needs means2d given as [N,2] so that .absgrad lands on the caller's tensor")
     return out[None], alphas[None, ..., None]
@@ -665,15 +667,17 @@ def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, i
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
                         colors: Tensor, opacity: Tensor, img_height: int, img_width: int, block_width: int,
                         background: Optional[Tensor] = None, return_alpha: bool = False, absgrad: bool = False,
-                        isects=None):
+                        isects=None, channels_first: bool = False):
     """gsplat-v0 signature (reference call: gsplat_renderer.py:86-99): bins + composites in one call.
-    colors [N,D], opacity [N,1] -> [H,W,D] (and alpha [H,W] when return_alpha)."""
+    colors [N,D], opacity [N,1] -> [H,W,D] (and alpha [H,W] when return_alpha).
+    channels_first (extension): the image comes out as [D,H,W] straight from the kernel — what the reference builds with
+    `.permute(2, 0, 1)` and every consumer (loss, metrics) then has to make contiguous, forward and backward."""
     if block_width != 16:
         raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
     flat, offsets = isects if isects is not None else bin_gaussians(xys, depths, radii, img_height, img_width, block_width,
                                                                     conics=conics, opacities=opacity)
     out, alphas = _composite(xys, conics, colors, opacity.reshape(-1), background, img_width, img_height, block_width,
-                             offsets, flat, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_HWC)
+                             offsets, flat, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_CHW if channels_first else L.GSPL_LAYOUT_HWC)
     return (out, alphas) if return_alpha else out
 
 

@@ -94,19 +94,23 @@ class HipGSplatRenderer(Renderer):
         pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, self.block_size, conics=conics, opacities=opacities)
         isects = None
 
-        def rasterize(feats, background, return_alpha=False, opac=opacities, absgrad=False):
+        def rasterize(feats, background, return_alpha=False, opac=opacities, absgrad=False, channels_first=False):
             nonlocal isects
             if isects is None:
                 isects = ops.bin_gaussians_end(pending)
             return ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, feats, opac, img_height=H, img_width=W,
                                            block_width=self.block_size, background=background, return_alpha=return_alpha,
-                                           absgrad=absgrad, isects=isects if opac is opacities else None)
+                                           absgrad=absgrad, isects=isects if opac is opacities else None,
+                                           channels_first=channels_first)
 
+        visible = radii > 0
         rgb = None
         if self.is_type_required(bits, self._RGB_REQUIRED):
             rgbs = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center, pc.get_features, None,
-                                      radii > 0, detach_means=True)
-            rgb = rasterize(rgbs, bg_color, absgrad=getattr(self, "absgrad", False)).permute(2, 0, 1)
+                                      visible, detach_means=True)
+            # [3,H,W] straight from the kernel: the reference permutes an [H,W,3] image, which costs the loss a 25 MB copy in
+            # the forward and another one for the incoming gradient in the backward
+            rgb = rasterize(rgbs, bg_color, absgrad=getattr(self, "absgrad", False), channels_first=True)
 
         alpha = acc_depth_im = acc_depth_inverted_im = exp_depth_im = exp_depth_inverted_im = None
         if self.is_type_required(bits, self._ACC_DEPTH_REQUIRED):
@@ -142,7 +146,7 @@ class HipGSplatRenderer(Renderer):
             "hard_depth": hard_depth_im, "hard_inverse_depth": hard_inverse_depth_im,
             "viewspace_points": xys,
             "viewspace_points_grad_scale": viewspace_grad_scale(W, H, xys),
-            "visibility_filter": radii > 0,
+            "visibility_filter": visible,
             "radii": radii,
         }
 

@@ -140,10 +140,10 @@ class HipGSplatV1RendererModule(Renderer):
         projection_for_rasterization = radii, means2d, depths, conics, compensations
         zero1 = torch.zeros((1,), dtype=torch.float, device=bg_color.device)
 
-        def rasterize(input_features, background, return_alpha=False, opac=opacities, absgrad=True):
+        def rasterize(input_features, background, return_alpha=False, opac=opacities, absgrad=True, channels_first=False):
             c, a = GSplatV1.rasterize(preprocessed_camera, projection_for_rasterization, isects, opacities=opac,
                                       colors=input_features, background=background, tile_size=self.config.block_size,
-                                      absgrad=absgrad)
+                                      absgrad=absgrad, channels_first=channels_first)
             return (c, a.squeeze(0).squeeze(-1)) if return_alpha else c
 
         outputs = {
@@ -180,8 +180,9 @@ class HipGSplatV1RendererModule(Renderer):
         if n > 0:
             f = feats[0] if len(feats) == 1 else torch.concat(feats, dim=-1)
             b = bgs[0] if len(bgs) == 1 else torch.concat(bgs, dim=-1)
-            render_features, render_alpha = rasterize(f, background=b, return_alpha=True)
-            render_features = render_features.permute(2, 0, 1)
+            # [D,H,W] straight from the kernel (the reference permutes an [H,W,D] image: every consumer of "render" would then
+            # copy it to make it contiguous, forward and backward); the per-type outputs are contiguous channel slices
+            render_features, render_alpha = rasterize(f, background=b, return_alpha=True, channels_first=True)
             render_alpha = render_alpha.unsqueeze(0)
             for k, (s, e) in index.items():
                 outputs[k] = render_features[s:e]
