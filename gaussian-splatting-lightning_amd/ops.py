@@ -237,7 +237,8 @@ class _SHFn(torch.autograd.Function):
             raise ValueError(f"degree {degree} needs {(degree + 1) ** 2} coefficients, got {n_coeffs}")
         mask8 = None
         if masks is not None:
-            mask8 = masks.to(torch.uint8).contiguous()
+            # a bool mask is reinterpreted, not converted (a conversion is one more launch per frame)
+            mask8 = masks.contiguous().view(torch.uint8) if masks.dtype == torch.bool else masks.to(torch.uint8).contiguous()
         colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev) if (flags & L.GSPL_SH_ADD_HALF_CLAMP) else None
         L.call("gspl_sh_fwd", N, int(degree), L.ptr(dirs), L.ptr(origin), L.ptr(dc), dc_stride, rest_ptr, rest_stride,

@@ -24,9 +24,18 @@ DEFAULT_ANTI_ALIASED_STATUS: bool = True
 
 def _project(means3D, scales, rotations, viewpoint_camera, scaling_modifier, block_size, W, H, kernel_size=0.3, **extra):
     kernel_size = extra.pop("filter_2d_kernel_size", kernel_size)
+    # the full, contiguous 4x4 world->camera matrix, built once per camera object (the reference hands the kernel a [3,4]
+    # transposed view per frame; completing and copying it is a launch per frame)
+    vm = getattr(viewpoint_camera, "_gspl_viewmat", None)
+    if vm is None or vm.device != means3D.device:
+        vm = viewpoint_camera.world_to_camera.T.to(device=means3D.device, dtype=torch.float32).contiguous()
+        try:
+            viewpoint_camera._gspl_viewmat = vm
+        except Exception:      # a frozen camera type: no cache
+            pass
     return ops.project_gaussians(
         means3d=means3D, scales=scales, glob_scale=scaling_modifier, quats=rotations,
-        viewmat=viewpoint_camera.world_to_camera.T[:3, :],
+        viewmat=vm,
         fx=viewpoint_camera.fx, fy=viewpoint_camera.fy, cx=viewpoint_camera.cx, cy=viewpoint_camera.cy,
         img_height=H, img_width=W, block_width=block_size, filter_2d_kernel_size=kernel_size, **extra)
 
