@@ -230,8 +230,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
         const uint32_t next_tile = TICKET ? s_tile : ntiles;        // (no ticket: one tile per workgroup)
         load_tile(next_tile, key_next, val_next);                   // in flight during the look-back and the write-out
         // ---- 4: look-back ------------------------------------------------------------------------------------------------
-        // The resident workgroups run in near lock-step, so a tile's predecessors are mostly LOCAL and a tile-by-tile walk
-        // would cover ~grid/2 of them.  The last tile of every RS_GROUP tiles (the "closer") also publishes the group's
+        // All tiles of a co-resident grid start together, so a tile's predecessors are mostly LOCAL and a tile-by-tile walk
+        // would cover ~tile/2 of them.  The last tile of every RS_GROUP tiles (the "closer") also publishes the group's
         // aggregate; a walk crosses its own group tile by tile and everything older group by group.
         if (t < nd) {
             uint32_t excl = 0u;
@@ -294,7 +294,8 @@ bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_i
     return true;
 }
 
-// Grid bound of the persistent pass kernels: workgroups the device is SURE to keep resident at once.  The occupancy API
+// Workgroups of a kernel the device is SURE to keep resident at once (certain = true; the bound of the one-tile-per-workgroup
+// launches) or is expected to (certain = false; the grid of the ticketed launches, where an overestimate is harmless).  The occupancy API
 // is exact for most shapes (tools/micro/residency_probe.hip) but a kernel sitting on a register-file boundary (64 VGPRs =
 // "8 waves per SIMD") was observed to get one wave per SIMD less than promised, and a grid that is not co-resident
 // dead-locks the look-back: one workgroup per CU is taken off the promise (never below one per CU, which always fits).
