@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -49,6 +49,8 @@ _SIGNATURES = {
                                  _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "gspl_sh_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),
+    "gspl_sh_fwd_batched": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
+    "gspl_sh_bwd_batched": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
     "gspl_isect_workspace_bytes": (c_size_t, [c_int, c_int64]),
     "gspl_isect_count": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "gspl_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),

@@ -654,7 +654,15 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     const float hx0 = (float)tx + TR::kPixelCentre;                 // centre of the half tile's first column
     const float hy0 = (float)(ty + w * 8) + TR::kPixelCentre;       // ... and first row
     const int64_t pixA = (int64_t)py * width + pxA, pixB = pixA + 8;
+#ifdef GSPL_BWD2_SWZ
+    // slab of one slot: rows 0-3 of column c at floats [4c, 4c+4), rows 4-7 at [64 + 4c, ...): the 16 lanes of a phase-2 slot
+    // read 16 consecutive 16-byte words per ds_read_b128 (conflict-free), phase 1 writes 64 distinct dwords per instruction
+    const int tl = ((l >> 3) >> 2) * 64 + (l & 7) * 4 + ((l >> 3) & 3);      // pixel A (B: + 32)
+    constexpr int TLB = 32;
+#else
     const int tl = (l & 7) * 8 + (l >> 3);             // pixel A's place in the column-major slab (B: + 64)
+    constexpr int TLB = 64;
+#endif
     const int ps = l >> 4, pc = l & 15;                // phase-2 role: splat slot, column of the half tile
     float* slab = s_slab + w * SLAB;
 
@@ -718,9 +726,15 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
             const float dx = r0.x - (hx0 + (float)pc);
             const float dy0 = r0.y - hy0;
             const v2f dy0v = {dy0, dy0};
+#ifdef GSPL_BWD2_SWZ
+            const float4* Fp = reinterpret_cast<const float4*>(slab + ps * 128 + pc * 4);
+            const float4* Sp = reinterpret_cast<const float4*>(slab + P2_SLOTS * 128 + ps * 128 + pc * 4);
+            const float4 f0 = Fp[0], f1 = Fp[16], q0 = Sp[0], q1 = Sp[16];
+#else
             const float4* Fp = reinterpret_cast<const float4*>(slab + ps * 128 + pc * 8);
             const float4* Sp = reinterpret_cast<const float4*>(slab + P2_SLOTS * 128 + ps * 128 + pc * 8);
             const float4 f0 = Fp[0], f1 = Fp[1], q0 = Sp[0], q1 = Sp[1];
+#endif
             const v2f F2[4] = {{f0.x, f0.y}, {f0.z, f0.w}, {f1.x, f1.y}, {f1.z, f1.w}};
             const v2f S2[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
             v2f s02 = {0.f, 0.f}, sy2 = {0.f, 0.f}, syy2 = {0.f, 0.f};
@@ -763,11 +777,13 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         // Reduction over the 16 lanes of the slot in two halves: first inside each quad, for all NV values; then lane q of
         // every quad keeps only the values k = q (mod 4) and those are summed across the four quads (row_ror 4, 8 keep
         // q), so that the lanes of quad 0 end up owning values q, q+4, q+8, ... and add them to the tile's LDS totals.
+#ifndef GSPL_ABL_NOREDUCE     // ablation builds only (timing without the first two reduction levels; results are wrong)
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             vals[k] = dpp_add<0xB1, 0xF>(vals[k]);    // quad_perm [1,0,3,2]
             vals[k] = dpp_add<0x4E, 0xF>(vals[k]);    // quad_perm [2,3,0,1]
         }
+#endif
         constexpr int NK = (NV + 3) / 4;
         const int pq = pc & 3;
         float kept[NK];
@@ -853,7 +869,13 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     // would put an LDS round trip into every candidate's critical path), reported at the flush
                     if (hit_flags && l == 0) atomicOr(&s_id[j], (int)0x80000000);
                     const v2f rv2 = {validA ? raw2.x : 0.f, validB ? raw2.y : 0.f};
+#ifdef GSPL_BWD2_FMED3
+                    // rv >= 0: the median of (rv, 0, alpha_max) is min(alpha_max, rv) in ONE instruction (fminf costs a
+                    // canonicalising v_max in front of the v_min because the select above hides that rv is already quiet)
+                    const v2f a2 = {__builtin_amdgcn_fmed3f(rv2.x, 0.f, TR::kAlphaMax), __builtin_amdgcn_fmed3f(rv2.y, 0.f, TR::kAlphaMax)};
+#else
                     const v2f a2 = {fminf(TR::kAlphaMax, rv2.x), fminf(TR::kAlphaMax, rv2.y)};
+#endif
                     v2f rw2 = rv2;     // o * vis where the pixel takes a gradient through alpha, else 0
                     if (TR::kClampKillsGrad) rw2 = (v2f){(rv2.x <= TR::kAlphaMax) ? rv2.x : 0.f, (rv2.y <= TR::kAlphaMax) ? rv2.y : 0.f};
                     const v2f om2 = (v2f){1.f, 1.f} - a2;
@@ -867,8 +889,8 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     R2 = __builtin_elementwise_fma(-cdot2, fac2, R2);
                     const v2f sp2 = -rw2 * v_alpha2;
                     float* F = slab + nb * 128 + tl;
-                    F[0] = fac2.x; F[64] = fac2.y;
-                    F[P2_SLOTS * 128] = sp2.x; F[P2_SLOTS * 128 + 64] = sp2.y;
+                    F[0] = fac2.x; F[TLB] = fac2.y;
+                    F[P2_SLOTS * 128] = sp2.x; F[P2_SLOTS * 128 + TLB] = sp2.y;
                     batch_j = gspl_writelane_i32(j, nb, batch_j);
                     if (++nb == P2_SLOTS) { phase2(P2_SLOTS); nb = 0; }
                 }

@@ -36,11 +36,11 @@ inline int check_hip(hipError_t e, const char* where) {
 
 // internal launchers shared between translation units (sh.hip -> inria.hip)
 namespace gspl {
-int sh_fwd_launch(int N, int degree, const float* dirs, const float* origin,
+int sh_fwd_launch(int N, int C, int degree, const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags,
                   float* colors, uint8_t* clamped, void* stream);
-int sh_bwd_launch(int N, int degree, int n_coeffs, const float* dirs, const float* origin,
+int sh_bwd_launch(int N, int C, int degree, int n_coeffs, const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream);

@@ -243,7 +243,7 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
         return check_launch("inria_preprocess_fwd(colors_precomp)");
     }
     const int stride = 3 * n_coeffs;
-    return sh_fwd_launch(N, degree, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
+    return sh_fwd_launch(N, 1, degree, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
                          GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream);
 }
 
@@ -276,7 +276,7 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
         if (degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("inria_preprocess_bwd: bad degree / n_coeffs");
         const int stride = 3 * n_coeffs;
         // dL/d(dir) lands in v_means; the geometry kernel accumulates on top
-        int rc = sh_bwd_launch(N, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
+        int rc = sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
                                GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream);
         if (rc != GSPL_OK) return rc;
         accum = true;

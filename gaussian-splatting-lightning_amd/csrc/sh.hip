@@ -170,9 +170,12 @@ struct ShTile {
     int merged;   // 1: dc inside the tile at col 0, rest at col 3
 };
 
+// C cameras per launch (C > 1: the Gaussian-sharded renderer evaluates its shard for every rank's camera,
+// gsplat_distributed_renderer.py:252-311): the coefficient rows are staged ONCE and evaluated against C origins; origin,
+// mask, mask32, colors and clamped are then arrays of C consecutive per-camera blocks.
 template <int DEG>
 __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(
-    int N,
+    int N, int C,
     const float* __restrict__ dirs, const float* __restrict__ origin,
     const float* __restrict__ dc, int dc_stride, const float* __restrict__ rest,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ mask32, int flags, ShTile tile, int vec_ok,
@@ -190,45 +193,49 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(
     const int r = threadIdx.x;
     if (r >= rows) return;
     const int n = n0 + r;
-    float out[3] = {0.f, 0.f, 0.f};
-    uint8_t cl[3] = {0, 0, 0};
-    const bool live = ((mask == nullptr) || (mask[n] != 0)) && ((mask32 == nullptr) || (mask32[n] > 0));
-    if (live) {
-        float dx = dirs[n * 3 + 0], dy = dirs[n * 3 + 1], dz = dirs[n * 3 + 2];
-        if (origin) { dx -= origin[0]; dy -= origin[1]; dz -= origin[2]; }
-        const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
-        dx *= inv; dy *= inv; dz *= inv;
-        float b[K];
-        sh_basis(degree, dx, dy, dz, b);
-        const float* d0 = (tile.merged && degree > 0) ? (lds + r * tile.ls) : (dc + (int64_t)n * dc_stride);
+    const float px = dirs[n * 3 + 0], py = dirs[n * 3 + 1], pz = dirs[n * 3 + 2];
+    for (int cam = 0; cam < C; ++cam) {
+        const int64_t cn = (int64_t)cam * N + n;
+        float out[3] = {0.f, 0.f, 0.f};
+        uint8_t cl[3] = {0, 0, 0};
+        const bool live = ((mask == nullptr) || (mask[cn] != 0)) && ((mask32 == nullptr) || (mask32[cn] > 0));
+        if (live) {
+            float dx = px, dy = py, dz = pz;
+            if (origin) { dx -= origin[cam * 3 + 0]; dy -= origin[cam * 3 + 1]; dz -= origin[cam * 3 + 2]; }
+            const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+            dx *= inv; dy *= inv; dz *= inv;
+            float b[K];
+            sh_basis(degree, dx, dy, dz, b);
+            const float* d0 = (tile.merged && degree > 0) ? (lds + r * tile.ls) : (dc + (int64_t)n * dc_stride);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out[c] = b[0] * d0[c];
-        const float* row = lds + r * tile.ls + (tile.merged ? 3 : 0);
+            for (int c = 0; c < 3; ++c) out[c] = b[0] * d0[c];
+            const float* row = lds + r * tile.ls + (tile.merged ? 3 : 0);
 #pragma unroll
-        for (int k = 1; k < K; ++k) {
+            for (int k = 1; k < K; ++k) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) out[c] += b[k] * row[(k - 1) * 3 + c];
-        }
-        if (flags & GSPL_SH_ADD_HALF_CLAMP) {
+                for (int c = 0; c < 3; ++c) out[c] += b[k] * row[(k - 1) * 3 + c];
+            }
+            if (flags & GSPL_SH_ADD_HALF_CLAMP) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                out[c] += 0.5f;
-                if (out[c] < 0.f) { out[c] = 0.f; cl[c] = 1; }
+                for (int c = 0; c < 3; ++c) {
+                    out[c] += 0.5f;
+                    if (out[c] < 0.f) { out[c] = 0.f; cl[c] = 1; }
+                }
             }
         }
-    }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) colors[n * 3 + c] = out[c];
-    if (clamped) {
+        for (int c = 0; c < 3; ++c) colors[cn * 3 + c] = out[c];
+        if (clamped) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) clamped[n * 3 + c] = cl[c];
+            for (int c = 0; c < 3; ++c) clamped[cn * 3 + c] = cl[c];
+        }
     }
 }
 
 // WITH_DIRS: also produce v_dirs (needs the coefficients -> stages them first).
 template <int DEG, bool WITH_DIRS>
 __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
-    int N, int n_coeffs,
+    int N, int C, int n_coeffs,
     const float* __restrict__ dirs, const float* __restrict__ origin,
     const float* __restrict__ dc, int dc_stride, const float* __restrict__ rest,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ mask32, int flags, const uint8_t* __restrict__ clamped,
@@ -249,23 +256,28 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < K; ++k) b[k] = 0.f;
     bool live = false;
-    if (r < rows) {
-        live = ((mask == nullptr) || (mask[n] != 0)) && ((mask32 == nullptr) || (mask32[n] > 0));
+    // camera `cam`: masked / clamp-masked colour gradient and the basis of the view direction
+    auto load_camera = [&](int cam) {
+        const int64_t cn = (int64_t)cam * N + n;
+        live = ((mask == nullptr) || (mask[cn] != 0)) && ((mask32 == nullptr) || (mask32[cn] > 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vc[c] = 0.f;
         if (live) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                vc[c] = v_colors[(int64_t)n * vc_stride + c];
-                if ((flags & GSPL_SH_ADD_HALF_CLAMP) && clamped && clamped[n * 3 + c]) vc[c] = 0.f;
+                vc[c] = v_colors[cn * vc_stride + c];
+                if ((flags & GSPL_SH_ADD_HALF_CLAMP) && clamped && clamped[cn * 3 + c]) vc[c] = 0.f;
             }
             dx = dirs[n * 3 + 0]; dy = dirs[n * 3 + 1]; dz = dirs[n * 3 + 2];
-            if (origin) { dx -= origin[0]; dy -= origin[1]; dz -= origin[2]; }
+            if (origin) { dx -= origin[cam * 3 + 0]; dy -= origin[cam * 3 + 1]; dz -= origin[cam * 3 + 2]; }
             inv = rsqrtf(dx * dx + dy * dy + dz * dz);
             dx *= inv; dy *= inv; dz *= inv;
             sh_basis(degree, dx, dy, dz, b);
         }
-    }
+    };
+    if (r < rows) load_camera(0);
 
-    if (WITH_DIRS) {
+    if (WITH_DIRS) {      // one camera only (checked by the launcher)
         if (degree > 0) {
             const float* base = tile.merged ? dc + (int64_t)n0 * tile.rs : rest + (int64_t)n0 * tile.rs;
             tile_load(base, rows, tile.rs, tile.ls, 1.f / (float)tile.rs, lds, vec_ok_in != 0);
@@ -291,18 +303,14 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
         __syncthreads();   // everyone is done reading the staged coefficients
     }
 
-    // coefficient gradients: write own row into LDS, then one flat coalesced store
+    // coefficient gradients: write own row into LDS (summed over the cameras), then one flat coalesced store
     if (r < rows) {
         float d0[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) d0[c] = live ? b[0] * vc[c] : 0.f;
+        float* row = lds + r * tile.ls;
+        const int col0 = (has_tile && tile.merged) ? 3 : 0;
         if (has_tile) {
-            float* row = lds + r * tile.ls;
-            int col0 = 0;
-            if (tile.merged) {
-                row[0] = d0[0]; row[1] = d0[1]; row[2] = d0[2];
-                col0 = 3;
-            }
 #pragma unroll
             for (int k = 1; k < K; ++k) {
                 const float bk = live ? b[k] : 0.f;
@@ -313,6 +321,20 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
             // zero any padding columns between the used row length and the global row stride
             for (int j = col0 + (n_coeffs - 1) * 3; j < tile.rs; ++j) row[j] = 0.f;
         }
+        for (int cam = 1; cam < C; ++cam) {
+            load_camera(cam);
+            if (!live) continue;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d0[c] += b[0] * vc[c];
+            if (has_tile) {
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) row[col0 + (k - 1) * 3 + c] += b[k] * vc[c];
+                }
+            }
+        }
+        if (has_tile && tile.merged) { row[0] = d0[0]; row[1] = d0[1]; row[2] = d0[2]; }
         if (!tile.merged || !has_tile) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) v_dc[(int64_t)n * dc_stride + c] = d0[c];
@@ -330,12 +352,13 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 }  // namespace gspl
 
 namespace gspl {
-int sh_fwd_launch(int N, int degree,
+int sh_fwd_launch(int N, int C, int degree,
                   const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags,
                   float* colors, uint8_t* clamped, void* stream) {
-    if (N < 0 || degree < 0 || degree > 4) return fail_arg("sh_fwd: bad N/degree");
+    if (N < 0 || C < 1 || degree < 0 || degree > 4) return fail_arg("sh_fwd: bad N/C/degree");
+    if (C > 1 && !origin) return fail_arg("sh_fwd: several cameras need their origins");
     if (N == 0) return GSPL_OK;
     if (!dirs || !dc || !colors || (degree > 0 && !rest)) return fail_arg("sh_fwd: NULL required pointer");
     ShTile tile;
@@ -356,7 +379,7 @@ int sh_fwd_launch(int N, int degree,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
             if (e != hipSuccess) return check_hip(e, "sh_fwd: hipFuncSetAttribute");                                  \
         }                                                                                                             \
-        hipLaunchKernelGGL(sh_fwd_kernel<DEG>, dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, dirs,   \
+        hipLaunchKernelGGL(sh_fwd_kernel<DEG>, dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, C, dirs, \
                            origin, dc, dc_stride, rest, mask, mask32, flags, tile, vec_ok, colors, clamped);          \
     } break;
     switch (degree) { GSPL_SH_FWD(0) GSPL_SH_FWD(1) GSPL_SH_FWD(2) GSPL_SH_FWD(3) GSPL_SH_FWD(4) }
@@ -370,17 +393,28 @@ extern "C" int gspl_sh_fwd(int N, int degree,
                            const float* dc, int dc_stride, const float* rest, int rest_stride,
                            const uint8_t* mask, int flags,
                            float* colors, uint8_t* clamped, void* stream) {
-    return gspl::sh_fwd_launch(N, degree, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, colors, clamped, stream);
+    return gspl::sh_fwd_launch(N, 1, degree, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, colors, clamped, stream);
+}
+
+// C cameras in one launch: origins [C,3], radii [C,N] (radius > 0 = evaluate; may be NULL), colors [C,N,3], clamped [C,N,3].
+// The coefficient rows are read once for all cameras.
+extern "C" int gspl_sh_fwd_batched(int C, int N, int degree,
+                                   const float* means, const float* origins,
+                                   const float* dc, int dc_stride, const float* rest, int rest_stride,
+                                   const int32_t* radii, int flags,
+                                   float* colors, uint8_t* clamped, void* stream) {
+    return gspl::sh_fwd_launch(N, C, degree, means, origins, dc, dc_stride, rest, rest_stride, nullptr, radii, flags, colors, clamped, stream);
 }
 
 namespace gspl {
-int sh_bwd_launch(int N, int degree, int n_coeffs,
+int sh_bwd_launch(int N, int C, int degree, int n_coeffs,
                   const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride,
                   float* v_dc, float* v_rest, float* v_dirs, void* stream) {
-    if (N < 0 || degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("sh_bwd: bad N/degree/n_coeffs");
+    if (N < 0 || C < 1 || degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("sh_bwd: bad N/C/degree/n_coeffs");
+    if (C > 1 && (v_dirs || !origin)) return fail_arg("sh_bwd: several cameras need their origins and give no direction gradient");
     if (N == 0) return GSPL_OK;
     if (!dirs || !v_colors || !v_dc || (n_coeffs > 1 && !v_rest)) return fail_arg("sh_bwd: NULL required pointer");
     if (v_dirs && (!dc || (degree > 0 && !rest))) return fail_arg("sh_bwd: v_dirs needs the coefficients");
@@ -409,7 +443,7 @@ int sh_bwd_launch(int N, int degree, int n_coeffs,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
             if (e != hipSuccess) return check_hip(e, "sh_bwd: hipFuncSetAttribute");                                  \
         }                                                                                                             \
-        hipLaunchKernelGGL((sh_bwd_kernel<DEG, WD>), dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N,   \
+        hipLaunchKernelGGL((sh_bwd_kernel<DEG, WD>), dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, C, \
                            n_coeffs, dirs, origin, dc, dc_stride, rest, mask, mask32, flags, clamped, v_colors, vc_stride, tile, vec_in, \
                            vec_out, v_dc, v_rest, v_dirs);                                                            \
     }
@@ -429,6 +463,16 @@ extern "C" int gspl_sh_bwd(int N, int degree, int n_coeffs,
                            const uint8_t* mask, int flags, const uint8_t* clamped,
                            const float* v_colors, int v_colors_stride,
                            float* v_dc, float* v_rest, float* v_dirs, void* stream) {
-    return gspl::sh_bwd_launch(N, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors,
+    return gspl::sh_bwd_launch(N, 1, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors,
                                v_colors_stride > 0 ? v_colors_stride : 3, v_dc, v_rest, v_dirs, stream);
+}
+
+// Backward of gspl_sh_fwd_batched: v_colors [C,N,3] (dense) -> v_dc / v_rest summed over the cameras, written once.
+extern "C" int gspl_sh_bwd_batched(int C, int N, int degree, int n_coeffs,
+                                   const float* means, const float* origins,
+                                   int dc_stride, int rest_stride,
+                                   const int32_t* radii, int flags, const uint8_t* clamped,
+                                   const float* v_colors, float* v_dc, float* v_rest, void* stream) {
+    return gspl::sh_bwd_launch(N, C, degree, n_coeffs, means, origins, nullptr, dc_stride, nullptr, rest_stride, nullptr, radii, flags, clamped,
+                               v_colors, 3, v_dc, v_rest, nullptr, stream);
 }

@@ -1,6 +1,6 @@
 """
 distributed.py — multi-GPU plumbing of the rasterizer path (one process per GPU, `torch.distributed`;
-backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests and in the shared-GPU debugging mode).
 
 Two modes:
 
@@ -9,18 +9,21 @@ Two modes:
    and the visible splats travel to the rank that renders that camera.  Where the reference sends two
    messages per peer (a float [n,11] and an int [n] tensor, :195-202), this sends ONE packed 48-byte record
    per splat — xy(2) depth(1) conic(3) compensation(1) opacity(1) rgb(3) radius(1, int32 bits) — through a single
-   autograd-aware `all_to_all_single` with split sizes; the backward pass is the reverse all-to-all of the same
+   autograd-aware all-to-all with split sizes; the backward pass is the reverse all-to-all of the same
    records' gradients.  On the MI355X full mesh each peer message rides its own xGMI link.
-2. Replicated Gaussians, cameras sharded (BASELINE.json north_star wording; what bench.py --gpus N runs):
-   only the densification statistics are all-reduced (`reduce_densification_stats`).
+2. Replicated Gaussians, cameras sharded (BASELINE.json north_star wording; `configs/ddp.yaml` in the reference):
+   parameter gradients are all-reduced every step (`all_reduce_gradients`), the densification statistics when a
+   densification consumes them (`reduce_densification_stats`).
+
+Backends: with RCCL the collectives take device tensors.  Any other backend (gloo: no GPU all-to-all) gets the
+same calls with the payload staged through host memory — slow, but it lets two processes share one GPU for tests.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
-import torch.distributed.nn.functional as dist_fn
 
 RECORD_FLOATS = 12     # 48 B per visible splat
 
@@ -31,6 +34,65 @@ def shard_bounds(n_gaussians: int, world_size: int, rank: int) -> Tuple[int, int
     lo = per * rank
     hi = n_gaussians if rank + 1 == world_size else lo + per
     return lo, hi
+
+
+def is_rccl(group=None) -> bool:
+    return dist.get_backend(group) == "nccl"
+
+
+def _staged(t: torch.Tensor, group) -> bool:
+    """Does `t` have to travel through host memory for this group's backend?"""
+    return t.is_cuda and not is_rccl(group)
+
+
+def _wire(t: torch.Tensor, group) -> torch.Tensor:
+    return t.cpu() if _staged(t, group) else t
+
+
+def gather_ints(value: int, device, group=None) -> List[int]:
+    """One integer per rank, in rank order (camera ids, Gaussian counts: gsplat_distributed_renderer.py:319-323,426)."""
+    world = dist.get_world_size(group)
+    wire_dev = device if (is_rccl(group) or torch.device(device).type == "cpu") else "cpu"
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=wire_dev)
+    out = torch.empty((world,), dtype=torch.int64, device=wire_dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return [int(v) for v in out.tolist()]
+
+
+def exchange_counts(send_counts: Sequence[int], device, group=None) -> List[int]:
+    """send_counts[j] = rows this rank sends to rank j -> rows it receives from each rank."""
+    wire_dev = device if (is_rccl(group) or torch.device(device).type == "cpu") else "cpu"
+    send = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=wire_dev)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return [int(v) for v in recv.tolist()]
+
+
+def _all_to_all_rows_raw(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group) -> torch.Tensor:
+    send = send.contiguous()
+    wire = _wire(send, group)
+    out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=wire.device)
+    dist.all_to_all_single(out, wire, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+    return out.to(send.device) if out.device != send.device else out
+
+
+class _AllToAllRows(torch.autograd.Function):
+    """Rows grouped by destination rank -> rows grouped by source rank; the backward is the reverse route."""
+
+    @staticmethod
+    def forward(ctx, send, send_counts, recv_counts, group):
+        ctx.route = (list(send_counts), list(recv_counts), group)
+        return _all_to_all_rows_raw(send, list(send_counts), list(recv_counts), group)
+
+    @staticmethod
+    def backward(ctx, v_out):
+        send_counts, recv_counts, group = ctx.route
+        return _all_to_all_rows_raw(v_out, recv_counts, send_counts, group), None, None, None
+
+
+def all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts: Sequence[int], group=None) -> torch.Tensor:
+    """Differentiable variable-size all-to-all of the rows of `send` ([sum(send_counts), ...], grouped by destination)."""
+    return _AllToAllRows.apply(send, list(send_counts), list(recv_counts), group)
 
 
 def pack_visible(radii, means2d, depths, conics, compensations, opacities, rgbs, visibility) -> torch.Tensor:
@@ -44,7 +106,7 @@ def pack_visible(radii, means2d, depths, conics, compensations, opacities, rgbs,
 def unpack_records(rec: torch.Tensor):
     """-> radii i32 [n], means2d [n,2], depths [n], conics [n,3], compensations [n], opacities [n,1], rgbs [n,3]"""
     means2d, depths, conics, comp, opac, rgbs, rbits = torch.split(rec, [2, 1, 3, 1, 1, 3, 1], dim=-1)
-    radii = rbits.detach().contiguous().view(torch.int32).squeeze(-1)
+    radii = rbits.detach().to(torch.float32).contiguous().view(torch.int32).squeeze(-1)     # (fp64 records in the CPU tests: exact)
     return radii, means2d, depths.squeeze(-1), conics, comp.squeeze(-1), opac, rgbs
 
 
@@ -54,15 +116,10 @@ def exchange_visible_splats(records_per_camera: Sequence[torch.Tensor], group=No
     world = dist.get_world_size(group)
     assert len(records_per_camera) == world
     dev = records_per_camera[0].device
-    send_counts = torch.tensor([r.shape[0] for r in records_per_camera], dtype=torch.int64, device=dev)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    recv_list = [int(v) for v in recv_counts.tolist()]
     send_list = [int(r.shape[0]) for r in records_per_camera]
-    send = torch.cat(list(records_per_camera), dim=0).contiguous()
-    out = torch.empty((sum(recv_list), RECORD_FLOATS), dtype=send.dtype, device=dev)
-    out = dist_fn.all_to_all_single(out, send, output_split_sizes=recv_list, input_split_sizes=send_list, group=group)
-    return out, recv_list
+    recv_list = exchange_counts(send_list, dev, group)
+    send = torch.cat(list(records_per_camera), dim=0)
+    return all_to_all_rows(send, send_list, recv_list, group), recv_list
 
 
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor, group=None):
@@ -75,17 +132,30 @@ def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Te
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
 
 
-def redistribute_rows(local: torch.Tensor, destination: torch.Tensor, group=None) -> torch.Tensor:
+def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bool = True) -> None:
+    """Replicated-Gaussian mode: sum (or average) `p.grad` of every parameter over the ranks, in place — what DDP does for
+    the reference's `configs/ddp.yaml`.  One collective per parameter tensor (five or six large tensors: each is its own
+    bucket), all in flight before the first wait, so RCCL pipelines them over the xGMI links."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in grads]
+    for w in works:
+        w.wait()
+    if average:
+        torch._foreach_mul_(grads, 1.0 / world)
+
+
+def redistribute_rows(local: torch.Tensor, destination: torch.Tensor, group=None, recv_counts: Optional[List[int]] = None) -> torch.Tensor:
     """Move row i of `local` to rank destination[i] (random rebalancing, gsplat_distributed_renderer.py:440-510):
-    one all_to_all_single per tensor with rows grouped by destination."""
+    one all-to-all per tensor with rows grouped by destination (rows keep their relative order per source)."""
     world = dist.get_world_size(group)
     order = torch.argsort(destination, stable=True)
-    send_counts = torch.bincount(destination, minlength=world).to(torch.int64)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    send = local[order].contiguous()
-    flat = send.reshape(send.shape[0], -1)
-    recv_list, send_list = [int(v) for v in recv_counts.tolist()], [int(v) for v in send_counts.tolist()]
-    out = torch.empty((sum(recv_list), flat.shape[1]), dtype=flat.dtype, device=flat.device)
-    dist.all_to_all_single(out, flat, output_split_sizes=recv_list, input_split_sizes=send_list, group=group)
-    return out.reshape((out.shape[0],) + tuple(local.shape[1:]))
+    send_list = [int(v) for v in torch.bincount(destination, minlength=world).tolist()]
+    if recv_counts is None:
+        recv_counts = exchange_counts(send_list, local.device, group)
+    send = local.detach()[order].contiguous()
+    return _all_to_all_rows_raw(send, send_list, list(recv_counts), group)

@@ -293,6 +293,66 @@ def sh_view_colors(degree: int, means: Tensor, camera_center: Tensor, dc: Tensor
     return _SHFn.apply(degree, m, camera_center, dc, rest, masks, L.GSPL_SH_ADD_HALF_CLAMP)
 
 
+class _SHBatchedFn(torch.autograd.Function):
+    """clamp(SH(means - origins[c]) + 0.5, 0) for C cameras in one launch (`gspl_sh_fwd_batched`): the coefficient rows are
+    read once for all cameras; the backward sums the coefficient gradients over the cameras and writes them once."""
+
+    @staticmethod
+    def forward(ctx, degree, means, origins, dc, rest, radii):
+        means, origins, dc, rest = _f32c(means), _f32c(origins), _f32c(dc), _f32c(rest)
+        C, N = origins.shape[0], means.shape[0]
+        dev = means.device
+        merged = rest is None
+        if merged:
+            K = dc.shape[1]
+            dc_stride = rest_stride = 3 * K
+            rest_ptr = L.ptr(dc, offset_bytes=12) if K > 1 else None
+            n_coeffs = K
+        else:
+            assert dc.shape[1] == 1
+            dc_stride, rest_stride = 3, 3 * rest.shape[1]
+            rest_ptr = L.ptr(rest) if rest.shape[1] > 0 else None
+            n_coeffs = 1 + rest.shape[1]
+        if (degree + 1) ** 2 > n_coeffs:
+            raise ValueError(f"degree {degree} needs {(degree + 1) ** 2} coefficients, got {n_coeffs}")
+        radii = None if radii is None else radii.to(torch.int32).contiguous()
+        colors = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((C, N, 3), dtype=torch.uint8, device=dev)
+        if N > 0:
+            with torch.cuda.device(dev):
+                L.call("gspl_sh_fwd_batched", C, N, int(degree), L.ptr(means), L.ptr(origins), L.ptr(dc), dc_stride, rest_ptr, rest_stride,
+                       L.ptr(radii), L.GSPL_SH_ADD_HALF_CLAMP, L.ptr(colors), L.ptr(clamped), L.stream())
+        ctx.save_for_backward(means, origins, dc, rest, radii, clamped)
+        ctx.cfg = (int(degree), merged, n_coeffs, dc_stride, rest_stride)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        means, origins, dc, rest, radii, clamped = ctx.saved_tensors
+        degree, merged, n_coeffs, dc_stride, rest_stride = ctx.cfg
+        C, N = origins.shape[0], means.shape[0]
+        v_colors = _f32c(v_colors)
+        v_dc = torch.empty_like(dc)
+        if merged:
+            v_rest = None
+            v_rest_ptr = L.ptr(v_dc, offset_bytes=12) if n_coeffs > 1 else None
+        else:
+            v_rest = torch.empty_like(rest)
+            v_rest_ptr = L.ptr(v_rest) if n_coeffs > 1 else None
+        if N > 0:
+            with torch.cuda.device(means.device):
+                L.call("gspl_sh_bwd_batched", C, N, degree, n_coeffs, L.ptr(means), L.ptr(origins), dc_stride, rest_stride,
+                       L.ptr(radii), L.GSPL_SH_ADD_HALF_CLAMP, L.ptr(clamped), L.ptr(v_colors), L.ptr(v_dc), v_rest_ptr, L.stream())
+        return None, None, None, v_dc, v_rest, None
+
+
+def sh_view_colors_batched(degree: int, means: Tensor, camera_centers: Tensor, dc: Tensor, rest: Optional[Tensor],
+                           radii: Optional[Tensor] = None) -> Tensor:
+    """`sh_view_colors` for C cameras at once: camera_centers [C,3], radii [C,N] (rows with radius <= 0 are skipped)
+    -> colours [C,N,3].  Means are detached (as gsplat_distributed_renderer.py:417 does)."""
+    return _SHBatchedFn.apply(degree, means.detach(), camera_centers, dc, rest, radii)
+
+
 # =============================================================================================
 # tile binning
 # =============================================================================================

@@ -4,16 +4,18 @@
 Per step, on each of W ranks (one process per GPU, MPStrategy = RCCL on ROCm):
   1. all_gather the W camera ids                                   (reference :319-323)
   2. project THIS rank's shard for all W cameras in ONE batched launch (`fully_fused_projection`, C = W) and
-     evaluate SH colours per camera for the visible splats           (reference :252-311)
+     evaluate the SH colours of all W cameras in ONE launch that reads the coefficients once (reference :252-311)
   3. ONE packed 48-B-record all-to-all (`distributed.exchange_visible_splats`; the reference sends a float and
      an int message, :195-202), autograd-aware: backward is the reverse all-to-all
-  4. bin + composite the received splats for the local camera        (reference :356-389)
+  4. bin (list-only two-level binning, optional tile-based culling) + composite the received splats for the local
+     camera                                                         (reference :356-389)
 Outputs follow the reference (:407-414): `render`, `cameras`, `projection_results_list`, `visible_mask_list`,
 `xys_grad_scale_required` — what `DistributedVanillaDensityControllerImpl` consumes.
 Random redistribution (:432-510) uses one all_to_all_single per tensor (`distributed.redistribute_rows`).
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional
 
@@ -22,6 +24,7 @@ import torch.distributed as dist
 
 from .. import distributed as D
 from .. import ops
+from ..optim_utils import replace_tensors_to_properties
 from .hip_gsplat_v1_renderer import GSplatV1
 from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw
 
@@ -37,55 +40,94 @@ class HipGSplatDistributedRenderer(RendererConfig):
     redistribute_threshold: float = 1.1
 
     def instantiate(self, *args, **kwargs) -> Renderer:
-        if self.tile_based_culling:
-            raise NotImplementedError("tile_based_culling is not built yet")
         return HipGSplatDistributedRendererImpl(self)
 
 
+class _Range:
+    """Profiler span: the Lightning profiler's `profile(name)` when the trainer has one (as the reference,
+    gsplat_distributed_renderer.py:316-379) and a roctx range (torch.cuda.nvtx = roctx on ROCm) for rocprofv3 --marker-trace."""
+
+    def __init__(self, profiler, name):
+        self.name = name
+        self.ctx = profiler.profile(name) if profiler is not None else contextlib.nullcontext()
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        torch.cuda.nvtx.range_pop()
+        return self.ctx.__exit__(*exc)
+
+
 class HipGSplatDistributedRendererImpl(Renderer):
+    profile_prefix = "[Renderer]GSplatDistributedRenderer."
+
     def __init__(self, config: HipGSplatDistributedRenderer) -> None:
         super().__init__()
         self.config = config
+        # the rasterizer consumes (flatten_ids, isect_offsets) only: the list-only two-level binning builds exactly the lists of
+        # isect_tiles + isect_offset_encode (bit-identical, tests/test_hip_parity.py) without 64-bit keys; with
+        # tile_based_culling (configs/distributed-accel.yaml; reference :54-55) tile hits that cannot reach alpha >= 1/255 are dropped
+        self.isect_encode = GSplatV1.isect_encode_lists_only
+        if config.tile_based_culling:
+            self.isect_encode = GSplatV1.isect_encode_tile_based_culling
         self.world_size = 1
         self.global_rank = 0
+        self.group = None
+        self.batched = True                                                   # one projection + one SH launch for all W cameras
         self.camera_lookup: Optional[Callable[[int, bool], object]] = None   # (camera idx, training) -> Camera
         self.on_density_changed = lambda: None
+        self.profiler = None
+
+    def _span(self, name):
+        return _Range(self.profiler, self.profile_prefix + name)
 
     # ---- setup: shard the Gaussians (reference :63-118) -------------------------------------------------
     def training_setup(self, module):
         self.world_size = module.trainer.world_size
         self.global_rank = module.trainer.global_rank
         lo, hi = D.shard_bounds(module.gaussian_model.n_gaussians, self.world_size, self.global_rank)
-        from internal.density_controllers.density_controller import Utils as DensityControllerUtils  # reference helper
         new_tensors = {k: v[lo:hi] for k, v in module.gaussian_model.properties.items()}
-        module.gaussian_model.properties = DensityControllerUtils.replace_tensors_to_properties(new_tensors, module.gaussian_optimizers)
+        module.gaussian_model.properties = replace_tensors_to_properties(new_tensors, module.gaussian_optimizers)
         self.on_density_changed = module.density_updated_by_renderer
         self.on_density_changed()
+        self.profiler = getattr(module.trainer, "profiler", None)
 
         def lookup(idx: int, training: bool):
             loader = module.trainer.train_dataloader if training else module.trainer.val_dataloaders
             return loader.dataset.image_cameras[idx]
 
         self.camera_lookup = lookup
+        # batched projection needs one image size for every camera (reference :104-116)
+        try:
+            outputs = module.trainer.datamodule.dataparser_outputs
+            for cams in (outputs.train_set.cameras, outputs.val_set.cameras):
+                if cams.width.unique().shape[0] + cams.height.unique().shape[0] != 2:
+                    self.batched = False
+                    break
+        except AttributeError:
+            pass
         return None, None
 
     # ---- forward -----------------------------------------------------------------------------------------
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
     def gather_cameras(self, viewpoint_camera):
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        if world == 1:
+        if self._world() == 1:
             return [viewpoint_camera]
-        ids = torch.empty(world, dtype=torch.int, device=viewpoint_camera.device)
-        dist.all_gather_into_tensor(ids, viewpoint_camera.idx.to(torch.int).reshape(1))
         cams = []
-        for i in ids.tolist():
-            cam = self.camera_lookup(int(i), self.training)
+        for i in D.gather_ints(int(viewpoint_camera.idx), viewpoint_camera.device, self.group):
+            cam = self.camera_lookup(i, self.training)
             if cam.device != viewpoint_camera.device:
                 cam.to_device(viewpoint_camera.device)
             cams.append(cam)
         return cams
 
     def batch_project(self, cameras, pc, scales, scaling_modifier):
-        """One launch for all W cameras (the kernel is per (camera, splat); reference :252-283)."""
+        """ONE projection launch and ONE SH launch for all W cameras (reference :252-311 loops over the cameras for the SH
+        colours; here the coefficient rows are read once)."""
         viewmats = torch.stack([c.world_to_camera.T for c in cameras])
         Ks = torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, scales.device) for c in cameras])
         W, H = camera_hw(cameras[0])
@@ -94,11 +136,24 @@ class HipGSplatDistributedRendererImpl(Renderer):
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(
             pc.get_means(), None, pc.get_rotations(), scales, viewmats=viewmats, Ks=Ks, width=W, height=H,
             eps2d=self.config.filter_2d_kernel_size, calc_compensations=True, packed=False)
+        centers = torch.stack([c.camera_center for c in cameras])
+        rgbs = ops.sh_view_colors_batched(pc.active_sh_degree, pc.get_xyz, centers, pc.get_shs_dc(), pc.get_shs_rest(), radii)
+        vis = radii > 0
+        results = [(radii[i], means2d[i], depths[i], conics[i], comps[i], vis[i]) for i in range(len(cameras))]
+        return results, [rgbs[i] for i in range(len(cameras))]
+
+    def non_batch_project(self, cameras, pc, scales, scaling_modifier):
+        """Cameras of different sizes: one projection and one SH launch per camera (reference :238-250)."""
+        if scaling_modifier != 1.:
+            scales = scales * scaling_modifier
         results, rgbs = [], []
-        for i, cam in enumerate(cameras):
-            vis = radii[i] > 0
-            results.append((radii[i], means2d[i], depths[i], conics[i], comps[i], vis))
-            rgbs.append(self.get_rgbs(pc, cam, vis))
+        for cam in cameras:
+            radii, means2d, depths, conics, comps = GSplatV1.project(
+                GSplatV1.preprocess_camera(cam), means3d=pc.get_means(), scales=scales, quats=pc.get_rotations(),
+                eps2d=self.config.filter_2d_kernel_size, anti_aliased=True)
+            r = (radii[0], means2d[0], depths[0], conics[0], comps[0], radii[0] > 0)
+            results.append(r)
+            rgbs.append(self.get_rgbs(pc, cam, r[-1]))
         return results, rgbs
 
     def get_rgbs(self, pc, camera, visibility):
@@ -107,40 +162,46 @@ class HipGSplatDistributedRendererImpl(Renderer):
     def forward(self, viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, render_types: list = None, **kwargs):
         if render_types is None:
             render_types = ["rgb"]
-        cameras = self.gather_cameras(viewpoint_camera)
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        scales, opacities = pc.get_scales(), pc.get_opacities()
-        projection_results_list, rgb_list = self.batch_project(cameras, pc, scales, scaling_modifier)
-        for r in projection_results_list:
-            if r[1].requires_grad:
-                r[1].retain_grad()              # per-camera xys: what the distributed density controller reads
+        with self._span("forward"):
+            with self._span("gather_cameras"):
+                cameras = self.gather_cameras(viewpoint_camera)
+            rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+            scales, opacities = pc.get_scales(), pc.get_opacities()
+            with self._span("project"):
+                project = self.batch_project if self.batched else self.non_batch_project
+                projection_results_list, rgb_list = project(cameras, pc, scales, scaling_modifier)
+            for r in projection_results_list:
+                if r[1].requires_grad:
+                    r[1].retain_grad()              # per-camera xys: what the distributed density controller reads
 
-        records = [D.pack_visible(r[0], r[1], r[2], r[3], r[4], opacities, rgb, r[5]) for r, rgb in zip(projection_results_list, rgb_list)]
-        if len(cameras) > 1:
-            received, _ = D.exchange_visible_splats(records)
-        else:
-            received = records[0]
-        radii, means2d, depths, conics, comps, opac, rgbs = D.unpack_records(received)
-        if self.config.anti_aliased:
-            opac = opac * comps.unsqueeze(-1)
-        opac = opac.squeeze(-1).unsqueeze(0)
+            with self._span("rasterizer_required_data_all2all"):
+                records = [D.pack_visible(r[0], r[1], r[2], r[3], r[4], opacities, rgb, r[5])
+                           for r, rgb in zip(projection_results_list, rgb_list)]
+                if len(cameras) > 1:
+                    received, _ = D.exchange_visible_splats(records, self.group)
+                else:
+                    received = records[0]
+                radii, means2d, depths, conics, comps, opac, rgbs = D.unpack_records(received)
+            if self.config.anti_aliased:
+                opac = opac * comps.unsqueeze(-1)
+            opac = opac.squeeze(-1).unsqueeze(0)
 
-        local = cameras[rank]
-        W, H = camera_hw(local)
-        pre = (None, None, (W, H))
-        projections = (radii.unsqueeze(0), means2d, depths.unsqueeze(0), conics.unsqueeze(0), None)
-        isects = GSplatV1.isect_encode(pre, (projections[0], means2d.unsqueeze(0), projections[2], projections[3], None),
-                                       tile_size=self.config.block_size)
-        rgb, _ = GSplatV1.rasterize(pre, projections, isects, opac, colors=rgbs, background=bg_color, tile_size=self.config.block_size,
-                                    absgrad=False)
-        rgb = rgb.permute(2, 0, 1)
-        hard_inverse_depth_im = None
-        if "hard_inverse_depth" in render_types:
-            inverse_depth = 1. / (depths.clamp_min(0.) + 1e-8).unsqueeze(-1)
-            hard_inverse_depth_im, _ = GSplatV1.rasterize(pre, projections, isects, opac + (1 - opac.detach()), colors=inverse_depth,
-                                                          background=torch.zeros((1,), dtype=torch.float, device=bg_color.device),
-                                                          tile_size=self.config.block_size, absgrad=False)
-            hard_inverse_depth_im = hard_inverse_depth_im.permute(2, 0, 1)
+            local = cameras[rank]
+            W, H = camera_hw(local)
+            pre = (None, None, (W, H))
+            projections = (radii.unsqueeze(0), means2d, depths.unsqueeze(0), conics.unsqueeze(0), None)
+            isects = self.isect_encode(pre, (projections[0], means2d.unsqueeze(0), projections[2], projections[3], None),
+                                       opac, tile_size=self.config.block_size)
+            with self._span("rasterize"):
+                # [3,H,W] straight from the kernel (the reference permutes an [H,W,3] image)
+                rgb, _ = GSplatV1.rasterize(pre, projections, isects, opac, colors=rgbs, background=bg_color,
+                                            tile_size=self.config.block_size, absgrad=False, channels_first=True)
+                hard_inverse_depth_im = None
+                if "hard_inverse_depth" in render_types:
+                    inverse_depth = 1. / (depths.clamp_min(0.) + 1e-8).unsqueeze(-1)
+                    hard_inverse_depth_im, _ = GSplatV1.rasterize(pre, projections, isects, opac + (1 - opac.detach()), colors=inverse_depth,
+                                                                  background=torch.zeros((1,), dtype=torch.float, device=bg_color.device),
+                                                                  tile_size=self.config.block_size, absgrad=False, channels_first=True)
         return {
             "render": rgb,
             "hard_inverse_depth": hard_inverse_depth_im,
@@ -155,33 +216,41 @@ class HipGSplatDistributedRendererImpl(Renderer):
         c = self.config
         if c.redistribute_interval < 0 or step >= c.redistribute_until or step % c.redistribute_interval != 0:
             return
+        self.redistribute(module)
+
+    def redistribute(self, module):
         with torch.no_grad():
-            counts = [0 for _ in range(self.world_size)]
-            dist.all_gather_object(counts, module.gaussian_model.get_xyz.shape[0])
-            if min(counts) * c.redistribute_threshold >= max(counts):
+            counts = D.gather_ints(module.gaussian_model.get_xyz.shape[0], module.gaussian_model.get_xyz.device, self.group)
+            if min(counts) * self.config.redistribute_threshold >= max(counts):
                 return
             self.random_redistribute(module)
 
-    def random_redistribute(self, module):
-        n = module.gaussian_model.get_xyz.shape[0]
-        destination = torch.randint(0, self.world_size, (n,), device=module.device)
-        move = lambda t: D.redistribute_rows(t, destination)
+    def random_redistribute(self, module, destination: Optional[torch.Tensor] = None):
+        """Every Gaussian moves to a uniformly random rank; the Adam moments travel with their parameters (reference :440-510)."""
+        xyz = module.gaussian_model.get_xyz
+        n = xyz.shape[0]
+        if destination is None:
+            destination = torch.randint(0, self.world_size, (n,), device=xyz.device)
+        send = [int(v) for v in torch.bincount(destination, minlength=self.world_size).tolist()]
+        recv = D.exchange_counts(send, xyz.device, self.group)
+        move = lambda t: D.redistribute_rows(t, destination, self.group, recv_counts=recv)
         new_tensors = {}
-        for opt in module.gaussian_optimizers:
-            for group in opt.param_groups:
-                assert len(group["params"]) == 1
-                state = opt.state.get(group["params"][0], None)
-                if state is not None:
-                    state["exp_avg"], state["exp_avg_sq"] = move(state["exp_avg"]), move(state["exp_avg_sq"])
-                    del opt.state[group["params"][0]]
-                    group["params"][0] = torch.nn.Parameter(move(group["params"][0]).requires_grad_(True))
-                    opt.state[group["params"][0]] = state
-                else:
-                    group["params"][0] = torch.nn.Parameter(move(group["params"][0]).requires_grad_(True))
-                new_tensors[group["name"]] = group["params"][0]
-        for name in module.gaussian_model.get_property_names():
-            if name not in new_tensors:
-                new_tensors[name] = move(module.gaussian_model.get_property(name))
+        with torch.no_grad():
+            for opt in module.gaussian_optimizers:
+                for group in opt.param_groups:
+                    assert len(group["params"]) == 1
+                    old = group["params"][0]
+                    state = opt.state.get(old, None)
+                    new = torch.nn.Parameter(move(old).requires_grad_(True))
+                    if state is not None:
+                        state["exp_avg"], state["exp_avg_sq"] = move(state["exp_avg"]), move(state["exp_avg_sq"])
+                        del opt.state[old]
+                        opt.state[new] = state
+                    group["params"][0] = new
+                    new_tensors[group["name"]] = new
+            for name in module.gaussian_model.get_property_names():
+                if name not in new_tensors:
+                    new_tensors[name] = move(module.gaussian_model.get_property(name))
         module.gaussian_model.properties = new_tensors
         self.on_density_changed()
 

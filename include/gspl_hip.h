@@ -129,6 +129,24 @@ int gspl_sh_bwd(int N, int degree, int n_coeffs,
                 float* v_dc, float* v_rest, float* v_dirs /*nullable*/,
                 void* stream);
 
+/* C cameras in ONE launch — what the Gaussian-sharded renderer needs per step (every rank evaluates its shard for all W
+ * cameras: gsplat_distributed_renderer.py:252-311,416-421, a Python loop of W SH calls there).  The coefficient rows are
+ * read once for all cameras; colours = clamp(SH(means - origins[c]) + 0.5, 0) with flags = GSPL_SH_ADD_HALF_CLAMP.
+ *    means [N,3]; origins [C,3]; radii [C,N] i32 nullable (rows with radius <= 0 are skipped and get zeros);
+ *    colors [C,N,3]; clamped [C,N,3] u8 (nullable without the clamp flag).
+ * Backward: v_colors [C,N,3] dense -> v_dc / v_rest (same layouts as gspl_sh_bwd) summed over the cameras and written
+ * once; no direction gradient (the reference detaches the means here). */
+int gspl_sh_fwd_batched(int C, int N, int degree,
+                        const float* means, const float* origins,
+                        const float* dc, int dc_stride, const float* rest, int rest_stride,
+                        const int32_t* radii /*nullable*/, int flags,
+                        float* colors, uint8_t* clamped /*nullable*/, void* stream);
+int gspl_sh_bwd_batched(int C, int N, int degree, int n_coeffs,
+                        const float* means, const float* origins,
+                        int dc_stride, int rest_stride,
+                        const int32_t* radii /*nullable*/, int flags, const uint8_t* clamped /*nullable*/,
+                        const float* v_colors, float* v_dc, float* v_rest, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3. Tile binning: (tile, depth) keys, radix sort, per-tile ranges.
  *    Replaces gsplat `isect_tiles` + `isect_offset_encode` (gsplat_v1_renderer.py:446-458) and

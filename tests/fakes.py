@@ -15,8 +15,15 @@ class FakeCamera:
         self.width, self.height = t(cam["width"], torch.int32), t(cam["height"], torch.int32)
         self.fov_x = t(2 * math.atan(cam["tanfovx"]))
         self.fov_y = t(2 * math.atan(cam["tanfovy"]))
-        self.idx = t(0, torch.int32)
+        self.idx = t(int(cam.get("idx", 0)), torch.int32)
         self.device = device
+
+    def to_device(self, device):
+        for k, v in list(vars(self).items()):
+            if isinstance(v, torch.Tensor):
+                setattr(self, k, v.to(device))
+        self.device = device
+        return self
 
 
 class FakeGaussianModel(torch.nn.Module):
@@ -46,3 +53,58 @@ class FakeGaussianModel(torch.nn.Module):
     def get_shs_dc(self): return self.shs_dc
     def get_shs_rest(self): return self.shs_rest
     def leaves(self): return [self.means, self.scales_, self.rotations_, self.opacities_, self.shs_dc, self.shs_rest]
+
+
+class FakePropertyModel(torch.nn.Module):
+    """Model with a `properties` dict the way internal/models/gaussian.py:122-190 keeps one (name -> Parameter), storing
+    activated values; what `training_setup` / `random_redistribute` of the sharded renderer and the density controllers'
+    optimizer surgery operate on."""
+
+    NAMES = ("means", "shs_dc", "shs_rest", "opacities", "scales", "rotations")
+
+    def __init__(self, means, scales, quats, opac, shs, active_sh_degree=3, extra=None):
+        super().__init__()
+        P = torch.nn.Parameter
+        self._props = {"means": P(means), "shs_dc": P(shs[:, :1].contiguous()), "shs_rest": P(shs[:, 1:].contiguous()),
+                       "opacities": P(opac), "scales": P(scales), "rotations": P(quats)}
+        for k, v in (extra or {}).items():
+            self._props[k] = P(v, requires_grad=False)
+        self.active_sh_degree = active_sh_degree
+        self.max_sh_degree = int(math.isqrt(shs.shape[1])) - 1
+        self.is_pre_activated = False
+
+    @property
+    def properties(self):
+        return self._props
+
+    @properties.setter
+    def properties(self, new):
+        self._props = dict(new)
+
+    @property
+    def n_gaussians(self):
+        return self._props["means"].shape[0]
+
+    def get_property_names(self):
+        return tuple(self._props.keys())
+
+    def get_property(self, name):
+        return self._props[name]
+
+    get_xyz = property(lambda s: s._props["means"])
+    get_scaling = property(lambda s: s._props["scales"])
+    get_rotation = property(lambda s: s._props["rotations"])
+    get_opacity = property(lambda s: s._props["opacities"])
+    get_features = property(lambda s: torch.cat((s._props["shs_dc"], s._props["shs_rest"]), dim=1))
+
+    def get_means(self): return self._props["means"]
+    def get_scales(self): return self._props["scales"]
+    def get_rotations(self): return self._props["rotations"]
+    def get_opacities(self): return self._props["opacities"]
+    def get_shs_dc(self): return self._props["shs_dc"]
+    def get_shs_rest(self): return self._props["shs_rest"]
+
+    def named_optimizer(self, lrs=None, cls=torch.optim.Adam, **kw):
+        lrs = lrs or {}
+        groups = [{"params": [self._props[n]], "lr": lrs.get(n, 1e-3), "name": n} for n in self.NAMES]
+        return cls(groups, **kw)

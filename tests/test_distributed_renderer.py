@@ -1,0 +1,290 @@
+"""The Gaussian-sharded renderer end to end with two ranks (reference: internal/renderers/gsplat_distributed_renderer.py).
+
+Two processes shard a seeded scene with `shard_bounds`, each renders its own camera through
+`HipGSplatDistributedRendererImpl.forward` (batched projection + batched SH, packed all-to-all, list-only binning,
+compositing) and back-propagates its own image loss.  Checked against the one-process result on the full model:
+the render of each rank's camera, the gradient of EVERY parameter row of the shard (= gradient of the sum of both losses),
+and the per-camera screen-space gradients the distributed density controller reads.  Then `training_setup` (sharding with
+optimizer surgery) and `random_redistribute` (Adam moments must follow their parameters).
+
+  * `-m gpu`     : both processes share cuda:0 (gloo, payload staged through the host — RCCL refuses two ranks on one
+                   device); every op is the HIP op; the one-process reference is `HipGSplatV1Renderer`.
+  * `-m "not gpu"`: CPU processes; the HIP ops are replaced IN THIS TEST by the fp64 oracle stages, so the renderer's
+                   host logic, the exchange and its autograd route run without a GPU; reference = `oracle.render_gsplat`.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N_SPLATS, W_IMG, H_IMG = 3000, 208, 144
+
+
+def _cameras():
+    from oracle import gsplat_oracle as O
+    cams = []
+    for i, (t, f) in enumerate((((0.0, 0.0, 4.0), 190.0), ((0.35, -0.2, 3.4), 205.0))):
+        cam = O.synthetic_camera(W_IMG, H_IMG, f, f + 3.0)
+        w2c = cam["world_to_camera"].clone()
+        w2c[3, :3] = torch.tensor(t)
+        cam["world_to_camera"] = w2c
+        cam["camera_center"] = torch.linalg.inv(w2c)[3, :3]
+        cam["idx"] = i
+        cams.append(cam)
+    return cams
+
+
+def _scene(dtype):
+    from oracle import gsplat_oracle as O
+    means, scales, quats, opac, shs = O.synthetic_scene(N_SPLATS, seed=77)
+    scales = scales * 5
+    return [t.to(dtype) for t in (means, scales, quats, opac, shs)]
+
+
+def _weights(dtype):
+    g = torch.Generator().manual_seed(3)
+    return [torch.randn(3, H_IMG, W_IMG, generator=g).to(dtype) for _ in range(2)]
+
+
+def _install_oracle_ops():
+    """CPU variant: route the op entry points the sharded renderer uses to the oracle stages (test only)."""
+    from oracle import gsplat_oracle as O
+    from gspl_amd import ops
+
+    def fully_fused_projection(means, covars, quats, scales, viewmats, Ks, width, height, eps2d=0.3, calc_compensations=False,
+                               packed=False, **kw):
+        outs = []
+        for c in range(viewmats.shape[0]):
+            K = Ks[c]
+            xys, depths, radii, conics, comp, _, _, _, _, _ = O.project_gaussians(
+                means, scales, 1.0, quats, viewmats[c].T, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
+                int(height), int(width), eps2d=eps2d)
+            outs.append((radii, xys, depths, conics, comp))
+        return tuple(torch.stack([o[i] for o in outs]) for i in range(5))
+
+    def sh_view_colors_batched(degree, means, centers, dc, rest, radii=None):
+        coeffs = torch.cat([dc, rest], dim=1)
+        cols = []
+        for c in range(centers.shape[0]):
+            rgb = O.sh_colors(degree, coeffs, means, centers[c], detach_dirs=True)
+            if radii is not None:
+                rgb = torch.where((radii[c] > 0)[:, None], rgb, torch.zeros((), dtype=rgb.dtype))
+            cols.append(rgb)
+        return torch.stack(cols)
+
+    def bin_gaussians(xys, depths, radii, img_height, img_width, block_width=16, mode=0, conics=None, opacities=None):
+        _, _, flat, offs = O.isect_tiles(O.MODE_GSPLAT, xys.detach(), radii, depths.detach(), img_width, img_height)
+        return torch.from_numpy(np.asarray(flat)), torch.from_numpy(np.asarray(offs))
+
+    def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_height, tile_size, isect_offsets, flatten_ids,
+                            backgrounds=None, absgrad=False, channels_first=False, **kw):
+        out, alpha = O.composite_c(O.MODE_GSPLAT, means2d.reshape(-1, 2), conics.reshape(-1, 3), colors.reshape(-1, colors.shape[-1]),
+                                   opacities.reshape(-1), backgrounds.reshape(-1), image_width, image_height,
+                                   isect_offsets.reshape(-1).numpy(), flatten_ids.numpy())
+        if channels_first:
+            out = out.permute(2, 0, 1)
+        return out[None], alpha[None, ..., None]
+
+    ops.fully_fused_projection = fully_fused_projection
+    ops.sh_view_colors_batched = sh_view_colors_batched
+    ops.bin_gaussians = bin_gaussians
+    ops.rasterize_to_pixels = rasterize_to_pixels
+
+
+def _reference_full_model(on_gpu, params, cams, weights, bg, dev):
+    """One-process result: every camera rendered from the FULL model, loss = sum over cameras of <render, weight>."""
+    from fakes import FakeCamera, FakeGaussianModel
+    if on_gpu:
+        from gspl_amd.renderers import HipGSplatV1Renderer
+        model = FakeGaussianModel(*[p.clone().to(dev) for p in params])
+        renderer = HipGSplatV1Renderer(anti_aliased=True).instantiate()
+        renders, xy_grads = [], []
+        loss = 0
+        outs = []
+        for cam, w in zip(cams, weights):
+            out = renderer(FakeCamera(cam, dev), model, bg.to(dev))
+            out["viewspace_points"].retain_grad()
+            outs.append(out)
+            loss = loss + (out["render"] * w.to(dev)).sum()
+        loss.backward()
+        grads = [model.means.grad, model.scales_.grad, model.rotations_.grad, model.opacities_.grad, model.shs_dc.grad, model.shs_rest.grad]
+        return [o["render"].detach().cpu() for o in outs], [g.cpu() for g in grads], [o["viewspace_points"].grad.cpu() for o in outs]
+    from oracle import gsplat_oracle as O
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    m, s, q, o, c = leaves
+    loss = 0
+    rs = []
+    for cam, w in zip(cams, weights):
+        r = O.render_gsplat(m, s, q, o, c, 3, cam["world_to_camera"].to(m.dtype), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W_IMG, H_IMG,
+                            bg, cam["camera_center"].to(m.dtype))
+        rs.append(r)
+        loss = loss + (r["render"] * w).sum()
+    loss.backward()
+    grads = [m.grad, s.grad, q.grad, o.grad, c.grad[:, :1], c.grad[:, 1:]]
+    return [r["render"].detach() for r in rs], grads, [r["xys"].grad for r in rs]
+
+
+class _Trainer:
+    def __init__(self, world, rank):
+        self.world_size, self.global_rank = world, rank
+        self.profiler = None
+
+
+class _Module:
+    """What the renderer touches of the LightningModule (gaussian_splatting.py): trainer, gaussian_model,
+    gaussian_optimizers, density_updated_by_renderer, device."""
+
+    def __init__(self, model, optimizers, world, rank, dev):
+        self.trainer, self.gaussian_model, self.gaussian_optimizers, self.device = _Trainer(world, rank), model, optimizers, dev
+        self.density_changes = 0
+
+    def density_updated_by_renderer(self):
+        self.density_changes += 1
+
+
+def _close(got, ref, rel, name):
+    from hip_helpers import assert_close_scaled
+    assert_close_scaled(got.detach().cpu().double().numpy(), ref.detach().cpu().double().numpy(), rel, name, frac_ok=1.0)
+
+
+def _worker(rank, world, port, tmpdir, on_gpu):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (HERE, os.path.dirname(HERE)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gspl_amd  # noqa: F401
+        from gspl_amd import distributed as D
+        from gspl_amd.renderers import HipGSplatDistributedRenderer
+        from fakes import FakeCamera, FakePropertyModel
+        dev = torch.device("cuda:0") if on_gpu else torch.device("cpu")
+        dtype = torch.float32 if on_gpu else torch.float64
+        if not on_gpu:
+            _install_oracle_ops()
+        params = _scene(dtype)
+        cams, weights = _cameras(), _weights(dtype)
+        bg = torch.tensor([0.2, 0.1, 0.4], dtype=dtype)
+        N = params[0].shape[0]
+        lo, hi = D.shard_bounds(N, world, rank)
+
+        # ---- training_setup: the full model is cut down to this rank's rows, optimizer parameters replaced, moments reset
+        ids = torch.arange(N, dtype=torch.float32)
+        model = FakePropertyModel(*[p.clone().to(dev) for p in params], extra={"ids": ids.to(dev)})
+        opt = model.named_optimizer()
+        for g in opt.param_groups:      # give the optimizer a state to reset
+            p = g["params"][0]
+            opt.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.ones_like(p), "exp_avg_sq": torch.ones_like(p)}
+        module = _Module(model, [opt], world, rank, dev)
+        renderer = HipGSplatDistributedRenderer().instantiate()
+        assert renderer.training_setup(module) == (None, None)
+        assert module.density_changes == 1 and renderer.world_size == world and renderer.global_rank == rank
+        assert model.n_gaussians == hi - lo and torch.equal(model.get_property("ids").cpu(), ids[lo:hi])
+        for g in opt.param_groups:
+            p = g["params"][0]
+            assert p is model.get_property(g["name"]) and p.shape[0] == hi - lo and p.requires_grad
+            st = opt.state[p]
+            assert st["exp_avg"].shape == p.shape and float(st["exp_avg"].abs().sum()) == 0 and float(st["exp_avg_sq"].abs().sum()) == 0
+        assert torch.equal(model.get_xyz.detach().cpu(), params[0][lo:hi])
+
+        # ---- forward / backward against the one-process result
+        camset = [FakeCamera(c, dev) for c in cams]
+        renderer.camera_lookup = lambda idx, training: camset[idx]
+        renderer.train()
+        out = renderer(camset[rank], model, bg.to(dev))
+        assert set(out) == {"render", "hard_inverse_depth", "cameras", "projection_results_list", "visible_mask_list", "xys_grad_scale_required"}
+        assert out["render"].shape == (3, H_IMG, W_IMG) and len(out["cameras"]) == world and out["xys_grad_scale_required"] is True
+        assert [int(c.idx) for c in out["cameras"]] == [0, 1]
+        for r in out["projection_results_list"]:          # what DistributedVanillaDensityControllerImpl.before_backward does
+            r[1].retain_grad()
+        (out["render"] * weights[rank].to(dev)).sum().backward()
+        ref_renders, ref_grads, ref_xy = _reference_full_model(on_gpu, params, cams, weights, bg, dev)
+        diff = (out["render"].detach().cpu() - ref_renders[rank]).abs()
+        assert float(diff.max()) <= (2e-5 if on_gpu else 1e-9), float(diff.max())
+        tol = 2e-4 if on_gpu else 1e-8
+        names = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+        for name, ref in zip(names, ref_grads):
+            got = model.get_property(name).grad
+            assert got is not None and got.shape[0] == hi - lo, name
+            _close(got, ref[lo:hi], tol, name)
+        for i, r in enumerate(out["projection_results_list"]):
+            assert torch.equal(out["visible_mask_list"][i], r[0] > 0)
+            _close(r[1].grad, ref_xy[i].reshape(N, 2)[lo:hi], tol, f"xys grad of camera {i}")
+        # hard inverse depth render type is produced and finite
+        with torch.no_grad():
+            d = renderer(camset[rank], model, bg.to(dev), render_types=["rgb", "hard_inverse_depth"])
+        assert d["hard_inverse_depth"].shape == (1, H_IMG, W_IMG) and bool(torch.isfinite(d["hard_inverse_depth"]).all())
+
+        # ---- random_redistribute: every row (parameter AND Adam moments AND non-optimised property) follows its id
+        with torch.no_grad():
+            for g in opt.param_groups:
+                p = g["params"][0]
+                row = model.get_property("ids").reshape(-1, *([1] * (p.dim() - 1)))
+                opt.state[p]["exp_avg"] = torch.zeros_like(p) + row * 0.5
+                opt.state[p]["exp_avg_sq"] = torch.zeros_like(p) + row * 0.25
+        before = module.density_changes
+        gen = torch.Generator().manual_seed(1234 + rank)
+        destination = torch.randint(0, world, (model.n_gaussians,), generator=gen).to(dev)
+        renderer.random_redistribute(module, destination=destination)
+        assert module.density_changes == before + 1
+        new_ids = model.get_property("ids").cpu()
+        counts = D.gather_ints(model.n_gaussians, dev)
+        assert sum(counts) == N
+        exp_ids = []
+        for src in range(world):
+            slo, shi = D.shard_bounds(N, world, src)
+            dsrc = torch.randint(0, world, (shi - slo,), generator=torch.Generator().manual_seed(1234 + src))
+            exp_ids.append(ids[slo:shi][dsrc == rank])
+        assert torch.equal(new_ids, torch.cat(exp_ids))
+        full = {"means": params[0], "scales": params[1], "rotations": params[2], "opacities": params[3],
+                "shs_dc": params[4][:, :1], "shs_rest": params[4][:, 1:]}
+        for g in opt.param_groups:
+            p = g["params"][0]
+            assert p is model.get_property(g["name"]) and p.requires_grad and p.shape[0] == new_ids.shape[0]
+            assert torch.equal(p.detach().cpu(), full[g["name"]][new_ids.long()])
+            st = opt.state[p]
+            row = new_ids.reshape(-1, *([1] * (p.dim() - 1))).to(p.dtype)
+            assert torch.equal(st["exp_avg"].cpu(), torch.zeros(p.shape, dtype=p.dtype) + row * 0.5)
+            assert torch.equal(st["exp_avg_sq"].cpu(), torch.zeros(p.shape, dtype=p.dtype) + row * 0.25)
+            assert float(st["step"]) == 3.0
+        # the rebalanced shards still render the same image
+        with torch.no_grad():
+            again = renderer(camset[rank], model, bg.to(dev))["render"]
+        assert float((again.cpu() - ref_renders[rank]).abs().max()) <= (2e-5 if on_gpu else 1e-9)
+
+        # ---- after_training_step honours interval / until / threshold
+        renderer.config.redistribute_interval, renderer.config.redistribute_until = 10, 100
+        calls = []
+        renderer.random_redistribute = lambda m, destination=None: calls.append(1)
+        renderer.after_training_step(5, module)          # not on the interval
+        renderer.after_training_step(200, module)        # past `until`
+        renderer.config.redistribute_threshold = 100.0   # balanced enough
+        renderer.after_training_step(10, module)
+        assert calls == []
+        renderer.config.redistribute_threshold = 1.0 + 1e-6
+        renderer.after_training_step(20, module)
+        assert calls == ([1] if min(counts) * renderer.config.redistribute_threshold < max(counts) else [])
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(tmp_path, on_gpu):
+    port = 29900 + (os.getpid() % 300) + (50 if on_gpu else 0)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), on_gpu), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_world2_sharded_renderer_cpu_oracle_ops(tmp_path):
+    _run(tmp_path, False)
+
+
+@pytest.mark.gpu
+def test_world2_sharded_renderer_shared_gpu(tmp_path):
+    _run(tmp_path, True)
