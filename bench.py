@@ -3,25 +3,37 @@
 bench.py — headline benchmark of the rasterizer hot path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S-1080p-1M] [--api vanilla|gsplat]
+                    [--parallelism auto|single|replicated|sharded] [--optimizer fused-adam|none|...]
 
-A "step" is one pass of the hot path over one camera of synthetic input: renderer forward
-(preprocess + SH + binning + compositing), an L1 image loss, and the full backward down to the
-activated Gaussian properties (means, scales, rotations, opacities, SH).  Inputs are resident in HBM
-before the timed region.  `value` = images/s over all ranks; `ms_per_step` = wall per step.
+A "step" is one TRAINING step over one camera of synthetic input: renderer forward (preprocess + SH + binning +
+compositing), the reference's photometric loss, the full backward down to the activated Gaussian properties (means,
+scales, rotations, opacities, SH), the optimizer step (fused Adam by default) and the density controller's statistics
+update.  Inputs are resident in HBM before the timed region.  `value` = images/s over all ranks with the optimizer
+step inside the timed region; the same line also carries `images_per_s_renderer_only` (forward + loss + backward +
+statistics, no parameter update — what round 1 reported as `value`), measured in a second timed region of the same run
+(N = 1 only).
 
-Multi-GPU (driver launches `torch.distributed.run ... bench.py --gpus N`): one process per GPU over
-RCCL; Gaussians replicated, one camera per rank per step (weak scaling), and — as BASELINE.json's
-north_star prescribes — an all-reduce of the densification statistics only (per-Gaussian screen-space
-gradient norm: SUM, visibility count: SUM, max radius: MAX; 12 B/Gaussian), issued when a densification would
-consume them (every 100 steps, the reference's cadence) and once at the end of the timed region.
+Multi-GPU (driver launches `torch.distributed.run ... bench.py --gpus N`), one process per GPU over RCCL, one camera per
+rank per step (weak scaling):
+  replicated  (default for N > 1; BASELINE.json north_star, the reference's configs/ddp.yaml): every rank holds all
+              Gaussians; parameter gradients are all-reduced (averaged) before the optimizer step, the densification
+              statistics (12 B/Gaussian) every 100 steps (the reference's cadence) and at the end of the timed region.
+  sharded     (the reference's configs/distributed.yaml): Gaussians sharded over the ranks, every rank projects its
+              shard for all N cameras, one packed all-to-all of visible-splat records, compositing local
+              (gspl_amd.renderers.HipGSplatDistributedRenderer), optimizer and statistics on the shard.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = composite backward; achieved = algorithmic bytes (76*I + 20*P,
-                SURVEY.md §8d) / its mean launch duration measured with HIP events inside the timed steps;
-                peak = 8000 GB/s (MI355X_MICROARCH.md).  `traffic` = PMC-measured HBM bytes per launch when
-                profiles/ holds them for this round, else null.
-  cpu_baseline  the oracle (kind "port": torch fp32 projection+SH restatement of the reference's Python +
-                the OpenMP C compositing loops) timed on the host cores, rank 0, N=1 only, one bounded pass.
+  roofline      dominant kernel = composite backward; achieved = algorithmic bytes (76*I + 20*P, SURVEY.md §8d, I = every
+                tile-rect intersection of the API benched) / its mean launch duration measured with HIP events inside the
+                timed steps; peak = 8000 GB/s (MI355X_MICROARCH.md).  Also: `list_entries` (I', what the kernel actually
+                walks after lossless tile culling) with the fraction computed on it, `valid_pairs` ((pixel, splat) pairs
+                COUNTED on the device for this frame) and `valu_frac` = 70 flop per counted pair / time / 157.3 TFLOP/s,
+                `traffic` = PMC-measured HBM bytes per launch with `traffic_source` naming the profile it was read from.
+  cpu_baseline  host-core baseline, rank 0, N = 1 only, one bounded pass: kind "port" = the oracle (torch fp32
+                projection + SH restating the reference's Python + the OpenMP C compositing loops); when the reference tree
+                is importable (GSPL_REFERENCE_ROOT, default /root/reference) its own project_gaussians + eval_sh are
+                timed as well (`reference_projection_sh`, kind "reference").  `--cpu-baseline-only` runs just this leg
+                (no GPU needed).
 """
 import argparse
 import json
@@ -49,9 +61,13 @@ def parse():
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
                    help="l1: mean |render - target| with torch ops; photometric: the reference's training loss "
                         "0.8 L1 + 0.2 (1 - SSIM) (vanilla_metrics.py:66-68) through the fused HIP loss kernels")
-    p.add_argument("--optimizer", default="none", choices=["none", "fused-adam", "selective-adam", "torch-adam"],
-                   help="optionally put an optimizer step inside the timed step (single-GPU study; the multi-GPU protocol of "
-                        "north_star exchanges densification statistics only, so the default step has none)")
+    p.add_argument("--optimizer", default="fused-adam", choices=["none", "fused-adam", "selective-adam", "torch-adam"],
+                   help="optimizer step inside the timed step (default: the package's fused Adam; none = renderer fwd+bwd rate only)")
+    p.add_argument("--parallelism", default="auto", choices=["auto", "single", "replicated", "sharded"],
+                   help="auto: single for one GPU, replicated (gradient all-reduce + optimizer on every rank) for several; "
+                        "sharded: Gaussian-sharded renderer with the packed all-to-all (configs/distributed.yaml)")
+    p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
+    p.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg and print it (no GPU needed)")
     p.add_argument("--stage-times", action="store_true",
                    help="time EVERY C-ABI call with events (stages_ms); default: only the compositing kernels the roofline needs")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -197,8 +213,13 @@ def cpu_baseline(workload_name, api):
                             [torch.from_numpy(g_xy), torch.from_numpy(g_con), torch.from_numpy(g_col), torch.from_numpy(g_op)])
     t5 = time.perf_counter()
     total = t5 - t0
+    ref = None
+    try:
+        ref = reference_projection_sh(workload_name, cores)
+    except Exception as e:      # the reference leg is optional evidence
+        ref = {"kind": "reference", "failed": repr(e)}
     return {
-        "value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port",
+        "value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port", "reference_projection_sh": ref,
         "sample": f"one fwd+bwd pass of {workload_name} (N={wl['n']}, {W}x{H}, I={int(flat.shape[0])}), fp32, "
                   f"torch CPU projection+SH (restating the reference's gaussian_projection.py/sh_utils.py) + OpenMP C compositing",
         "ms": {"project_sh_fwd": (t1 - t0) * 1e3, "binning": (t2 - t1) * 1e3, "composite_fwd": (t3 - t2) * 1e3,
@@ -206,8 +227,58 @@ def cpu_baseline(workload_name, api):
     }
 
 
+def reference_projection_sh(workload_name, cores):
+    """The reference's OWN CPU/PyTorch path named by BASELINE.json (internal/utils/gaussian_projection.py:6-138
+    project_gaussians + internal/utils/sh_utils.py:57-113 eval_sh), forward and autograd backward, timed on the host cores.
+    Needs the reference tree (GSPL_REFERENCE_ROOT, default /root/reference): absent on the GPU boxes -> None."""
+    import importlib.util
+    from gspl_amd import synthetic
+    root = os.environ.get("GSPL_REFERENCE_ROOT", "/root/reference")
+    files = [os.path.join(root, "internal", "utils", f) for f in ("gaussian_projection.py", "sh_utils.py")]
+    if not all(os.path.exists(f) for f in files):
+        return None
+    mods = []
+    for i, f in enumerate(files):
+        spec = importlib.util.spec_from_file_location(f"_gspl_ref_mod{i}", f)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods.append(m)
+    gp, sh = mods
+    wl = synthetic.WORKLOADS[workload_name]
+    torch.set_num_threads(cores)
+    means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
+    cam = synthetic.camera(wl["width"], wl["height"], wl["fx"])
+    W, H = wl["width"], wl["height"]
+    t = torch.tensor
+
+    def one_pass():
+        m, s, q, c = [x.clone().requires_grad_(True) for x in (means, scales, quats, shs)]
+        t0 = time.perf_counter()
+        res = gp.project_gaussians(means_3d=m, scales=s, scale_modifier=1.0, quaternions=q, world_to_camera=cam["world_to_camera"],
+                                   fx=t(cam["fx"]), fy=t(cam["fy"]), cx=t(cam["cx"]), cy=t(cam["cy"]),
+                                   img_height=t(H), img_width=t(W), block_width=16)
+        xys, depths, radii, conics, comp = res[:5]
+        dirs = m.detach() - cam["camera_center"]
+        dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        rgbs = torch.clamp_min(sh.eval_sh(3, c.transpose(1, 2), dirs) + 0.5, 0.0)      # [N,3,K] as vanilla_renderer.py:100
+        t1 = time.perf_counter()
+        (xys.sum() + conics.sum() + comp.sum() + rgbs.sum()).backward()
+        t2 = time.perf_counter()
+        return (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+    one_pass()                                   # warm-up
+    runs = [one_pass() for _ in range(3)]
+    fwd, bwd = min(r[0] for r in runs), min(r[1] for r in runs)
+    return {"kind": "reference", "fwd_ms": round(fwd, 2), "bwd_ms": round(bwd, 2), "cores": cores, "root": root,
+            "sample": f"{workload_name}: reference project_gaussians + eval_sh (degree 3), fp32, 1 warm-up + min of 3, sum() losses"}
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        sample = args.workload if args.cpu_sample == "auto" else args.cpu_sample
+        print(json.dumps(cpu_baseline(sample, args.api)), flush=True)
+        return
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -227,75 +298,153 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    mode = args.parallelism
+    if mode == "auto":
+        mode = "single" if world == 1 else "replicated"
+    if mode == "single" and world > 1:
+        sys.exit("--parallelism single needs --gpus 1")
 
     import gspl_amd  # noqa: F401
-    from gspl_amd import _lib, synthetic
+    from gspl_amd import _lib, ops, synthetic
+    from gspl_amd import distributed as gdist
+    from gspl_amd.density import update_densification_stats
     _lib.lib()
     wl = synthetic.WORKLOADS[args.workload]
+    W, H = wl["width"], wl["height"]
     means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
     # every rank renders its own camera (cameras sharded): a small per-rank dolly keeps the work equal
-    cam = synthetic.camera(wl["width"], wl["height"], wl["fx"], distance=wl.get("distance", 4.0) + 0.01 * rank)
-    tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
-    step = make_step(args.api, dev, wl, cam, tensors, args.loss)
-    optimizer = None
-    if args.optimizer != "none":
-        # eps 1e-15 as the reference (internal/models/vanilla_gaussian.py:266-300).  The bench tensors are ACTIVATED values
-        # (post-exp scales, post-sigmoid opacities), so the reference's learning rates — meant for the raw parameters —
-        # are scaled down by 1e3: the optimizer's cost is measured without letting the synthetic scene drift.
-        groups = [{"params": [t], "lr": lr * 1e-3} for t, lr in zip(tensors, (1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3))]
-        if args.optimizer == "torch-adam":
-            optimizer = torch.optim.Adam(groups, eps=1e-15)
-        else:
-            from gspl_amd import optimizers as gopt
-            optimizer = (gopt.FusedAdam if args.optimizer == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15)
-    N = wl["n"]
+    cam_dicts = [synthetic.camera(W, H, wl["fx"], distance=wl.get("distance", 4.0) + 0.01 * r) for r in range(world)]
+    cam = cam_dicts[rank]
+    # eps 1e-15 as the reference (internal/models/vanilla_gaussian.py:266-300).  The bench tensors are ACTIVATED values
+    # (post-exp scales, post-sigmoid opacities), so the reference's learning rates — meant for the raw parameters —
+    # are scaled down by 1e3: the optimizer's cost is measured without letting the synthetic scene drift.
+    LRS = (1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3)         # means, scales, rotations, opacities, SH
+
+    def make_optimizer(kind, groups):
+        if kind == "none":
+            return None
+        if kind == "torch-adam":
+            return torch.optim.Adam(groups, eps=1e-15)
+        from gspl_amd import optimizers as gopt
+        return (gopt.FusedAdam if kind == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15)
+
+    DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
+    counter = {"n": 0}
+
+    if mode == "sharded":
+        # ---- the reference's configs/distributed.yaml: Gaussians sharded, one packed all-to-all per step ------------------
+        from gspl_amd.renderers import HipGSplatDistributedRenderer
+        lo, hi = gdist.shard_bounds(wl["n"], world, rank)
+        model = synthetic.ModelObject(*[t[lo:hi].contiguous().to(dev) for t in (means, scales, quats, opac, shs)])
+        N = hi - lo
+        cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
+        # tile_based_culling as in the reference's configs/distributed-accel.yaml (lossless here: same images and gradients)
+        renderer = HipGSplatDistributedRenderer(tile_based_culling=True).instantiate()
+        renderer.world_size, renderer.global_rank = world, rank
+        renderer.camera_lookup = lambda idx, training: cams[idx]
+        renderer.train()
+        bg = torch.zeros(3, device=dev)
+        target = torch.full((3, H, W), 0.5, device=dev)
+        loss_fn = (lambda img: ops.photometric_loss(img, target, 0.2)) if args.loss == "photometric" else (lambda img: (img - target).abs().mean())
+        tensors = model.leaves()
+        lrs = LRS[:4] + (LRS[4], LRS[4] / 20.0)
+        grad_scale = torch.tensor([0.5 * W, 0.5 * H], device=dev)
+        state = {}
+
+        def step():
+            for t in tensors:
+                t.grad = None
+            marks = state.get("marks")
+            if marks is not None:
+                marks.append(_mark())
+            out = renderer(cams[rank], model, bg)
+            for r in out["projection_results_list"]:      # DistributedVanillaDensityControllerImpl.before_backward
+                r[1].retain_grad()
+            loss = loss_fn(out["render"])
+            if marks is not None:
+                marks.append(_mark())
+            loss.backward()
+            if marks is not None:
+                marks.append(_mark())
+            state["out"], state["loss"] = out, loss
+            return state
+        step.state = state
+
+        def stats(st, accum, denom, max_radii):           # DistributedVanillaDensityControllerImpl.update_states, fused kernel
+            out = st["out"]
+            for r, vis in zip(out["projection_results_list"], out["visible_mask_list"]):
+                update_densification_stats(r[1].grad, vis, r[0], accum, denom, max_radii, scale=grad_scale)
+        visible = None
+        api = "gsplat"
+    else:
+        tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
+        N = wl["n"]
+        step = make_step(args.api, dev, wl, cam, tensors, args.loss)
+        lrs = LRS
+
+        def stats(st, accum, denom, max_radii):
+            densification_stats(st, accum, denom, max_radii)
+        api = args.api
+
     accum = torch.zeros(N, device=dev)
     denom = torch.zeros(N, device=dev)
     max_radii = torch.zeros(N, device=dev)                       # float, as the reference's buffer (vanilla_density_controller.py:61)
 
-    from gspl_amd import distributed as gdist
-    DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
-    counter = {"n": 0}
+    def make_full_step(optimizer, opt_kind):
+        def full_step(force_reduce=False):
+            st = step()
+            with torch.no_grad():
+                stats(st, accum, denom, max_radii)
+                if optimizer is not None:
+                    if mode == "replicated":
+                        # replicas stay identical: average the parameter gradients over the ranks (DDP of configs/ddp.yaml)
+                        gdist.all_reduce_gradients(tensors)
+                    if opt_kind == "selective-adam" and "radii" in st:
+                        optimizer.step(st["radii"] > 0)
+                    else:
+                        optimizer.step()
+                counter["n"] += 1
+                # replicated mode: the statistics are accumulated locally and made identical on all ranks when a densification
+                # would consume them (every DENSIFY_INTERVAL steps) — and once at the end of the timed region so that every
+                # run pays for at least one reduction.  Sharded mode: every rank keeps the statistics of its own rows.
+                if mode == "replicated" and (force_reduce or counter["n"] % DENSIFY_INTERVAL == 0):
+                    gdist.reduce_densification_stats(accum, denom, max_radii)
+            return st
+        return full_step
 
-    def full_step(force_reduce=False):
-        st = step()
-        with torch.no_grad():
-            densification_stats(st, accum, denom, max_radii)
-            if optimizer is not None:
-                if args.optimizer == "selective-adam":
-                    optimizer.step(st["radii"] > 0)
-                else:
-                    optimizer.step()
-            counter["n"] += 1
-            # statistics are accumulated locally and made identical on all ranks when a densification would consume
-            # them (every DENSIFY_INTERVAL steps) — and once at the end of the timed region so that every run pays
-            # for at least one reduction
-            if dist is not None and (force_reduce or counter["n"] % DENSIFY_INTERVAL == 0):
-                gdist.reduce_densification_stats(accum, denom, max_radii)
-        return st
+    def timed_region(full_step, steps, warmup):
+        for _ in range(warmup):
+            full_step(force_reduce=True)
+        # Host hygiene: a full (generation-2) pass of Python's cyclic GC walks every object torch has imported — 30-40 ms during
+        # which no kernel is launched, once every ~130 steps.  Freezing what exists after warm-up keeps later collections to
+        # the objects of the steps themselves.
+        import gc
+        gc.collect()
+        gc.freeze()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        step.state["marks"] = []
+        _lib.profile_start(None if args.stage_times else ("gspl_composite_bwd_packed", "gspl_composite_bwd", "gspl_composite_fwd"))
+        t0 = time.perf_counter()
+        for k in range(steps):
+            full_step(force_reduce=(k == steps - 1))
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = _lib.profile_stop()
+        marks = step.state.pop("marks")
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof, marks
 
-    for _ in range(args.warmup):
-        full_step(force_reduce=True)
-    # Host hygiene: a full (generation-2) pass of Python's cyclic GC walks every object torch has imported — 30-40 ms during
-    # which no kernel is launched, once every ~130 steps (seen as one 38 ms step in GSPL_BENCH_DUMP=1 runs).  Freezing what
-    # exists after warm-up keeps later collections to the objects of the steps themselves.
-    import gc
-    gc.collect()
-    gc.freeze()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    step.state["marks"] = []
-    _lib.profile_start(None if args.stage_times else ("gspl_composite_bwd_packed", "gspl_composite_bwd", "gspl_composite_fwd"))
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        st = full_step(force_reduce=(k == args.steps - 1))
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = _lib.profile_stop()
-    marks = step.state.pop("marks")
+    groups = [{"params": [t], "lr": lr * 1e-3} for t, lr in zip(tensors, lrs)]
+    optimizer = make_optimizer(args.optimizer, groups)
+    ops.KEEP_LAST_RASTER = True
+    elapsed, prof, marks = timed_region(make_full_step(optimizer, args.optimizer), args.steps, args.warmup)
     phase_fwd = sum(marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)) / args.steps
     phase_bwd = sum(marks[i + 1].elapsed_time(marks[i + 2]) for i in range(0, len(marks), 3)) / args.steps
     if os.environ.get("GSPL_BENCH_DUMP") and rank == 0:
@@ -307,53 +456,85 @@ def main():
         print("step spans ms: median %.3f p90 %.3f p99 %.3f max %.3f; outliers (>2x median): %s" % (
             srt[len(srt) // 2], srt[int(len(srt) * 0.9)], srt[int(len(srt) * 0.99)], srt[-1],
             [(i, round(x, 2), round(fw[i], 2)) for i, x in enumerate(spans) if x > 2 * srt[len(srt) // 2]][:40]), file=sys.stderr)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    renderer_only = None
+    if world == 1 and optimizer is not None and not args.no_renderer_only:
+        # second timed region of the same run: the step without a parameter update (round 1's `value`)
+        e2, _, m2 = timed_region(make_full_step(None, "none"), args.steps, 2)
+        renderer_only = {"images_per_s": round(args.steps / e2, 3), "ms_per_step": round(e2 / args.steps * 1e3, 4),
+                         "fwd_ms": round(sum(m2[i].elapsed_time(m2[i + 1]) for i in range(0, len(m2), 3)) / args.steps, 4),
+                         "bwd_ms": round(sum(m2[i + 1].elapsed_time(m2[i + 2]) for i in range(0, len(m2), 3)) / args.steps, 4)}
 
     if rank == 0:
         mean = lambda name: (sum(prof[name]) / len(prof[name])) if prof.get(name) else None
         # per-STEP totals (an entry point called twice per step, e.g. the two phases of the Inria preprocess, counts twice)
         stages = {k: round(sum(v) / args.steps, 4) for k, v in prof.items()}
-        # intersections of this workload (for the algorithmic byte model)
-        from gspl_amd import ops
-        with torch.no_grad():
-            if args.api == "vanilla":
-                I = None
-            m, s, q, o, c = tensors
-            vm = cam["world_to_camera"].T.contiguous().to(dev)
-            _, _, radii, _, _, tiles, _ = ops.project_gaussians(m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"],
-                                                                wl["height"], wl["width"], 16)
-            I_gsplat = int(tiles.sum().item())
-        P = wl["width"] * wl["height"]
+        P = W * H
         bwd_ms = mean("gspl_composite_bwd_packed") or mean("gspl_composite_bwd")
-        fwd_ms = mean("gspl_composite_fwd")
-        # vanilla rect convention gives a slightly different I; measure it from the sort call count instead
-        I = I_gsplat
-        alg_bytes = 76.0 * I + 20.0 * P
+        # ---- the frame the byte / flop models are evaluated on: the LAST compositing call of the timed steps -----------------
+        last = ops.LAST_RASTER
+        I = list_entries = valid_pairs = None
+        with torch.no_grad():
+            if last is not None:
+                list_entries = int(last["flatten_ids"].shape[0])
+                # (pixel, splat) pairs the compositing actually blends, COUNTED on the device: per-splat hit-pixel counts of the
+                # same lists (gspl_composite_scores), summed
+                count = ops.composite_scores(last["means2d"], last["conics"], last["opacities"], W, H, 16, last["offsets"],
+                                             last["flatten_ids"], mode=last["mode"])[0]
+                valid_pairs = int(count.sum(dtype=torch.int64).item())
+                if mode != "sharded":
+                    if api == "vanilla":      # every tile-rect intersection in the Inria convention: the same binning without culling
+                        I = int(ops.bin_gaussians(last["means2d"], last["depths"], last["radii"], H, W, 16, mode=_lib.GSPL_MODE_INRIA)[0].shape[0])
+                    else:
+                        m, s, q, o, c = tensors
+                        vm = cam["world_to_camera"].T.contiguous().to(dev)
+                        tiles = ops.project_gaussians(m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)[5]
+                        I = int(tiles.sum().item())
         roofline = None
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f).get(f"{args.workload}/{args.api}", {}).get("composite_bwd_kernel", {}).get("traffic_bytes")
-        except OSError:
-            pass
         if bwd_ms:
-            achieved = alg_bytes / (bwd_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "composite_bwd_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes": alg_bytes, "avg_ms": round(bwd_ms, 4), "intersections": I}
+            kernel = _lib.lib().gspl_composite_bwd_kernel_name().decode()
+            traffic = traffic_source = None
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        entry = json.load(f).get(f"{args.workload}/{api}", {})
+                    entry = entry.get(kernel) or entry.get("composite_bwd_kernel") or {}
+                    if entry.get("traffic_bytes"):
+                        traffic = entry["traffic_bytes"]
+                        traffic_source = f"profiles/{name} ({entry.get('source', 'earlier PMC run, not this run')})"
+                        break
+                except OSError:
+                    pass
+            t_s = bwd_ms * 1e-3
+            bytes_I = (76.0 * I + 20.0 * P) if I is not None else None
+            bytes_L = (76.0 * list_entries + 20.0 * P) if list_entries is not None else None
+            alg = bytes_I if bytes_I is not None else bytes_L
+            achieved = alg / t_s / 1e9
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                        "algorithmic_bytes": alg, "avg_ms": round(bwd_ms, 4),
+                        "intersections": I, "list_entries": list_entries,
+                        "frac_on_list_entries": round(bytes_L / t_s / 1e9 / HBM_PEAK_GBS, 5) if bytes_L else None,
+                        "valid_pairs": valid_pairs, "flop_per_pair": 70,
+                        "valu_frac": round(valid_pairs * 70.0 / t_s / (FP32_PEAK_TFLOPS * 1e12), 5) if valid_pairs else None,
+                        "valu_peak_tflops": FP32_PEAK_TFLOPS}
+        step_desc = ("renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd"
+                     + (" + gradient all-reduce" if mode == "replicated" and args.optimizer != "none" else "")
+                     + ("" if args.optimizer == "none" else " + " + args.optimizer + " step") + " + densification stats")
+        par = {"single": "single GPU",
+               "replicated": f"replicated Gaussians, {world} camera(s)/step, all-reduce of parameter gradients every step and of the densification stats every {DENSIFY_INTERVAL} steps",
+               "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of visible-splat records (configs/distributed.yaml)"}[mode]
         line = {
             "metric": "training images/sec + fwd/bwd ms @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(world * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "api": args.api, "n_gaussians": N, "width": wl["width"], "height": wl["height"],
-                       "sh_degree": 3, "loss": args.loss, "optimizer": args.optimizer,
-                       "step": "renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd + densification stats"
-                               + ("" if args.optimizer == "none" else " + " + args.optimizer + " step"),
-                       "parallelism": f"replicated Gaussians, {world} camera(s)/step, all-reduce of densification stats only"},
+            "config": {"workload": args.workload, "api": api, "n_gaussians": wl["n"], "width": W, "height": H,
+                       "sh_degree": 3, "loss": args.loss, "optimizer": args.optimizer, "step": step_desc,
+                       "parallelism": par, "parallelism_mode": mode},
+            "images_per_s_with_optimizer": round(world * args.steps / elapsed, 3) if args.optimizer != "none" else None,
+            "images_per_s_renderer_only": (renderer_only["images_per_s"] if renderer_only else
+                                           (round(world * args.steps / elapsed, 3) if args.optimizer == "none" else None)),
+            "renderer_only": renderer_only,
             "stages_ms": stages,
             # device time between the events at the start of the step, before loss.backward() and after it
             "fwd_ms": round(phase_fwd, 4),

@@ -43,6 +43,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "gspl_abi_version": (c_int, []),
     "gspl_last_error": (ctypes.c_char_p, []),
+    "gspl_composite_bwd_kernel_name": (ctypes.c_char_p, []),
     "gspl_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                  c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float,

@@ -1181,6 +1181,15 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
     return rc;
 }
 
+// Name of the kernel template gspl_composite_bwd / gspl_composite_bwd_packed launch in this build (for profile look-ups).
+extern "C" const char* gspl_composite_bwd_kernel_name(void) {
+#ifndef GSPL_BWD_V2
+    return "composite_bwd2_kernel";
+#else
+    return "composite_bwd_kernel";
+#endif
+}
+
 #ifdef GSPL_COUNT_PAIRS
 // instrumentation build only: copy (and optionally reset) the counters of the compositing kernels
 extern "C" int gspl_debug_pair_stats(unsigned long long* out8, int reset) {

@@ -421,6 +421,10 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 # `has_hit_any_pixels` to the caller's screen-space tensor (the fork-only side channel gsplat's SelectiveAdam adapter
 # reads, internal/optimizers.py:39).  Off by default: it is one more byte store per (tile, splat) in the hot kernel.
 TRACK_HIT_PIXELS = False
+# Introspection for bench.py / tools: with KEEP_LAST_RASTER set, the last compositing forward leaves its per-splat inputs and
+# tile lists in LAST_RASTER (a dict of tensors; nothing is copied).
+KEEP_LAST_RASTER = False
+LAST_RASTER: Optional[dict] = None
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -449,6 +453,10 @@ class _CompositeFn(torch.autograd.Function):
             width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
             L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.stream())
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids)
+        if KEEP_LAST_RASTER:
+            global LAST_RASTER
+            LAST_RASTER = dict(mode=mode, width=width, height=height, means2d=means2d, conics=conics, opacities=opacities,
+                               flatten_ids=flatten_ids, offsets=offsets)
         ctx.cfg = (width, height, tile_size, tile_w, tile_h, bool(absgrad), mode, layout)
         ctx.means2d_ref = means2d_in      # the caller's tensor object: `.absgrad` is attached to it in backward
         return out, alphas
@@ -811,6 +819,10 @@ class _InriaRasterizeFn(torch.autograd.Function):
             L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.stream())
         ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
                               radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids)
+        if KEEP_LAST_RASTER:
+            global LAST_RASTER
+            LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=means2d, conics=conics, opacities=opac,
+                               flatten_ids=flat, offsets=offsets, radii=radii, depths=depths)
         ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
                    float(s.scale_modifier), colors_precomp is not None, opacities.shape)
         ctx.set_materialize_grads(False)      # the integer `radii` output would otherwise get a zero "gradient" tensor per step

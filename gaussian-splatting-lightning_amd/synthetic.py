@@ -53,3 +53,53 @@ def camera(width: int, height: int, fx: float, fy: float = None, distance: float
     center = torch.linalg.inv(w2c)[3, :3]
     return {"world_to_camera": w2c, "full_projection": full, "camera_center": center, "fx": fx, "fy": fy,
             "cx": width / 2.0, "cy": height / 2.0, "width": width, "height": height, "tanfovx": tanx, "tanfovy": tany}
+
+
+class CameraObject:
+    """The fields of the reference's `Camera` (internal/cameras/cameras.py:13-43) the renderers read, on `device`."""
+
+    def __init__(self, cam: dict, device, idx: int = 0):
+        import math
+        t = lambda v, dt=torch.float32: torch.tensor(v, dtype=dt, device=device)
+        self.world_to_camera = cam["world_to_camera"].to(device)
+        self.full_projection = cam["full_projection"].to(device)
+        self.camera_center = cam["camera_center"].to(device)
+        self.fx, self.fy, self.cx, self.cy = t(cam["fx"]), t(cam["fy"]), t(cam["cx"]), t(cam["cy"])
+        self.width, self.height = t(cam["width"], torch.int32), t(cam["height"], torch.int32)
+        self.fov_x, self.fov_y = t(2 * math.atan(cam["tanfovx"])), t(2 * math.atan(cam["tanfovy"]))
+        self.idx = t(idx, torch.int32)
+        self.device = device
+
+    def to_device(self, device):
+        for k, v in list(vars(self).items()):
+            if isinstance(v, torch.Tensor):
+                setattr(self, k, v.to(device))
+        self.device = device
+        return self
+
+
+class ModelObject(torch.nn.Module):
+    """Getter surface of the reference's Gaussian model (internal/models/gaussian.py:122-323) over ACTIVATED tensors
+    (means, scales, unit quaternions, opacities, SH dc / rest), as `pre_activate_all_properties` leaves them."""
+
+    def __init__(self, means, scales, quats, opac, shs, active_sh_degree: int = 3):
+        super().__init__()
+        P = torch.nn.Parameter
+        self.means, self.scales_, self.rotations_, self.opacities_ = P(means), P(scales), P(quats), P(opac)
+        self.shs_dc, self.shs_rest = P(shs[:, :1].contiguous()), P(shs[:, 1:].contiguous())
+        self.active_sh_degree = active_sh_degree
+        self.is_pre_activated = False
+
+    get_xyz = property(lambda s: s.means)
+    get_scaling = property(lambda s: s.scales_)
+    get_rotation = property(lambda s: s.rotations_)
+    get_opacity = property(lambda s: s.opacities_)
+    get_features = property(lambda s: torch.cat((s.shs_dc, s.shs_rest), dim=1))
+
+    def get_means(self): return self.means
+    def get_scales(self): return self.scales_
+    def get_rotations(self): return self.rotations_
+    def get_opacities(self): return self.opacities_
+    def get_shs_dc(self): return self.shs_dc
+    def get_shs_rest(self): return self.shs_rest
+    def leaves(self): return [self.means, self.scales_, self.rotations_, self.opacities_, self.shs_dc, self.shs_rest]

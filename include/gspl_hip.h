@@ -283,6 +283,9 @@ int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layo
                               float* v_packed, int packed_stride /* floats per row, >= 6+D(+2) */, int absgrad,
                               uint8_t* hit_flags /*nullable*/, void* stream);
 
+/* Name of the kernel template the two backward entry points launch in this build (profile look-ups in bench.py). */
+const char* gspl_composite_bwd_kernel_name(void);
+
 /* ------------------------------------------------------------------------------------------
  * 6. Inria-convention preprocess (the front half of the fused `GaussianRasterizer`).
  *    Replaces `diff_gaussian_rasterization.GaussianRasterizer.forward` up to the sort
