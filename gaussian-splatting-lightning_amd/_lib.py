@@ -75,7 +75,7 @@ _SIGNATURES = {
     "gspl_bin_sort": (c_int, [c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_composite_fwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
-                                   c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+                                   c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_composite_bwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                                    _P, _P, _P, _P, _P, _P, _P]),

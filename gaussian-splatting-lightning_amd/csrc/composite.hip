@@ -120,14 +120,17 @@ static constexpr int FLIST = FCHUNK + 2;      // room for the odd-count padding 
 __device__ unsigned long long g_pair_stats[8];
 #endif
 
-template <int D, int MODE, bool CHW>
+// HITS: also report, per splat, whether any pixel composited it (hit_flags[g] = 1; the fork's `has_hit_any_pixels`, set by its
+// rasterizer forward: gsplat_v1_renderer.py:287 reads it as `acc_vis`).  Per candidate one wave-wide "any lane contributed" bit
+// is collected in a scalar mask; after the round the lane that gathered the candidate stores its flag.
+template <int D, int MODE, bool CHW, bool HITS>
 __global__ __launch_bounds__(64) void composite_fwd_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
     float* __restrict__ out_colors, float* __restrict__ out_alphas, float* __restrict__ final_Ts,
-    int32_t* __restrict__ last_ids) {
+    int32_t* __restrict__ last_ids, uint8_t* __restrict__ hit_flags) {
     using TR = ModeTraits<MODE>;
     __shared__ __attribute__((aligned(16))) float s_x[FLIST];
     __shared__ __attribute__((aligned(16))) float s_y[FLIST];
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
                 for (int c = 0; c < D; ++c) s_col[ncand * D + c] = 0.f;
             }
             bool all_done = false;
+            unsigned long long hitmask = 0ull;      // HITS: bit k = some pixel composited candidate k of this round
             for (int k = 0; k < ncand; k += 2) {
                 const v2f x2 = *reinterpret_cast<const v2f*>(&s_x[k]);
                 const v2f y2 = *reinterpret_cast<const v2f*>(&s_y[k]);
@@ -223,11 +227,15 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
                     T = contrib ? next_T : T;
                     last = contrib ? pos[e] : last;
                     done = done || stop;
+                    if constexpr (HITS) hitmask |= (__ballot(contrib) != 0ull ? 1ull : 0ull) << (k + e);
                 }
 #ifdef GSPL_COUNT_PAIRS
                 if (l == 0) atomicAdd(&g_pair_stats[6], 1ull);
 #endif
                 if (__all(done)) { all_done = true; break; }
+            }
+            if constexpr (HITS) {
+                if (cand && ((hitmask >> slot) & 1ull)) hit_flags[g] = 1;
             }
             if (all_done) break;
         }
@@ -940,10 +948,15 @@ template <int D, int MODE, bool CHW>
 static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
-                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, hipStream_t s) {
-    hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW>), dim3(4 * n_tiles), dim3(64), 0, s,
-                       n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                       offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids);
+                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, uint8_t* hit_flags, hipStream_t s) {
+    if (hit_flags)
+        hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, true>), dim3(4 * n_tiles), dim3(64), 0, s,
+                           n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
+                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags);
+    else
+        hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, false>), dim3(4 * n_tiles), dim3(64), 0, s,
+                           n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
+                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags);
     return check_launch("composite_fwd");
 }
 
@@ -1092,7 +1105,8 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
                                   const float* opacities, const float* backgrounds,
                                   int width, int height, int tile_size, int tile_w, int tile_h,
                                   const int32_t* offsets, const int32_t* flatten_ids,
-                                  float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, void* stream) {
+                                  float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids,
+                                  uint8_t* hit_flags, void* stream) {
     using namespace gspl;
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_fwd: bad argument");
     if (rc != GSPL_OK) return rc;
@@ -1101,7 +1115,7 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
     const int n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, s)
+#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, s)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_FWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_FWD) }

@@ -430,7 +430,7 @@ LAST_RASTER: Optional[dict] = None
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets, flatten_ids,
-                absgrad, mode, layout):
+                absgrad, mode, layout, track_hits=False):
         lib = L.lib()
         means2d_in = means2d
         means2d, conics, colors, opacities = map(_f32c, (means2d, conics, colors, opacities))
@@ -448,10 +448,16 @@ class _CompositeFn(torch.autograd.Function):
         alphas = torch.empty((height, width), dtype=torch.float32, device=dev)
         final_Ts = torch.empty((height, width), dtype=torch.float32, device=dev)
         last_ids = torch.empty((height, width), dtype=torch.int32, device=dev)
-        L.call("gspl_composite_fwd", 
-            N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
-            width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
-            L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.stream())
+        # `has_hit_any_pixels` of the fork's rasterizer (set in ITS forward; read as `acc_vis`, gsplat_v1_renderer.py:287, and by
+        # SelectiveAdam, internal/optimizers.py:39): which splats some pixel actually composited
+        hit = torch.zeros((N,), dtype=torch.uint8, device=dev) if track_hits else None
+        with torch.cuda.device(dev):
+            L.call("gspl_composite_fwd",
+                   N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
+                   width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
+                   L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.ptr(hit), L.stream())
+        if hit is not None:
+            means2d_in.has_hit_any_pixels = hit.view(torch.bool)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids)
         if KEEP_LAST_RASTER:
             global LAST_RASTER
@@ -493,17 +499,17 @@ class _CompositeFn(torch.autograd.Function):
             T_final = final_Ts
             vo = v_out if layout == L.GSPL_LAYOUT_HWC else v_out.permute(1, 2, 0)
             v_bg = (vo * T_final[..., None]).sum(dim=(0, 1))
-        return v_means2d, v_conics, v_colors, v_opac.reshape(opacities.shape), v_bg, None, None, None, None, None, None, None, None
+        return v_means2d, v_conics, v_colors, v_opac.reshape(opacities.shape), v_bg, None, None, None, None, None, None, None, None, None
 
 
 def _composite(means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets, flatten_ids,
-               absgrad, mode, layout):
+               absgrad, mode, layout, track_hits=False):
     """Channel-count adapter: kernels are built for D in {1,2,3,4,8}; other widths are zero-padded /
     split into groups of 8 (extra channels composite to zero and carry zero gradient)."""
     D = colors.shape[1]
     if D in _SUPPORTED_D:
         return _CompositeFn.apply(means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets,
-                                  flatten_ids, absgrad, mode, layout)
+                                  flatten_ids, absgrad, mode, layout, track_hits)
     outs, alphas = [], None
     for s in range(0, D, 8):
         e = min(D, s + 8)
@@ -515,7 +521,7 @@ def _composite(means2d, conics, colors, opacities, backgrounds, width, height, t
             c = torch.nn.functional.pad(c, (0, pad))
             bg = None if bg is None else torch.nn.functional.pad(bg, (0, pad))
         o, alphas = _CompositeFn.apply(means2d, conics, c, opacities, bg, width, height, tile_size, offsets, flatten_ids,
-                                       absgrad and s == 0, mode, layout)
+                                       absgrad and s == 0, mode, layout, track_hits and s == 0)
         outs.append(o[..., :w] if layout == L.GSPL_LAYOUT_HWC else o[:w])
     return torch.cat(outs, dim=-1 if layout == L.GSPL_LAYOUT_HWC else 0), alphas
 
@@ -523,18 +529,19 @@ def _composite(means2d, conics, colors, opacities, backgrounds, width, height, t
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
                         image_width: int, image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
                         backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
-                        absgrad: bool = False, channels_first: bool = False) -> Tuple[Tensor, Tensor]:
+                        absgrad: bool = False, channels_first: bool = False, track_hits: bool = False) -> Tuple[Tensor, Tensor]:
     """gsplat signature as the reference calls it (gsplat_v1_renderer.py:588-601): means2d [N,2] (or [1,N,2]),
     conics [1,N,3], colors [1,N,D], opacities [1,N], isect_offsets [1,th,tw], backgrounds [1,D].
     Returns (colors [1,H,W,D], alphas [1,H,W,1]).  With absgrad=True, backward sets `means2d.absgrad`.
-    channels_first (extension): colors come out as [1,D,H,W] straight from the kernel (see `rasterize_gaussians`)."""
+    channels_first (extension): colors come out as [1,D,H,W] straight from the kernel (see `rasterize_gaussians`).
+    track_hits: set `means2d.has_hit_any_pixels` ([N] bool: composited by some pixel) in the forward, as the fork's rasterizer does."""
     if packed or masks is not None:
         raise NotImplementedError("packed / masks are not used by the reference")
     m2 = means2d if means2d.dim() == 2 else means2d.squeeze(0)
     out, alphas = _composite(m2, conics.reshape(-1, 3), colors.reshape(-1, colors.shape[-1]), opacities.reshape(-1),
                              None if backgrounds is None else backgrounds.reshape(-1), image_width, image_height, tile_size,
                              isect_offsets.reshape(-1), flatten_ids, absgrad, L.GSPL_MODE_GSPLAT,
-                             L.GSPL_LAYOUT_CHW if channels_first else L.GSPL_LAYOUT_HWC)
+                             L.GSPL_LAYOUT_CHW if channels_first else L.GSPL_LAYOUT_HWC, track_hits)
     if absgrad and m2 is not means2d:
         raise ValueError("absgrad needs means2d given as [N,2] so that .absgrad lands on the caller's tensor")
     return out[None], alphas[None, ..., None]
@@ -816,7 +823,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
         L.call("gspl_composite_fwd", 
             N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
             L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat) if n_isects else None,
-            L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.stream())
+            L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), None, L.stream())
         ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
                               radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids)
         if KEEP_LAST_RASTER:

@@ -140,10 +140,10 @@ class HipGSplatV1RendererModule(Renderer):
         projection_for_rasterization = radii, means2d, depths, conics, compensations
         zero1 = torch.zeros((1,), dtype=torch.float, device=bg_color.device)
 
-        def rasterize(input_features, background, return_alpha=False, opac=opacities, absgrad=True, channels_first=False):
+        def rasterize(input_features, background, return_alpha=False, opac=opacities, absgrad=True, channels_first=False, track_hits=False):
             c, a = GSplatV1.rasterize(preprocessed_camera, projection_for_rasterization, isects, opacities=opac,
                                       colors=input_features, background=background, tile_size=self.config.block_size,
-                                      absgrad=absgrad, channels_first=channels_first)
+                                      absgrad=absgrad, channels_first=channels_first, track_hits=track_hits)
             return (c, a.squeeze(0).squeeze(-1)) if return_alpha else c
 
         outputs = {
@@ -182,12 +182,13 @@ class HipGSplatV1RendererModule(Renderer):
             b = bgs[0] if len(bgs) == 1 else torch.concat(bgs, dim=-1)
             # [D,H,W] straight from the kernel (the reference permutes an [H,W,D] image: every consumer of "render" would then
             # copy it to make it contiguous, forward and backward); the per-type outputs are contiguous channel slices
-            render_features, render_alpha = rasterize(f, background=b, return_alpha=True, channels_first=True)
+            # track_hits: the fork's rasterizer sets `means2d.has_hit_any_pixels` in its forward (read below as `acc_vis`)
+            render_features, render_alpha = rasterize(f, background=b, return_alpha=True, channels_first=True, track_hits=True)
             render_alpha = render_alpha.unsqueeze(0)
             for k, (s, e) in index.items():
                 outputs[k] = render_features[s:e]
             outputs["alpha"] = render_alpha
-            outputs["acc_vis"] = getattr(means2d, "has_hit_any_pixels", None)
+            outputs["acc_vis"] = means2d.has_hit_any_pixels          # avoid overriding by hard depth (gsplat_v1_renderer.py:286-287)
             if self.is_type_required(bits, self._ACC_DEPTH_INVERTED_REQUIRED):
                 d = outputs["acc_depth"]
                 outputs["acc_depth_inverted"] = torch.where(d > 0, 1. / d, d.detach().max())

@@ -244,6 +244,8 @@ int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int layout,
                        int width, int height, int tile_size, int tile_w, int tile_h,
                        const int32_t* offsets, const int32_t* flatten_ids,
                        float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids,
+                       uint8_t* hit_flags /*nullable: [N], zeroed by the caller; 1 = some pixel composited the splat (the
+                                            fork's has_hit_any_pixels / acc_vis, gsplat_v1_renderer.py:287)*/,
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------

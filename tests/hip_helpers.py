@@ -13,7 +13,7 @@ def t32(a, device=None):
     return torch.as_tensor(np.asarray(a), dtype=torch.float32).contiguous().to(device or dev())
 
 
-def hip_composite_fwd(mode, means2d, conics, colors, opac, bg, W, H, offsets, flat, layout=L.GSPL_LAYOUT_HWC):
+def hip_composite_fwd(mode, means2d, conics, colors, opac, bg, W, H, offsets, flat, layout=L.GSPL_LAYOUT_HWC, hits=None):
     lib = L.lib()
     N, D = colors.shape
     tw, th = (W + 15) // 16, (H + 15) // 16
@@ -25,7 +25,7 @@ def hip_composite_fwd(mode, means2d, conics, colors, opac, bg, W, H, offsets, fl
     n_isects = flat.shape[0]
     L.check(lib.gspl_composite_fwd(N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
                                    L.ptr(bg), W, H, 16, tw, th, L.ptr(offsets), L.ptr(flat) if n_isects else None,
-                                   L.ptr(out), L.ptr(alphas), L.ptr(final_T), L.ptr(last), L.stream()), "composite_fwd")
+                                   L.ptr(out), L.ptr(alphas), L.ptr(final_T), L.ptr(last), L.ptr(hits), L.stream()), "composite_fwd")
     return out, alphas, final_T, last
 
 

@@ -116,6 +116,18 @@ def test_hip_gsplat_renderers_contract_and_parity(which):
     vp = out["viewspace_points"]
     assert_close_scaled(vp.grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", 0.995)
     assert hasattr(vp, "absgrad") and torch.all(vp.absgrad >= vp.grad.abs() - 1e-6)
+    if which != "v0":
+        # `acc_vis` (the fork's has_hit_any_pixels, set by the rasterizer FORWARD: gsplat_v1_renderer.py:287): present before any
+        # backward, and exactly the splats some pixel composites — checked against the per-splat hit-pixel counts of the same
+        # lists (gspl_composite_scores, itself checked against the oracle in tests/test_scores.py)
+        from gspl_amd import ops
+        acc = out["acc_vis"]
+        assert acc is not None and acc.dtype == torch.bool and acc.shape == (N,)
+        _, _, flat, offs = out["isects"]
+        _, m2, _, conics, _ = out["projections"]
+        count = ops.composite_scores(m2.reshape(N, 2), conics.reshape(N, 3), out["opacities"].reshape(N), W, H, 16, offs, flat)[0]
+        assert torch.equal(acc, count > 0)
+        assert not bool((acc & ~out["visibility_filter"]).any()) and 0 < int(acc.sum()) < int(out["visibility_filter"].sum())
 
 
 def test_hip_gsplat_renderer_depth_types():
