@@ -41,7 +41,7 @@ def _cam_tensors(cam):
     return vm, K
 
 
-from hip_helpers import assert_close_scaled, hip_composite_bwd, hip_composite_fwd, t32  # noqa: E402
+from hip_helpers import assert_pixels_close, assert_close_scaled, hip_composite_bwd, hip_composite_fwd, t32  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------
@@ -64,13 +64,13 @@ def test_projection_vs_reference_golden(hip, golden_dir, cam):
     assert np.array_equal(tiles.cpu().numpy()[same], z[p + "tiles"][same])
     np.testing.assert_allclose(xys.detach().cpu().numpy(), z[p + "xys"], rtol=1e-5, atol=2e-3)
     np.testing.assert_allclose(depths.detach().cpu().numpy(), z[p + "depths"], rtol=1e-5, atol=1e-6)
-    assert_close_scaled(conics.detach().cpu().numpy(), z[p + "conics"], 2e-4, "conics", frac_ok=0.999)
+    assert_close_scaled(conics.detach().cpu().numpy(), z[p + "conics"], 2e-4, "conics", frac_ok=0.999, rel_all=5e-2)
     np.testing.assert_allclose(comp.detach().cpu().numpy(), z[p + "comp"], rtol=2e-4, atol=1e-6)
     loss = (xys * t32(z[p + "w_xy"])).sum() + (depths * t32(z[p + "w_d"])).sum() + (conics * t32(z[p + "w_c"])).sum() \
         + (comp * t32(z[p + "w_k"])).sum()
     loss.backward()
     for got, name in ((means.grad, "g_means"), (scales.grad, "g_scales"), (quats.grad, "g_quats")):
-        assert_close_scaled(got.cpu().numpy(), z[p + name], 3e-4, name, frac_ok=0.998)
+        assert_close_scaled(got.cpu().numpy(), z[p + name], 3e-4, name, frac_ok=0.998, rel_all=5e-2)
 
 
 def test_projection_known_answer_vector(hip, golden_dir):
@@ -110,12 +110,12 @@ def test_projection_vs_oracle_fp64_batched_cameras(hip):
         same = rad.numpy() == radii[ci].cpu().numpy()
         assert same.mean() > 0.999
         np.testing.assert_allclose(means2d[ci].detach().cpu().numpy()[same], xys.detach().numpy()[same], rtol=1e-5, atol=2e-3)
-        assert_close_scaled(conics[ci].detach().cpu().numpy()[same], con.detach().numpy()[same], 2e-4, "conics", 0.999)
+        assert_close_scaled(conics[ci].detach().cpu().numpy()[same], con.detach().numpy()[same], 2e-4, "conics", 0.999, rel_all=5e-2)
         loss = loss + (xys * ws[0][ci].double()).sum() + (dep * ws[1][ci].double()).sum() \
             + (con * ws[2][ci].double()).sum() + (cmp_ * ws[3][ci].double()).sum()
     loss.backward()
     for got, ref, name in ((m.grad, md.grad, "means"), (s.grad, sd.grad, "scales"), (q.grad, qd.grad, "quats")):
-        assert_close_scaled(got.cpu().numpy(), ref.numpy(), 3e-4, name, frac_ok=0.998)
+        assert_close_scaled(got.cpu().numpy(), ref.numpy(), 3e-4, name, frac_ok=0.998, rel_all=5e-2)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -430,7 +430,11 @@ def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
     keep = ref["fragile_g"] == 0
     assert keep.mean() > 0.9            # splats touching a fragile pixel are excused (a pixel touches many splats)
     for k in ("v_means2d", "v_means2d_abs", "v_conics", "v_colors", "v_opacities"):
-        assert_close_scaled(got[k].cpu().numpy()[keep], ref[k][keep], 1e-4, f"{k} mode={mode} D={D}", frac_ok=0.9995)
+        assert_close_scaled(got[k].cpu().numpy()[keep], ref[k][keep], 1e-4, f"{k} mode={mode} D={D}", frac_ok=0.9995, rel_all=2e-3)
+        # the excused splats (they touch a pixel whose skip / stop decision sits within 2e-5 of its threshold) are bounded too
+        assert_close_scaled(got[k].cpu().numpy(), ref[k], 1e-4, f"{k} mode={mode} D={D} incl. fragile", frac_ok=0.9, rel_all=5e-2)
+    # ... and so are the fragile pixels of the forward
+    assert np.abs(out.cpu().numpy() - out_ref).max() <= 1e-3
     # hit flags (the fork's `has_hit_any_pixels`): a splat some pixel composited has a colour weight alpha*T > 0 there, so with a
     # random dL/dout its oracle colour gradient is non-zero — and zero for every splat no pixel took
     hit = got["hit"].cpu().numpy().astype(bool)
@@ -513,11 +517,11 @@ def test_end_to_end_gsplat_api(hip):
     r = O.render_gsplat(*dl, 3, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W, H,
                         bg.double(), cam["camera_center"].double())
     (r["render"] * wimg.double()).sum().backward()
-    diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
-    assert np.mean(diff <= 1e-5) > 0.999, diff.max()       # a radius/ceil or fragile flip touches a few pixels
+    # a radius/ceil or fragile flip touches a few pixels: >= 99.9 % within 1e-5, ALL within 4e-3
+    assert_pixels_close(render.detach().cpu().numpy(), r["render"].detach().numpy())
     assert np.array_equal((radii > 0).cpu().numpy(), r["mask"].numpy())
     for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
-        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995)
+        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=0.5)
 
 
 def test_end_to_end_inria_api(hip):
@@ -537,14 +541,13 @@ def test_end_to_end_inria_api(hip):
     r = O.render_inria(*dl, 3, cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
                        cam["tanfovx"], cam["tanfovy"], W, H, bg.double())
     (r["render"] * wimg.double()).sum().backward()
-    diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
-    assert np.mean(diff <= 1e-5) > 0.999, diff.max()
+    assert_pixels_close(render.detach().cpu().numpy(), r["render"].detach().numpy())
     assert np.mean(radii.cpu().numpy() == r["radii"].numpy()) > 0.999
     for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
-        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995)
+        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=0.5)
     # viewspace gradient in Inria units: pixel gradient * 0.5 * (W, H)
     ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * W, 0.5 * H])
-    assert_close_scaled(screen.grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995)
+    assert_close_scaled(screen.grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995, rel_all=0.5)
     assert torch.all(screen.grad[:, 2] == 0)
 
 
@@ -627,8 +630,8 @@ def test_inria_api_precomputed_cov3d_and_colors_and_scale_modifier(hip):
     cv = O.cov3d_from_scale_rot(sd, mod, qd)
     cv6 = torch.stack([cv[:, 0, 0], cv[:, 0, 1], cv[:, 0, 2], cv[:, 1, 1], cv[:, 1, 2], cv[:, 2, 2]], -1)
     (cv6 * cov6.grad.cpu().double()).sum().backward()
-    assert_close_scaled(sd.grad.numpy(), s.grad.cpu().numpy(), 2e-4, "scales via cov3D_precomp", frac_ok=0.995)
-    assert_close_scaled(qd.grad.numpy(), q.grad.cpu().numpy(), 2e-4, "quats via cov3D_precomp", frac_ok=0.995)
+    assert_close_scaled(sd.grad.numpy(), s.grad.cpu().numpy(), 2e-4, "scales via cov3D_precomp", frac_ok=0.995, rel_all=0.5)
+    assert_close_scaled(qd.grad.numpy(), q.grad.cpu().numpy(), 2e-4, "quats via cov3D_precomp", frac_ok=0.995, rel_all=0.5)
 
     # (b) colors_precomp == SH evaluated outside; gradient flows to the colours
     rgbs = O.sh_colors(3, shs.double(), means.double(), cam["camera_center"].double(), detach_dirs=True).float()

@@ -7,7 +7,7 @@ import torch
 
 from oracle import gsplat_oracle as O
 from fakes import FakeCamera, FakeGaussianModel
-from hip_helpers import assert_close_scaled
+from hip_helpers import assert_close_scaled, assert_pixels_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -37,8 +37,7 @@ def _oracle_grads(api, params, cam, wimg, bg):
 
 
 def _check(model, dl, render, r, quats_normalised_by_renderer=False):
-    diff = np.abs(render.detach().cpu().numpy() - r["render"].detach().numpy())
-    assert np.mean(diff <= 1e-5) > 0.999, diff.max()
+    assert_pixels_close(render.detach().cpu().numpy(), r["render"].detach().numpy())      # 99.9 % within 1e-5, all within 4e-3
     shs_grad = torch.cat([model.shs_dc.grad, model.shs_rest.grad], dim=1)
     for got, ref, name in zip([model.means.grad, model.scales_.grad, model.rotations_.grad, model.opacities_.grad, shs_grad], dl,
                               ("means", "scales", "quats", "opacities", "shs")):
@@ -47,7 +46,7 @@ def _check(model, dl, render, r, quats_normalised_by_renderer=False):
             # GSPlatRenderer divides the rotations by their norm (gsplat_renderer.py:68): the radial part vanishes
             q = ref.detach()
             ref_g = (ref_g - q * (q * ref_g).sum(-1, keepdim=True)) / q.norm(dim=-1, keepdim=True)
-        assert_close_scaled(got.cpu().numpy(), ref_g.numpy(), 1e-4, name, frac_ok=0.995)
+        assert_close_scaled(got.cpu().numpy(), ref_g.numpy(), 1e-4, name, frac_ok=0.995, rel_all=0.5)
 
 
 def test_hip_vanilla_renderer_contract_and_parity():
@@ -67,7 +66,7 @@ def test_hip_vanilla_renderer_contract_and_parity():
     r, dl = _oracle_grads("inria", params, cam, wimg, bg)
     _check(model, dl, out["render"], r)
     ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * cam["width"], 0.5 * cam["height"]])
-    assert_close_scaled(out["viewspace_points"].grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace grad", 0.995)
+    assert_close_scaled(out["viewspace_points"].grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace grad", 0.995, rel_all=0.5)
     # depth render type (override colour path)
     d = renderer(camera, model, bg.to(DEV), render_types=["depth"])
     assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].detach().max()) > 0
@@ -114,7 +113,7 @@ def test_hip_gsplat_renderers_contract_and_parity(which):
     r, dl = _oracle_grads("gsplat", params, cam, wimg, bg)
     _check(model, dl, out["render"], r, quats_normalised_by_renderer=(which == "v0"))
     vp = out["viewspace_points"]
-    assert_close_scaled(vp.grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", 0.995)
+    assert_close_scaled(vp.grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", 0.995, rel_all=0.5)
     assert hasattr(vp, "absgrad") and torch.all(vp.absgrad >= vp.grad.abs() - 1e-6)
     if which != "v0":
         # `acc_vis` (the fork's has_hit_any_pixels, set by the rasterizer FORWARD: gsplat_v1_renderer.py:287): present before any
@@ -175,7 +174,7 @@ def test_distributed_renderer_world1_matches_v1():
     (out["render"] * wimg.to(DEV)).sum().backward()
     (ref["render"] * wimg.to(DEV)).sum().backward()
     for a, b in zip(m2.leaves(), m1.leaves()):
-        assert_close_scaled(a.grad.cpu().numpy(), b.grad.cpu().numpy(), 2e-5, "grad", frac_ok=0.999)
+        assert_close_scaled(a.grad.cpu().numpy(), b.grad.cpu().numpy(), 2e-5, "grad", frac_ok=0.999, rel_all=1e-3)
     xys = out["projection_results_list"][0][1]
     assert xys.grad is not None and xys.grad.shape == (params[0].shape[0], 2)
 
