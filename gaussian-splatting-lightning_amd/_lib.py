@@ -57,6 +57,7 @@ _SIGNATURES = {
     "gspl_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, _P, _P]),
     "gspl_bin_workspace_bytes": (c_size_t, [c_int, c_int64]),
+    "gspl_sort_force_ticket": (c_int, [c_int]),
     "gspl_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gspl_loss_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_loss_photometric_fwd": (c_int, [c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),

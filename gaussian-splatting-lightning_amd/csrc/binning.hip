@@ -11,13 +11,12 @@
 //
 // Roofline: HBM-bound.  Emit: 16 B read per visible Gaussian + 12 B written per intersection.
 // Sort: 12 B x I x 2 x ceil(bits/8) with bits = 32 + ceil(log2(tiles)).
-// The scan and the sort are rocPRIM device primitives (header-only, compiled here for gfx950);
-// only the significant key bits are sorted.
+// Scans and sorts are the in-tree one-sweep kernels of sort.hip (gspl_sort.h) on every path and at every size; only the
+// significant key bits are sorted.
 #include <cstring>
 #include <cstdlib>
 #include "gspl_device.h"
 #include "gspl_host.h"
-#include <rocprim/rocprim.hpp>
 #include "gspl_sort.h"
 #include "gspl_sort_device.h"
 
@@ -45,7 +44,7 @@ __device__ __forceinline__ void tile_rect(float x, float y, int radius, int tile
 template <int MODE>
 __global__ __launch_bounds__(256) void isect_count_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    int tile_size, int tile_w, int tile_h, int32_t* __restrict__ tiles_per_gauss, int64_t* __restrict__ counts64) {
+    int tile_size, int tile_w, int tile_h, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ counts32) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
     int n = 0;
@@ -56,7 +55,7 @@ __global__ __launch_bounds__(256) void isect_count_kernel(
         n = max(maxx - minx, 0) * max(maxy - miny, 0);
     }
     tiles_per_gauss[g] = n;
-    counts64[g] = n;
+    counts32[g] = n;
 }
 
 template <int MODE>
@@ -99,12 +98,6 @@ __global__ __launch_bounds__(256) void isect_offsets_kernel(
     }
 }
 
-__global__ void fill_i64_kernel(int64_t* p, int64_t v) { *p = v; }
-__global__ __launch_bounds__(256) void bin_big_list_kernel(int N, const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
-                                                           int32_t* __restrict__ big_list, unsigned long long* __restrict__ n_big) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N && counts[order[i]] < 0) big_list[atomicAdd(n_big, 1ull)] = i;
-}
 __global__ void fill_i32_kernel(int n, int32_t v, int32_t* __restrict__ p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -118,27 +111,34 @@ static inline int key_bits(int n_tiles) {
     return 32 + b;
 }
 
+// 64-bit keyed path (isect_tiles API): counts (i32) | scan states | keys + values scratch | two sort plans (the key has up to
+// 32 + log2(tiles) significant bits: sorted as [0, 24) then [24, bits), three passes each at most)
+static constexpr int ISECT_MAX_KEY_BITS = 56;      // 32 depth bits + up to 2^24 tiles
 struct IsectWorkspace {
-    size_t counts_off, scan_tmp_off, scan_tmp_bytes;
-    size_t keys_off, vals_off, sort_tmp_off, sort_tmp_bytes;
-    size_t total;
+    size_t counts_off, scan_off, keys_off, vals_off, sort_off, sort_bytes;
+    size_t total_count, total;
+    RadixPlan lo, hi;
+    bool two_sorts;
 };
 
-static int plan_workspace(int N, int64_t n_isects, IsectWorkspace& w) {
-    size_t scan_tmp = 0, sort_tmp = 0;
-    hipError_t e = rocprim::inclusive_scan(nullptr, scan_tmp, (const int64_t*)nullptr, (int64_t*)nullptr, (size_t)(N > 0 ? N : 1),
-                                           rocprim::plus<int64_t>(), (hipStream_t)0);
-    if (e != hipSuccess) return check_hip(e, "isect: scan size query");
-    const size_t ni = (size_t)(n_isects > 0 ? n_isects : 1);
-    e = rocprim::radix_sort_pairs(nullptr, sort_tmp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, ni, 0, 64, (hipStream_t)0);
-    if (e != hipSuccess) return check_hip(e, "isect: sort size query");
+static int plan_workspace(int N, int64_t n_isects, int key_bits_total, IsectWorkspace& w) {
+    const size_t n = (size_t)(N > 0 ? N : 1), ni = (size_t)(n_isects > 0 ? n_isects : 1);
+    if (ni > RADIX_MAX_ITEMS || n > RADIX_MAX_ITEMS) { set_error("isect", "more than 2^30-1 items"); return GSPL_ERR_UNSUPPORTED; }
     size_t off = 0;
-    w.counts_off = off; off = align_up(off + sizeof(int64_t) * (size_t)(N > 0 ? N : 1), 256);
-    w.scan_tmp_off = off; w.scan_tmp_bytes = scan_tmp; off = align_up(off + scan_tmp, 256);
-    w.keys_off = off; off = align_up(off + sizeof(uint64_t) * ni, 256);
-    w.vals_off = off; off = align_up(off + sizeof(uint32_t) * ni, 256);
-    w.sort_tmp_off = off; w.sort_tmp_bytes = sort_tmp; off = align_up(off + sort_tmp, 256);
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.counts_off = take(4 * n);
+    w.scan_off = take(scan_state_bytes(n) + 64);          // states + one counter word
+    w.total_count = off;
+    w.keys_off = take(8 * ni);
+    w.vals_off = take(4 * ni);
+    const int split = key_bits_total > 32 ? 24 : 0;
+    w.two_sorts = key_bits_total > 32;
+    bool ok = true;
+    if (w.two_sorts) ok = radix_plan(ni, 0, split, 8, RADIX_TILE_U64, w.lo) && radix_plan(ni, split, key_bits_total, 8, RADIX_TILE_U64, w.hi);
+    else ok = radix_plan(ni, 0, key_bits_total, 8, RADIX_TILE_U64, w.lo);
+    if (!ok) { set_error("isect", "key bits not representable"); return GSPL_ERR_UNSUPPORTED; }
+    w.sort_bytes = w.lo.total_bytes > (w.two_sorts ? w.hi.total_bytes : 0) ? w.lo.total_bytes : w.hi.total_bytes;
+    w.sort_off = take(w.sort_bytes);
     w.total = off;
     return GSPL_OK;
 }
@@ -304,12 +304,6 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
     }
 }
 
-// counts[order[i]] as int64: the input "array" of the scan over per-splat tile counts in depth order (no gather pass)
-struct GatherCount {
-    const int32_t* counts;
-    __device__ int64_t operator()(uint32_t g) const { return (int64_t)(counts[g] & 0x7fffffff); }
-};
-
 // Load-balanced emission.  A lane-per-splat loop would let every lane write its own run of records (8 B stores 30-60 B
 // apart: partial-line writes, and one huge splat serialises a whole wave).  Here a wave owns 64 consecutive splats of
 // the depth order = one CONTIGUOUS output range; lanes walk that range in stride (coalesced 8-B stores) and find the
@@ -330,7 +324,18 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, const int32_t* __restrict__ big_list,
-    int tile_size, int tile_w, int tile_h, uint64_t* __restrict__ tile_keys, int64_t capacity) {
+    int tile_size, int tile_w, int tile_h, uint64_t* __restrict__ tile_keys, int64_t capacity, RadixHeader hdr) {
+    // the kernel also prepares the tile sort (gspl_sort_device.h): digit histograms of the tile ids it writes, rows cleared
+    __shared__ uint32_t s_hist[RADIX_MAX_PASSES * RADIX_BINS];
+    radix_hist_clear(s_hist);
+    radix_states_clear(hdr, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+    __syncthreads();
+    // consecutive output slots carry different tile ids: one LDS atomic per record and pass (no wave-uniform shortcut)
+    auto count_tile = [&](uint32_t tile_id) {
+#pragma unroll
+        for (int p = 0; p < RADIX_MAX_PASSES; ++p)
+            if (p < hdr.passes) atomicAdd(&s_hist[p * RADIX_BINS + ((tile_id >> (hdr.shift[p] - 32)) & hdr.mask[p])], 1u);
+    };
     __shared__ int s_start[4][65];
     __shared__ int s_out[4][64];
     __shared__ uint32_t s_gid[4][64];
@@ -404,8 +409,11 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
             const int tx = (int)s_c0[w][o][r] + kk - (int)s_pre[w][o][r];
             const int ty = s_row0[w][o] + r;
             const int64_t out = wave_base + s_out[w][o] + kk;
-            if (out < capacity)      // a speculative launch may have guessed the list length too low (the host redoes it)
-                tile_keys[out] = ((uint64_t)(uint32_t)(ty * tile_w + tx) << 32) | s_gid[w][o];
+            if (out < capacity) {    // a speculative launch may have guessed the list length too low (the host redoes it)
+                const uint32_t tile_id = (uint32_t)(ty * tile_w + tx);
+                tile_keys[out] = ((uint64_t)tile_id << 32) | s_gid[w][o];
+                count_tile(tile_id);
+            }
         }
     }
     // ---- phase B: the big splats of the whole frame, dealt out to the workgroups -------------------------------------------
@@ -414,11 +422,10 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     // by the scan of the counts.  All 256 threads work on one splat: rows in chunks of 256 (one per thread: exact column
     // span, scan), then every output slot of the chunk by one thread (row by binary search in the chunk's prefix).
     const int n_big = (int)cum_sorted[N];
-    if ((int)blockIdx.x >= n_big) return;              // uniform per workgroup
     __shared__ int s_bpre[257];
     __shared__ int s_bc0[256];
     __shared__ int s_bwave[4];
-    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {      // (uniform per workgroup)
         const int bi = big_list[b];
         const int g = (int)order[bi];
         int64_t out = (bi == 0) ? 0 : cum_sorted[bi - 1];
@@ -449,104 +456,48 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
 #pragma unroll
                 for (int step = 128; step > 0; step >>= 1) r += (k >= s_bpre[r + step]) ? step : 0;
                 const int tx = s_bc0[r] + k - s_bpre[r];
-                if (out + k < capacity) tile_keys[out + k] = ((uint64_t)(uint32_t)((rbase + r) * tile_w + tx) << 32) | (uint32_t)g;
+                if (out + k < capacity) {
+                    const uint32_t tile_id = (uint32_t)((rbase + r) * tile_w + tx);
+                    tile_keys[out + k] = ((uint64_t)tile_id << 32) | (uint32_t)g;
+                    count_tile(tile_id);
+                }
             }
             out += total;
         }
     }
+    __syncthreads();
+    radix_hist_flush(s_hist, hdr);
 }
-
-__global__ __launch_bounds__(256) void bin_offsets_kernel(int64_t n_isects, const uint64_t* __restrict__ keys, int n_tiles,
-                                                          int32_t* __restrict__ offsets, int32_t* __restrict__ flatten_ids) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_isects) return;
-    const uint64_t rec = keys[i];
-    flatten_ids[i] = (int32_t)(uint32_t)rec;
-    const int cur = (int)(rec >> 32);
-    if (i == 0) {
-        for (int t = 0; t <= cur && t < n_tiles; ++t) offsets[t] = 0;
-    } else {
-        const int prev = (int)(keys[i - 1] >> 32);
-        for (int t = prev + 1; t <= cur && t < n_tiles; ++t) offsets[t] = (int32_t)i;
-    }
-    if (i == n_isects - 1)
-        for (int t = cur + 1; t < n_tiles; ++t) offsets[t] = (int32_t)n_isects;
-}
-
-// rocPRIM tuning (swept on MI355X, S-1080p-1M: 8 variants, tools/bench_stages.sh).  The library default switches to a
-// merge sort below 2^20 items (20 small merge launches for the 1 M-splat depth sort, 0.15 ms): both sorts are forced
-// onto the onesweep radix path, with 1024-thread blocks of few items per thread (more blocks in flight) and 7-bit
-// digits for the 13-bit tile sort.  bin_count 0.20 -> 0.14 ms, bin_emit_sort 0.37 -> 0.31 ms.
-#ifndef GSPL_TS_BITS
-#define GSPL_TS_BITS 7
-#endif
-#ifndef GSPL_TS_SB
-#define GSPL_TS_SB 1024
-#endif
-#ifndef GSPL_TS_SI
-#define GSPL_TS_SI 8
-#endif
-#ifndef GSPL_DS_SB
-#define GSPL_DS_SB 1024
-#endif
-#ifndef GSPL_DS_BITS
-#define GSPL_DS_BITS 8
-#endif
-#ifndef GSPL_DS_SI
-#define GSPL_DS_SI 4
-#endif
-using DepthSortCfg = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 8>, rocprim::kernel_config<GSPL_DS_SB, GSPL_DS_SI>, GSPL_DS_BITS,
-                                        rocprim::block_radix_rank_algorithm::match>,
-    32 * 1024>;
-using TileSortCfg = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 32>, rocprim::kernel_config<GSPL_TS_SB, GSPL_TS_SI>, GSPL_TS_BITS,
-                                        rocprim::block_radix_rank_algorithm::match>,
-    32 * 1024>;
 
 struct BinWorkspace {
-    size_t keys_off, ids_off, keys2_off, counts_off, scan_tmp_off, scan_tmp_bytes, sort1_tmp_off, sort1_tmp_bytes;
-    size_t tkeys_off, tvals_off, tkeys2_off, sort2_tmp_off, sort2_tmp_bytes;
-    size_t total_count, total, scan_states_off;
-    bool own_depth_sort;
+    size_t keys_off, ids_off, keys2_off, counts_off, sort1_off, sort1_bytes, scan_states_off;
+    size_t tkeys_off, tkeys2_off, sort2_off, sort2_bytes;
+    size_t total_count, total;
+    RadixPlan depth, tile;
 };
 
-static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
+// Workspace of the list-only binning.  Count half: depth keys / ids (x2 for the ping-pong), counts, the depth sort's header and
+// look-back rows followed by the scan's state words.  Emit/sort half (sized by the list length or a guess of it): the 8-byte
+// records (x2) and the tile sort's header and rows.
+static int plan_bin(int N, int64_t n_isects, int n_tiles, BinWorkspace& w) {
     const size_t n = (size_t)(N > 0 ? N : 1), ni = (size_t)(n_isects > 0 ? n_isects : 1);
-    size_t scan_tmp = 0, s1 = 0, s2 = 0;
-    hipError_t e = rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator((const uint32_t*)nullptr, GatherCount{nullptr}),
-                                           (int64_t*)nullptr, n, rocprim::plus<int64_t>(), (hipStream_t)0);
-    if (e != hipSuccess) return check_hip(e, "bin: scan size query");
-    e = rocprim::radix_sort_pairs<DepthSortCfg>(nullptr, s1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
-    if (e != hipSuccess) return check_hip(e, "bin: sort1 size query");
-    e = rocprim::radix_sort_keys<TileSortCfg>(nullptr, s2, (const uint64_t*)nullptr, (uint64_t*)nullptr, ni, 32, 64, (hipStream_t)0);
-    if (e != hipSuccess) return check_hip(e, "bin: sort2 size query");
+    if (n > RADIX_MAX_ITEMS || ni > RADIX_MAX_ITEMS) { set_error("bin", "more than 2^30-1 splats or intersections"); return GSPL_ERR_UNSUPPORTED; }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     w.keys_off = take(4 * n); w.ids_off = take(4 * n); w.keys2_off = take(4 * n);
     w.counts_off = take(4 * n);
-    w.scan_tmp_bytes = scan_tmp; w.scan_tmp_off = take(scan_tmp);
-    // depth sort: own one-sweep sort (gspl_sort.h) or rocPRIM
-    RadixPlan dp;
-    // own sort + scan while all tiles fit the device at once (~1 M splats); beyond, tiles would be drawn from a counter and the
-    // library's larger tiles win (measured at 6 M splats: 137 us per pass and a 132 us scan against ~100 and ~50)
-    w.own_depth_sort = radix_plan(n, 0, 32, 8, RADIX_TILE_U32, dp) && radix_sort_u32_is_single_wave_of_tiles(n);
-#ifdef GSPL_ROCPRIM_DEPTH_SORT
-    w.own_depth_sort = false;
-#endif
-    // ... followed by the state words of the one-launch scan of the counts (cleared by the key pass with the sort's rows)
-    w.scan_states_off = 0;
-    if (w.own_depth_sort) {
-        w.scan_states_off = dp.total_bytes;
-        const size_t need = dp.total_bytes + scan_state_bytes(n);
-        if (need > s1) s1 = need;
-    }
-    w.sort1_tmp_bytes = s1; w.sort1_tmp_off = take(s1);
+    if (!radix_plan(n, 0, 32, 8, RADIX_TILE_U32, w.depth)) return fail_arg("bin: depth sort plan");
+    w.scan_states_off = w.depth.total_bytes;          // the scan's state words follow the sort's rows (one clear covers both)
+    w.sort1_bytes = w.depth.total_bytes + scan_state_bytes(n);
+    w.sort1_off = take(w.sort1_bytes);
     w.total_count = off;
-    w.tkeys_off = take(8 * ni); w.tvals_off = w.tkeys_off; w.tkeys2_off = take(8 * ni);
-    w.sort2_tmp_bytes = s2; w.sort2_tmp_off = take(s2);
+    w.tkeys_off = take(8 * ni); w.tkeys2_off = take(8 * ni);
+    // n_tiles <= 0: size query (the tile grid is not known to gspl_bin_workspace_bytes) -> the widest plan, four passes
+    int bits = n_tiles > 0 ? key_bits(n_tiles) - 32 : 32;
+    if (bits < 2) bits = 2;                             // at least two passes: the pass before the last clears the tile counters
+    if (!radix_plan(ni, 32, 32 + bits, bits > 8 ? 8 : (bits + 1) / 2, RADIX_TILE_U64, w.tile) || w.tile.passes < 2) return fail_arg("bin: tile sort plan");
+    w.sort2_bytes = w.tile.total_bytes;
+    w.sort2_off = take(w.sort2_bytes);
     w.total = off;
     return GSPL_OK;
 }
@@ -555,7 +506,7 @@ static int plan_bin(int N, int64_t n_isects, BinWorkspace& w) {
 
 extern "C" size_t gspl_bin_workspace_bytes(int N, int64_t n_isects) {
     gspl::BinWorkspace w;
-    if (gspl::plan_bin(N, n_isects, w) != GSPL_OK) return 0;
+    if (gspl::plan_bin(N, n_isects, 0, w) != GSPL_OK) return 0;
     return n_isects > 0 ? w.total : w.total_count;
 }
 
@@ -572,7 +523,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     if (tile_w > 65535 || tile_h > 65535) { set_error("bin_count", "more than 65535 tile rows or columns"); return GSPL_ERR_UNSUPPORTED; }
     if ((conics == nullptr) != (opacities == nullptr)) return fail_arg("bin_count: conics and opacities go together");
     BinWorkspace w;
-    int rc = plan_bin(N, 0, w);
+    int rc = plan_bin(N, 0, tile_w * tile_h, w);
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total_count) return fail_ws("bin_count");
     static_assert(GSPL_BIN_SPAN_BYTES == 2 * sizeof(SpanRecord), "spans = N primary + N extension records");
@@ -583,62 +534,42 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     int32_t* counts = (int32_t*)(ws + w.counts_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
-    size_t tmp = w.sort1_tmp_bytes;
-    hipError_t e = hipSuccess;
-    if (w.own_depth_sort) {
-        // Own one-sweep sort, prepared by the key pass itself.  Four 8-bit passes: the sorted sequence ends where it
-        // started, so the key pass writes the ids straight into `order`.
-        RadixPlan dp;
-        radix_plan((size_t)N, 0, 32, 8, RADIX_TILE_U32, dp);
-        RadixHeader hdr;
-        radix_header_args(dp, ws + w.sort1_tmp_off, hdr);
-        hdr.state_vec4 = (uint32_t)((dp.total_bytes - dp.states_off + scan_state_bytes((size_t)N)) / 16);      // + the scan's words
-        e = hipMemsetAsync(ws + w.sort1_tmp_off + dp.hist_off, 0, dp.header_bytes, s);
-        if (e != hipSuccess) return check_hip(e, "bin_count: histogram clear");
-        if (mode == GSPL_MODE_GSPLAT)
-            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
-        else
-            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_INRIA, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
-        rc = check_launch("bin_keys");
-        if (rc != GSPL_OK) return rc;
-        uint32_t* const kbuf[2] = {keys, keys2};
-        uint32_t* const vbuf[2] = {(uint32_t*)order, ids};
-        rc = radix_sort_u32(dp, ws + w.sort1_tmp_off, kbuf, vbuf, true, s);
-        if (rc != GSPL_OK) return rc;
-    } else {
-        RadixHeader hdr = {};
-        if (mode == GSPL_MODE_GSPLAT)
-            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, false>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans, hdr);
-        else
-            hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_INRIA, false>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, ids, counts, (SpanRecord*)spans, hdr);
-        rc = check_launch("bin_keys");
-        if (rc != GSPL_OK) return rc;
-        e = rocprim::radix_sort_pairs<DepthSortCfg>(ws + w.sort1_tmp_off, tmp, keys, keys2, ids, (uint32_t*)order, (size_t)N, 0, 32, s);
-        if (e != hipSuccess) return check_hip(e, "bin_count: depth sort");
-    }
-    if (w.own_depth_sort)
-    {
-        RadixPlan dp;
-        radix_plan((size_t)N, 0, 32, 8, RADIX_TILE_U32, dp);
-        // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte
-        // read-back gives the host both numbers
-        return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_tmp_off + w.scan_states_off,
-                                    (uint32_t*)(ws + w.sort1_tmp_off + dp.ticket_off) + RADIX_MAX_PASSES, big_list, s);
-    }
-    tmp = w.scan_tmp_bytes;
-    e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp,
-                                rocprim::make_transform_iterator((const uint32_t*)order, GatherCount{counts}), cum_tiles, (size_t)N,
-                                rocprim::plus<int64_t>(), s);
-    if (e != hipSuccess) return check_hip(e, "bin_count: inclusive_scan");
-    // big splats of this (library scan) path: listed in any order — each finds its output range through cum_tiles
-    hipLaunchKernelGGL(fill_i64_kernel, dim3(1), dim3(1), 0, s, cum_tiles + N, (int64_t)0);
-    hipLaunchKernelGGL(bin_big_list_kernel, dim3(grid), dim3(256), 0, s, N, (const uint32_t*)order, counts, big_list, (unsigned long long*)(cum_tiles + N));
-    return check_launch("bin_count(big list)");
+    // Depth sort on the own one-sweep sort, prepared by the key pass itself (digit histograms, cleared look-back rows).  Four
+    // 8-bit passes: the sorted sequence ends where it started, so the key pass writes the ids straight into `order`.
+    const RadixPlan& dp = w.depth;
+    RadixHeader hdr;
+    radix_header_args(dp, ws + w.sort1_off, hdr);
+    hdr.state_vec4 = (uint32_t)((dp.total_bytes - dp.states_off + scan_state_bytes((size_t)N)) / 16);      // + the scan's words
+    hipError_t e = hipMemsetAsync(ws + w.sort1_off + dp.hist_off, 0, dp.header_bytes, s);
+    if (e != hipSuccess) return check_hip(e, "bin_count: histogram clear");
+    if (mode == GSPL_MODE_GSPLAT)
+        hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
+    else
+        hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_INRIA, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
+    rc = check_launch("bin_keys");
+    if (rc != GSPL_OK) return rc;
+    uint32_t* const kbuf[2] = {keys, keys2};
+    uint32_t* const vbuf[2] = {(uint32_t*)order, ids};
+    rc = radix_sort_u32(dp, ws + w.sort1_off, kbuf, vbuf, true, s);
+    if (rc != GSPL_OK) return rc;
+    // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many, and copies the sorts'
+    // error word to cum_tiles[N + 1] — one 24-byte read-back gives the host the list length, the big count and the health
+    uint32_t* ctr = (uint32_t*)(ws + w.sort1_off + dp.ticket_off);
+    return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off,
+                                ctr + RADIX_MAX_PASSES, big_list, ctr + RADIX_ERR_WORD, s);
+}
+
+// Process-wide switch of every sort and scan to tiles drawn from a counter (what the host does after cum_tiles[N + 1] reported a
+// look-back time-out; also GSPL_SORT_FORCE_TICKET=1).
+extern "C" int gspl_sort_force_ticket(int on) {
+    gspl::radix_force_ticket(on != 0);
+    return GSPL_OK;
 }
 
 // Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has
 // room for: it may be a GUESS of the list length, launched before the host knows the real one — records past it are
 // dropped, and the caller repeats the call with the real length when the guess was too low.
+// The kernel also prepares the tile sort: digit histograms of the records it writes, look-back rows cleared.
 extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                              const float* conics, const float* opacities,
                              const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
@@ -651,20 +582,30 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     if (capacity > 0x7fffffffll) return fail_arg("bin_emit: more than 2^31-1 intersections");
     if (!means2d || !radii || !order || !cum_tiles || !big_list || !spans || !workspace) return fail_arg("bin_emit: NULL required pointer");
     BinWorkspace w;
-    int rc = plan_bin(N, capacity, w);
+    int rc = plan_bin(N, capacity, tile_w * tile_h, w);
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total) return fail_ws("bin_emit");
-    uint64_t* tkeys = (uint64_t*)((char*)workspace + w.tkeys_off);
+    char* ws = (char*)workspace;
+    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
+    // the tile sort's header for a list of `capacity` records: the real list is not longer (else the emission is repeated), so its
+    // look-back rows lie inside the cleared range; the histograms count exactly the records written
+    RadixHeader hdr;
+    radix_header_args(w.tile, ws + w.sort2_off, hdr);
+    hdr.state_vec4 = (uint32_t)((w.tile.total_bytes - w.tile.states_off) / 16);
+    hipError_t e = hipMemsetAsync(ws + w.sort2_off + w.tile.hist_off, 0, w.tile.header_bytes, s);
+    if (e != hipSuccess) return check_hip(e, "bin_emit: histogram clear");
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity, hdr);
     else
-        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity);
+        hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity, hdr);
     return check_launch("bin_emit");
 }
 
 // Sort half: the first n_isects (<= capacity) records of the workspace gspl_bin_emit filled -> flatten_ids, offsets.
+// Two (for more than 65536 tiles: three) one-sweep passes on the tile id; the last one writes the splat ids alone and counts
+// the records per tile, a one-workgroup scan turns the counts into `offsets`.
 extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
                              int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gspl;
@@ -679,20 +620,17 @@ extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, in
     if (capacity > 0x7fffffffll) return fail_arg("bin_sort: more than 2^31-1 intersections");
     if (!flatten_ids || !workspace) return fail_arg("bin_sort: NULL required pointer");
     BinWorkspace w;
-    int rc = plan_bin(N, capacity, w);
+    int rc = plan_bin(N, capacity, n_tiles, w);       // the layout gspl_bin_emit used
     if (rc != GSPL_OK) return rc;
     if (workspace_bytes < w.total) return fail_ws("bin_sort");
     char* ws = (char*)workspace;
-    uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
-    uint64_t* tkeys2 = (uint64_t*)(ws + w.tkeys2_off);
-    size_t tmp = w.sort2_tmp_bytes;
-    const int bits = key_bits(n_tiles) - 32;
-    hipError_t e = rocprim::radix_sort_keys<TileSortCfg>(ws + w.sort2_tmp_off, tmp, tkeys, tkeys2, (size_t)n_isects, 32,
-                                            32 + (bits > 0 ? bits : 1), s);
-    if (e != hipSuccess) return check_hip(e, "bin_sort: tile sort");
-    const int64_t g2 = (n_isects + 255) / 256;
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3((unsigned)g2), dim3(256), 0, s, n_isects, (const uint64_t*)tkeys2, n_tiles, offsets, flatten_ids);
-    return check_launch("bin_offsets");
+    uint64_t* const tk[2] = {(uint64_t*)(ws + w.tkeys_off), (uint64_t*)(ws + w.tkeys2_off)};
+    // same bit split as the emission's histograms, tile count of the REAL list length
+    RadixPlan tp = w.tile;
+    radix_replan_items(tp, (size_t)n_isects);
+    rc = radix_sort_tiles(tp, ws + w.sort2_off, tk, true, (uint32_t*)flatten_ids, (uint32_t*)offsets, (uint32_t)n_tiles, s);
+    if (rc != GSPL_OK) return rc;
+    return tile_offsets_from_counts((uint32_t*)offsets, (uint32_t)n_tiles, s);
 }
 
 extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const int32_t* radii,
@@ -709,7 +647,7 @@ extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const i
 
 extern "C" size_t gspl_isect_workspace_bytes(int N, int64_t n_isects) {
     gspl::IsectWorkspace w;
-    if (gspl::plan_workspace(N, n_isects, w) != GSPL_OK) return 0;
+    if (gspl::plan_workspace(N, n_isects, gspl::ISECT_MAX_KEY_BITS, w) != GSPL_OK) return 0;      // sized for the widest key
     return w.total;
 }
 
@@ -723,22 +661,24 @@ extern "C" int gspl_isect_count(int N, int mode, const float* means2d, const int
     if (N == 0) return GSPL_OK;
     if (!means2d || !radii || !tiles_per_gauss || !cum_tiles || !workspace) return fail_arg("isect_count: NULL required pointer");
     IsectWorkspace w;
-    int rc = plan_workspace(N, 0, w);
+    int rc = plan_workspace(N, 0, ISECT_MAX_KEY_BITS, w);
     if (rc != GSPL_OK) return rc;
-    if (workspace_bytes < w.scan_tmp_off + w.scan_tmp_bytes) return fail_ws("isect_count");
+    if (workspace_bytes < w.total_count) return fail_ws("isect_count");
     char* ws = (char*)workspace;
-    int64_t* counts = (int64_t*)(ws + w.counts_off);
+    int32_t* counts = (int32_t*)(ws + w.counts_off);
     const int grid = (N + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ws + w.scan_off, 0, scan_state_bytes((size_t)N) + 64, s);
+    if (e != hipSuccess) return check_hip(e, "isect_count: state clear");
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL(isect_count_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, tile_size, tile_w, tile_h, tiles_per_gauss, counts);
     else
         hipLaunchKernelGGL(isect_count_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, tile_size, tile_w, tile_h, tiles_per_gauss, counts);
     rc = check_launch("isect_count");
     if (rc != GSPL_OK) return rc;
-    size_t tmp = w.scan_tmp_bytes;
-    hipError_t e = rocprim::inclusive_scan(ws + w.scan_tmp_off, tmp, counts, cum_tiles, (size_t)N, rocprim::plus<int64_t>(), s);
-    return check_hip(e, "isect_count: inclusive_scan");
+    // inclusive scan of the counts in memory order: the chained-look-back scan of sort.hip with the identity gather
+    uint32_t* ctr = (uint32_t*)(ws + w.scan_off + scan_state_bytes((size_t)N));
+    return scan_gathered_counts(nullptr, counts, cum_tiles, (size_t)N, ws + w.scan_off, ctr, nullptr, ctr + 1, s);
 }
 
 extern "C" int gspl_isect_emit_sort(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
@@ -752,25 +692,44 @@ extern "C" int gspl_isect_emit_sort(int N, int mode, const float* means2d, const
     if (n_isects > 0x7fffffffll) return fail_arg("isect_emit_sort: more than 2^31-1 intersections");
     if (!means2d || !radii || !depths || !cum_tiles || !isect_ids || !flatten_ids || !workspace) return fail_arg("isect_emit_sort: NULL required pointer");
     IsectWorkspace w;
-    int rc = plan_workspace(N, n_isects, w);
+    const int bits = key_bits(tile_w * tile_h);
+    int rc = plan_workspace(N, n_isects, bits, w);
     if (rc != GSPL_OK) return rc;
-    if (workspace_bytes < w.total) return fail_ws("isect_emit_sort");
+    IsectWorkspace wmax;
+    rc = plan_workspace(N, n_isects, ISECT_MAX_KEY_BITS, wmax);       // the size gspl_isect_workspace_bytes promised
+    if (rc != GSPL_OK) return rc;
+    if (workspace_bytes < wmax.total) return fail_ws("isect_emit_sort");
     char* ws = (char*)workspace;
-    uint64_t* keys = (uint64_t*)(ws + w.keys_off);
-    uint32_t* vals = (uint32_t*)(ws + w.vals_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
+    // Stable LSD sort of (u64 key, u32 value) pairs on the significant key bits: [0, 24) then [24, bits), at most three 8-bit
+    // passes each.  The buffers ping-pong between the caller's arrays and the workspace; the emission starts in the one that
+    // makes the LAST pass land in the caller's arrays.
+    uint64_t* ukeys = (uint64_t*)isect_ids;
+    uint32_t* uvals = (uint32_t*)flatten_ids;
+    uint64_t* wkeys = (uint64_t*)(ws + wmax.keys_off);
+    uint32_t* wvals = (uint32_t*)(ws + wmax.vals_off);
+    const int total_passes = w.lo.passes + (w.two_sorts ? w.hi.passes : 0);
+    const bool start_in_user = (total_passes % 2) == 0;
+    uint64_t* k0 = start_in_user ? ukeys : wkeys;
+    uint32_t* v0 = start_in_user ? uvals : wvals;
+    uint64_t* k1 = start_in_user ? wkeys : ukeys;
+    uint32_t* v1 = start_in_user ? wvals : uvals;
     if (mode == GSPL_MODE_GSPLAT)
-        hipLaunchKernelGGL(isect_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, cum_tiles, tile_size, tile_w, tile_h, keys, vals);
+        hipLaunchKernelGGL(isect_emit_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, cum_tiles, tile_size, tile_w, tile_h, k0, v0);
     else
-        hipLaunchKernelGGL(isect_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, cum_tiles, tile_size, tile_w, tile_h, keys, vals);
+        hipLaunchKernelGGL(isect_emit_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, cum_tiles, tile_size, tile_w, tile_h, k0, v0);
     rc = check_launch("isect_emit");
     if (rc != GSPL_OK) return rc;
-    size_t tmp = w.sort_tmp_bytes;
-    const int bits = key_bits(tile_w * tile_h);
-    hipError_t e = rocprim::radix_sort_pairs(ws + w.sort_tmp_off, tmp, keys, (uint64_t*)isect_ids, vals, (uint32_t*)flatten_ids,
-                                             (size_t)n_isects, 0, bits, s);
-    return check_hip(e, "isect_emit_sort: radix_sort_pairs");
+    uint64_t* kb[2] = {k0, k1};
+    uint32_t* vb[2] = {v0, v1};
+    rc = radix_sort_u64(w.lo, ws + wmax.sort_off, kb, vb, false, s);
+    if (rc != GSPL_OK) return rc;
+    if (w.two_sorts) {
+        if (w.lo.passes & 1) { kb[0] = k1; kb[1] = k0; vb[0] = v1; vb[1] = v0; }
+        rc = radix_sort_u64(w.hi, ws + wmax.sort_off, kb, vb, false, s);
+    }
+    return rc;
 }
 
 extern "C" int gspl_isect_offsets(int64_t n_isects, const int64_t* isect_ids, int tile_w, int tile_h,

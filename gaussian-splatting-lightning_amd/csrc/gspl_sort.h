@@ -16,7 +16,7 @@
 //     several consecutive tiles per draw serialise the look-back — a batch's first tile waits for the previous batch's LAST.)
 //   * the per-tile state is one 32-bit word (2 flag bits | 30 count bits) moved with agent-scope relaxed atomics —
 //     coherent across the eight XCD L2s without cache write-backs, and self-describing, so no fences.
-// Sizes above 2^30 - 1 items do not fit the state word: callers fall back to rocPRIM there.
+// Sizes above 2^30 - 1 items do not fit the state word: callers report GSPL_ERR_UNSUPPORTED there.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -51,6 +51,7 @@ struct RadixPlan {
 // Plan a sort of key bits [begin_bit, end_bit).  digit_bits = widest digit (<= 8); passes = ceil(bits / digit_bits),
 // the bits are spread evenly over the passes.  Returns false if the request is not representable.
 bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_items, RadixPlan& plan);
+void radix_replan_items(RadixPlan& plan, size_t n);      // the same plan for n <= plan.n items
 
 // Sort.  keys[0]/vals[0] hold the input; buffer 1 is scratch of the same size.  The sorted sequence ends in buffer
 // (plan.passes & 1).  vals may be nullptr (keys only).  `prepared`: the caller already zeroed the header
@@ -61,10 +62,22 @@ void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr)
 
 // True when a (u32 key, u32 value) sort of n items runs one tile per workgroup (the fast path: no tile counter).  Callers with
 // a library alternative use it to stay on that path only: with tiles drawn from a counter the pass kernel is bounded by the
-// counter (~16 ns per tile) and loses to rocPRIM's larger tiles (6 M pairs: 137 us per pass against ~100).
+// counter (~16 ns per tile) and queueing on it costs ~16 ns per tile.
 bool radix_sort_u32_is_single_wave_of_tiles(size_t n);
 
+static constexpr int RADIX_ERR_WORD = 15;              // word of the 16-word counter block that collects look-back time-outs
+
 int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
+// Tile sort of the binning: records (tile id << 32 | splat id) sorted on plan's bits (inside the high word); the sorted low
+// words land in ids_out, tile_counts[0, n_tile_counts) receives the number of records per tile id (plan.passes >= 2).
+int radix_sort_tiles(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], bool prepared, uint32_t* ids_out,
+                     uint32_t* tile_counts, uint32_t n_tile_counts, void* stream);
+int tile_offsets_from_counts(uint32_t* counts, uint32_t n, void* stream);      // exclusive prefix, in place
+// Exclusive scan of n u32 (n < 2^32; three launches; workspace: exclusive_scan_u32_workspace_bytes(n), 4-byte aligned).
+size_t exclusive_scan_u32_workspace_bytes(size_t n);
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* workspace, void* stream);
+// Process-wide: draw tiles from a counter in every sort and scan from now on (after a look-back time-out was reported).
+void radix_force_ticket(bool on);
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 
 // Inclusive scan of counts[order[i]] (int32 -> int64) in ONE launch: the same chained look-back as the sort passes (one
@@ -74,7 +87,9 @@ static constexpr int SCAN_TILE = 2048;
 size_t scan_state_bytes(size_t n);
 // Counts with bit 31 set are TAGGED: the bit is not part of the count, and with `tagged_list` (nullable) the scan also writes
 // the positions i of the tagged items in order to tagged_list[0..) and their number to cum[n] (cum then has n + 1 entries).
+// order may be nullptr (identity).  `err`: the sort header's error word (nullable); with tagged_list the scan also copies it to
+// cum[n + 1] (cum then has n + 2 entries), so that one host read-back carries the list length and the health of the sorts.
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket /* zero on entry */,
-                         int32_t* tagged_list, void* stream);
+                         int32_t* tagged_list, uint32_t* err, void* stream);
 
 }  // namespace gspl

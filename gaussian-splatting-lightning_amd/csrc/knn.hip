@@ -9,7 +9,7 @@
 // Design: exact search on a uniform grid instead of the Morton-chunk search of the CUDA package.
 //   1. bounds: min/max of the cloud (float atomics on order-preserving integer images)
 //   2. cells:  cell edge h = cbrt(volume * TARGET / N), grid clamped to 256^3; per-point cell id, histogram
-//   3. scan of the histogram (rocPRIM), counting-sort scatter of the points into cell order
+//   3. scan of the histogram (exclusive_scan_u32 of sort.hip), counting-sort scatter of the points into cell order
 //   4. search: one lane per point walks the cube shells around its cell (Chebyshev radius r = 1, 2, ...), keeping the
 //      three smallest d^2; after shell r every unvisited point is farther than r*h, so the search stops as soon as
 //      the third-smallest d^2 <= (r*h)^2 — exact, and ~27 cells x TARGET points for a uniform cloud.
@@ -18,7 +18,7 @@
 #include <cstdlib>
 #include "gspl_device.h"
 #include "gspl_host.h"
-#include <rocprim/rocprim.hpp>
+#include "gspl_sort.h"
 
 namespace gspl {
 
@@ -205,9 +205,7 @@ static size_t knn_cell_capacity(int N) {
 
 static int plan_knn(int N, KnnWorkspace& w) {
     const size_t n = (size_t)(N > 0 ? N : 1), cells = knn_cell_capacity(N);
-    size_t scan_tmp = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, cells + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
-    if (e != hipSuccess) return check_hip(e, "knn: scan size query");
+    const size_t scan_tmp = exclusive_scan_u32_workspace_bytes(cells + 1);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = knn_align(off + bytes); return o; };
     w.bounds_off = take(8 * 4);
@@ -264,9 +262,8 @@ extern "C" int gspl_knn3_mean_dist2(int N, const float* points, float* out, void
     hipLaunchKernelGGL(knn_count_kernel, dim3(grid_n), dim3(256), 0, s, N, points, (const KnnGrid*)grid, cell_id, count);
     rc = check_launch("knn_count");
     if (rc != GSPL_OK) return rc;
-    size_t tmp = w.scan_tmp_bytes;
-    e = rocprim::exclusive_scan(ws + w.scan_tmp_off, tmp, (const uint32_t*)count, start, 0u, cells + 1, rocprim::plus<uint32_t>(), s);
-    if (e != hipSuccess) return check_hip(e, "knn: exclusive_scan");
+    rc = exclusive_scan_u32((const uint32_t*)count, start, cells + 1, ws + w.scan_tmp_off, s);
+    if (rc != GSPL_OK) return rc;
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(grid_n), dim3(256), 0, s, N, points, (const int32_t*)cell_id, (const uint32_t*)start, cursor, sorted);
     hipLaunchKernelGGL(knn_search_kernel, dim3(grid_n), dim3(256), 0, s, N, (const KnnGrid*)grid, (const uint32_t*)start, (const float4*)sorted, out);
     return check_launch("knn_search");

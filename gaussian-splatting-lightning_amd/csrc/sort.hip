@@ -78,7 +78,13 @@ __global__ __launch_bounds__(RS_THREADS) void radix_header_kernel(const KeyT* __
 // Walk the state rows `p`, p-1, ..., lo of one digit column: add LOCAL counts and go on, add a GLOBAL count and finish;
 // an unpublished row is polled.  RS_WINDOW rows are fetched per step (a state load is a round trip past the XCD L2).
 // Returns the first row not consumed (lo - 1 when the range is exhausted).
-__device__ __forceinline__ int walk_states(const uint32_t* __restrict__ rows, int t, int p, int lo, uint32_t& excl, bool& finished) {
+// A predecessor that never publishes (only possible in the counter-free mode when the grid is neither co-resident nor
+// dispatched in index order) does not hang or fault the device: after 2^22 polls the walk gives up, raises the sort's error
+// word and carries on with what it has — the output is then garbage, every workgroup still terminates, and the host turns the
+// word into a status / re-runs the sort with tiles drawn from a counter (gspl_bin_count reports it through cum_tiles[N + 1]).
+__device__ uint32_t g_sort_error_sink;
+__device__ __forceinline__ int walk_states(const uint32_t* __restrict__ rows, int t, int p, int lo, uint32_t& excl, bool& finished,
+                                           uint32_t* __restrict__ err) {
     uint32_t spins = 0u;
     while (!finished && p >= lo) {
         uint32_t s[RS_WINDOW];
@@ -97,7 +103,7 @@ __device__ __forceinline__ int walk_states(const uint32_t* __restrict__ rows, in
         p -= adv;
         if (adv == 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) __builtin_trap();          // a predecessor never published: fail loudly, do not hang
+            if (++spins > (1u << 22)) { atomicOr(err, 1u); finished = true; }      // a predecessor never published: flag it, do not hang
         }
     }
     return p;
@@ -125,12 +131,18 @@ struct RadixShared {
 //   looping over tiles b, b + grid, ... was measured to dead-lock when three processes shared the GPU: resident
 //   workgroups waited for tiles of workgroups that could not start).  The draw for the next tile is issued a tile ahead; a
 //   single-address atomic is served at ~60 M/s, which bounds this mode at ~16 ns per tile.
-template <typename KeyT, bool VALUES, int IPT, bool TICKET>
+// FINAL (u64 keys, no values; the LAST pass of the tile sort of the binning): the sorted records leave as their low words only
+//   (vals_out = the per-tile lists of splat ids), and the number of records per tile id (the key's high word) is counted into
+//   aux[tile id].  The pass before left the records ordered by the low digit, so after the in-tile permutation equal tile ids are
+//   contiguous runs in LDS: one atomic pair per run (subtract its first slot, add one past its last).
+// aux_zero > 0: workgroup 0 clears aux[0, aux_zero) (the pass BEFORE the final one prepares the counters).
+template <typename KeyT, bool VALUES, int IPT, bool TICKET, bool FINAL>
 __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                 KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                 uint32_t ntiles, int shift, int nbits, const uint32_t* __restrict__ hist,
                                                                 uint32_t* __restrict__ states, uint32_t* __restrict__ gstates,
-                                                                uint32_t* __restrict__ ticket) {
+                                                                uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                                                                uint32_t* __restrict__ aux, uint32_t aux_zero) {
     constexpr uint32_t TILE = RS_THREADS * IPT;
     __shared__ RadixShared<KeyT, VALUES, IPT> sh;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -159,6 +171,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
         __syncthreads();
         tile = s_tile;
     }
+    if (aux_zero != 0u && blockIdx.x == 0)
+        for (uint32_t j = (uint32_t)t; j < aux_zero; j += RS_THREADS) aux[j] = 0u;
     load_tile(tile, key, val);
     if (t < RADIX_BINS) {
         uint32_t c = 0u;
@@ -239,9 +253,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
                 bool finished = false;
                 int p = (int)tile - 1;
                 const bool closer = ((tile + 1u) % RS_GROUP) == 0u;
-                if (((uint32_t)(p + 1) % RS_GROUP) != 0u) p = walk_states(states, t, p, (p / RS_GROUP) * RS_GROUP, excl, finished);
+                if (((uint32_t)(p + 1) % RS_GROUP) != 0u) p = walk_states(states, t, p, (p / RS_GROUP) * RS_GROUP, excl, finished, err);
                 if (closer) state_store(gstates + (size_t)(tile / RS_GROUP) * RADIX_BINS + t, (finished ? RS_FLAG_GLOBAL : RS_FLAG_LOCAL) | (excl + my_count));
-                if (!finished) walk_states(gstates, t, (p + 1) / RS_GROUP - 1, 0, excl, finished);
+                if (!finished) walk_states(gstates, t, (p + 1) / RS_GROUP - 1, 0, excl, finished, err);
                 state_store(states + (size_t)tile * RADIX_BINS + t, RS_FLAG_GLOBAL | (excl + my_count));
                 if (closer) state_store(gstates + (size_t)(tile / RS_GROUP) * RADIX_BINS + t, RS_FLAG_GLOBAL | (excl + my_count));
             }
@@ -256,8 +270,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_pass_kernel(const KeyT* __re
                 const KeyT k = sh.xkey[i];
                 const uint32_t d = (uint32_t)(k >> shift) & mask;
                 const uint32_t gpos = sh.gbase[d] + i;
-                keys_out[gpos] = k;
-                if (VALUES) vals_out[gpos] = sh.xval[i];
+                if constexpr (FINAL) {
+                    vals_out[gpos] = (uint32_t)k;
+                    const uint32_t id = (uint32_t)((unsigned long long)k >> 32);
+                    const bool run_first = (i == 0u) || ((uint32_t)((unsigned long long)sh.xkey[i - 1] >> 32) != id);
+                    const bool run_last = (i + 1u == tile_n) || ((uint32_t)((unsigned long long)sh.xkey[i + 1] >> 32) != id);
+                    if (run_first && run_last) atomicAdd(aux + id, 1u);
+                    else if (run_first) atomicSub(aux + id, i);
+                    else if (run_last) atomicAdd(aux + id, i + 1u);
+                } else {
+                    keys_out[gpos] = k;
+                    if (VALUES) vals_out[gpos] = sh.xval[i];
+                }
             }
         }
 #pragma unroll
@@ -294,6 +318,14 @@ bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_i
     return true;
 }
 
+// Same bit split and workspace, fewer items (n <= the n the plan was made for): the rows of every pass start earlier but stay
+// inside the range the plan's header covers.
+void radix_replan_items(RadixPlan& plan, size_t n) {
+    plan.n = (uint32_t)n;
+    plan.ntiles = (uint32_t)((n + plan.tile_items - 1) / plan.tile_items);
+    plan.ngroups = plan.ntiles / RS_GROUP;
+}
+
 // Workgroups of a kernel the device is SURE to keep resident at once (certain = true; the bound of the one-tile-per-workgroup
 // launches) or is expected to (certain = false; the grid of the ticketed launches, where an overestimate is harmless).  The occupancy API
 // is exact for most shapes (tools/micro/residency_probe.hip) but a kernel sitting on a register-file boundary (64 VGPRs =
@@ -311,20 +343,30 @@ static unsigned resident_blocks(Kernel kernel, bool certain = true) {
     return (unsigned)per_cu * (unsigned)cus;
 }
 
+// force_ticket: process-wide switch to the counter mode (set by the host after a look-back time-out, or by GSPL_SORT_FORCE_TICKET)
+static bool g_force_ticket = false;
+void radix_force_ticket(bool on) { g_force_ticket = on; }
+static bool ticket_forced() { static const bool env = getenv("GSPL_SORT_FORCE_TICKET") != nullptr; return env || g_force_ticket; }
+
+struct PassAux { uint32_t* aux; uint32_t aux_zero; bool final_ids; };
+
 template <typename KeyT, bool VALUES, int IPT>
 static int launch_pass(const RadixPlan& plan, int p, const KeyT* kin, const uint32_t* vin, KeyT* kout, uint32_t* vout, const uint32_t* hist,
-                       uint32_t* states, uint32_t* gstates, uint32_t* ticket, hipStream_t s) {
+                       uint32_t* states, uint32_t* gstates, uint32_t* ticket, uint32_t* err, PassAux ax, hipStream_t s) {
     static unsigned safe = 0, full = 0;       // same values on every device of a node; a benign race at worst
     if (safe == 0) {
-        full = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT, true>, false);
-        safe = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT, false>, true);
+        full = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT, true, false>, false);
+        safe = resident_blocks(radix_pass_kernel<KeyT, VALUES, IPT, false, false>, true);
     }
-    if (plan.ntiles <= safe && !getenv("GSPL_SORT_FORCE_TICKET"))
-        hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT, false>), dim3(plan.ntiles), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, plan.n,
-                           plan.ntiles, plan.shift[p], plan.bits[p], hist, states, gstates, ticket);
-    else
-        hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT, true>), dim3(plan.ntiles < full ? plan.ntiles : full), dim3(RS_THREADS), 0, s, kin, vin,
-                           kout, vout, plan.n, plan.ntiles, plan.shift[p], plan.bits[p], hist, states, gstates, ticket);
+    const bool single = plan.ntiles <= safe && !ticket_forced();
+    const dim3 grid(single ? plan.ntiles : (plan.ntiles < full ? plan.ntiles : full));
+#define GSPL_PASS(TK, FN) hipLaunchKernelGGL((radix_pass_kernel<KeyT, VALUES, IPT, TK, FN>), grid, dim3(RS_THREADS), 0, s, kin, vin, kout, vout, plan.n, \
+                                             plan.ntiles, plan.shift[p], plan.bits[p], hist, states, gstates, ticket, err, ax.aux, ax.aux_zero)
+    if constexpr (sizeof(KeyT) == 8 && !VALUES) {
+        if (ax.final_ids) { if (single) GSPL_PASS(false, true); else GSPL_PASS(true, true); return check_launch("radix_sort(final pass)"); }
+    }
+    if (single) GSPL_PASS(false, false); else GSPL_PASS(true, false);
+#undef GSPL_PASS
     return check_launch("radix_sort(pass)");
 }
 
@@ -338,7 +380,8 @@ void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr)
 }
 
 template <typename KeyT, int IPT>
-static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
+static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const keys[2], uint32_t* const vals[2], bool prepared, void* stream,
+                           uint32_t* final_ids = nullptr, uint32_t* tile_counts = nullptr, uint32_t n_tile_counts = 0) {
     if (plan.n == 0) return GSPL_OK;
     if (plan.tile_items != (uint32_t)(RS_THREADS * IPT)) return fail_arg("radix_sort: plan made for another tile size");
     hipStream_t s = (hipStream_t)stream;
@@ -357,10 +400,19 @@ static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const k
         int rc = check_launch("radix_sort(header)");
         if (rc != GSPL_OK) return rc;
     }
+    uint32_t* err = (uint32_t*)(ws + plan.ticket_off) + RADIX_ERR_WORD;
     for (int p = 0; p < plan.passes; ++p) {
         int rc;
-        if (vals) rc = launch_pass<KeyT, true, IPT>(plan, p, keys[p & 1], vals[p & 1], keys[(p + 1) & 1], vals[(p + 1) & 1], hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, (uint32_t*)(ws + plan.ticket_off) + p, s);
-        else rc = launch_pass<KeyT, false, IPT>(plan, p, keys[p & 1], nullptr, keys[(p + 1) & 1], nullptr, hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, (uint32_t*)(ws + plan.ticket_off) + p, s);
+        PassAux ax = {nullptr, 0u, false};
+        if (final_ids) {      // tile sort: the last pass writes ids + per-tile counts, the one before clears the counters
+            const bool last = p == plan.passes - 1;
+            ax.aux = tile_counts;
+            ax.final_ids = last;
+            if (p == plan.passes - 2) ax.aux_zero = n_tile_counts;
+        }
+        uint32_t* vout = (final_ids && p == plan.passes - 1) ? final_ids : (vals ? vals[(p + 1) & 1] : nullptr);
+        if (vals) rc = launch_pass<KeyT, true, IPT>(plan, p, keys[p & 1], vals[p & 1], keys[(p + 1) & 1], vout, hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, (uint32_t*)(ws + plan.ticket_off) + p, err, ax, s);
+        else rc = launch_pass<KeyT, false, IPT>(plan, p, keys[p & 1], nullptr, keys[(p + 1) & 1], vout, hist + p * RADIX_BINS, states + p * pass_words, states + p * pass_words + (size_t)plan.ntiles * RADIX_BINS, (uint32_t*)(ws + plan.ticket_off) + p, err, ax, s);
         if (rc != GSPL_OK) return rc;
     }
     return GSPL_OK;
@@ -368,8 +420,16 @@ static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const k
 
 bool radix_sort_u32_is_single_wave_of_tiles(size_t n) {
     static unsigned safe = 0;
-    if (safe == 0) safe = resident_blocks(radix_pass_kernel<uint32_t, true, RADIX_TILE_U32 / RS_THREADS, false>, true);
-    return (n + RADIX_TILE_U32 - 1) / RADIX_TILE_U32 <= safe && !getenv("GSPL_SORT_FORCE_TICKET");
+    if (safe == 0) safe = resident_blocks(radix_pass_kernel<uint32_t, true, RADIX_TILE_U32 / RS_THREADS, false, false>, true);
+    return (n + RADIX_TILE_U32 - 1) / RADIX_TILE_U32 <= safe && !ticket_forced();
+}
+
+// The tile sort of the binning: u64 records (tile id << 32 | splat id) sorted on the tile-id bits [32, 32 + tile_bits);
+// the sorted low words go straight to `ids_out`, `tile_counts[0, n_tile_counts)` receives the number of records of every tile id.
+// The pass count must be >= 2 (the pass before the last clears the counters): callers with a single pass clear them themselves.
+int radix_sort_tiles(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], bool prepared, uint32_t* ids_out,
+                     uint32_t* tile_counts, uint32_t n_tile_counts, void* stream) {
+    return radix_sort_impl<uint64_t, RADIX_TILE_U64 / RS_THREADS>(plan, workspace, keys, nullptr, prepared, stream, ids_out, tile_counts, n_tile_counts);
 }
 
 int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
@@ -390,7 +450,7 @@ template <bool TICKET>      // as radix_pass_kernel: one tile per workgroup, or 
 __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
                                                                  int64_t* __restrict__ cum, uint32_t n, uint32_t ntiles,
                                                                  unsigned long long* __restrict__ states, uint32_t* __restrict__ ticket,
-                                                                 int32_t* __restrict__ tagged_list) {
+                                                                 int32_t* __restrict__ tagged_list, uint32_t* __restrict__ err) {
     __shared__ unsigned long long s_wave[RS_WAVES];
     __shared__ unsigned long long s_excl;
     __shared__ uint32_t s_tile;
@@ -410,7 +470,7 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
             const uint32_t i = first + k;
             // bit 31 of a count tags the item: the tagged items are ranked along the way (their number rides in bits 40.. of
             // the scanned value; the counts themselves add up to < 2^31)
-            const uint32_t c = i < n ? (uint32_t)counts[order[i]] : 0u;
+            const uint32_t c = i < n ? (uint32_t)counts[order ? order[i] : i] : 0u;
             v[k] = (unsigned long long)(c & 0x7fffffffu) | ((unsigned long long)(c >> 31) << 40);
             mine += v[k];
         }
@@ -447,7 +507,7 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
                     p -= take;
                     if (take == 0) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 24)) __builtin_trap();                       // a predecessor never published: fail loudly
+                        if (++spins > (1u << 22)) { if (l == 0) atomicOr(err, 1u); break; }       // a predecessor never published: flag it, do not hang
                     }
                 }
                 if (l == 0) __hip_atomic_store(states + tile, SC_FLAG_GLOBAL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,7 +524,12 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
                 cum[i] = (int64_t)(run & ((1ull << 40) - 1ull));
                 if (tagged_list) {
                     if (v[k] >> 40) tagged_list[(run >> 40) - 1ull] = (int32_t)i;
-                    if (i == n - 1u) cum[n] = (int64_t)(run >> 40);      // how many are tagged
+                    if (i == n - 1u) {
+                        cum[n] = (int64_t)(run >> 40);      // how many are tagged
+                        // ... and the error word of the sorts that ran before this scan on the same header (the depth sort), plus
+                        // this scan's own: the host reads it with the list length (0 = fine)
+                        cum[n + 1] = (int64_t)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
@@ -473,26 +538,112 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
     }
 }
 
+// counts[0, n) (u32, left by the FINAL pass of the tile sort) -> exclusive prefix in place, as int32 offsets.  One workgroup:
+// n is the number of image tiles (8160 at 1080p; a few hundred thousand for very large images).
+__global__ __launch_bounds__(1024) void tile_offsets_kernel(uint32_t* __restrict__ counts, uint32_t n) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    if (t == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 4096u) {
+        const uint32_t i0 = base + (uint32_t)t * 4u;
+        uint32_t v[4], mine = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? counts[i0 + k] : 0u; mine += v[k]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (l >= d) incl += up; }
+        if (l == 63) s_wave[w] = incl;
+        __syncthreads();
+        uint32_t woff = 0u, total = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t c = s_wave[k]; if (k < w) woff += c; total += c; }
+        uint32_t run = s_carry + woff + (incl - mine);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < n) counts[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+        if (t == 0) s_carry += total;
+        __syncthreads();
+    }
+}
+
+int tile_offsets_from_counts(uint32_t* counts, uint32_t n, void* stream) {
+    if (n == 0) return GSPL_OK;
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, n);
+    return check_launch("tile_offsets");
+}
+
+// ---- plain exclusive scan of u32 (the cell histogram of knn.hip; a one-off initialisation op) ---------------------------------
+// blocks of 4096 items: block sums -> exclusive scan of the sums by one workgroup -> per-block scan + base.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums) {
+    __shared__ uint32_t s_wave[16];
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const uint32_t i0 = blockIdx.x * 4096u + (uint32_t)t * 4u;
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine += (i0 + k < n) ? in[i0 + k] : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+    if (l == 0) s_wave[w] = mine;
+    __syncthreads();
+    if (t == 0) { uint32_t tot = 0u; for (int k = 0; k < 16; ++k) tot += s_wave[k]; sums[blockIdx.x] = tot; }
+}
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ bases,
+                                                           uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_wave[16];
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const uint32_t i0 = blockIdx.x * 4096u + (uint32_t)t * 4u;
+    uint32_t v[4], mine = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (i0 + k < n) ? in[i0 + k] : 0u; mine += v[k]; }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (l >= d) incl += up; }
+    if (l == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < w) woff += s_wave[k];
+    uint32_t run = bases[blockIdx.x] + woff + (incl - mine);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+}
+size_t exclusive_scan_u32_workspace_bytes(size_t n) { return ((n + 4095) / 4096 + 1) * sizeof(uint32_t); }
+int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* workspace, void* stream) {
+    if (n == 0) return GSPL_OK;
+    const unsigned blocks = (unsigned)((n + 4095) / 4096);
+    uint32_t* sums = (uint32_t*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(blocks), dim3(1024), 0, s, in, (uint32_t)n, sums);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, sums, blocks);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(blocks), dim3(1024), 0, s, in, (uint32_t)n, (const uint32_t*)sums, out);
+    return check_launch("exclusive_scan_u32");
+}
+
 size_t scan_state_bytes(size_t n) {
     const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     return ((tiles ? tiles : 1) * sizeof(unsigned long long) + 15) / 16 * 16;
 }
 
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* states, uint32_t* ticket,
-                         int32_t* tagged_list, void* stream) {
+                         int32_t* tagged_list, uint32_t* err, void* stream) {
     if (n == 0) return GSPL_OK;
+    if (!err) {
+        if (hipGetSymbolAddress((void**)&err, HIP_SYMBOL(g_sort_error_sink)) != hipSuccess) return fail_arg("scan: no error word");
+    }
     static unsigned safe = 0, full = 0;
     if (safe == 0) {
         full = resident_blocks(scan_gather_kernel<true>, false);
         safe = resident_blocks(scan_gather_kernel<false>, true);
     }
     const unsigned ntiles = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
-    if (ntiles <= safe && !getenv("GSPL_SORT_FORCE_TICKET"))
+    if (ntiles <= safe && !ticket_forced())
         hipLaunchKernelGGL(scan_gather_kernel<false>, dim3(ntiles), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum, (uint32_t)n, ntiles,
-                           (unsigned long long*)states, ticket, tagged_list);
+                           (unsigned long long*)states, ticket, tagged_list, err);
     else
         hipLaunchKernelGGL(scan_gather_kernel<true>, dim3(ntiles < full ? ntiles : full), dim3(RS_THREADS), 0, (hipStream_t)stream, order, counts, cum,
-                           (uint32_t)n, ntiles, (unsigned long long*)states, ticket, tagged_list);
+                           (uint32_t)n, ntiles, (unsigned long long*)states, ticket, tagged_list, err);
     return check_launch("scan_gathered_counts");
 }
 

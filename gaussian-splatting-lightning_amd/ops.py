@@ -640,7 +640,7 @@ class _PendingBins:
     """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
     __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "spans", "offsets", "tile_w", "tile_h",
-                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes", "big_list")
+                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes", "big_list", "depths", "count")
 
 
 _PINNED_WORDS: list = []      # free list of pinned int64 words for the count read-back
@@ -669,23 +669,29 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     if conics is not None and opacities is not None:
         p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
     p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
-    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = p.big_list = None
+    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = p.big_list = p.depths = p.count = None
     p.capacity = p.ws2_bytes = 0
     if N > 0:
         p.order = torch.empty((N,), dtype=torch.int32, device=dev)
-        p.cum = torch.empty((N + 1,), dtype=torch.int64, device=dev)      # scan [N] + the number of big splats
+        p.cum = torch.empty((N + 2,), dtype=torch.int64, device=dev)      # scan [N] + the number of big splats + the sorts' error word
         p.big_list = torch.empty((N,), dtype=torch.int32, device=dev)     # depth-order indices of the splats taller than 16 tile rows
         p.spans = torch.empty((N, L.GSPL_BIN_SPAN_BYTES // 4), dtype=torch.int32, device=dev)
         ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
         if ws_bytes == 0:
             raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
-               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.big_list), L.ptr(p.spans), L.ptr(ws), ws_bytes,
-               L.stream())
-        # the one host read-back of the pipeline (sizes the sort buffers)
-        p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((1,), dtype=torch.int64).pin_memory()
-        p.host_count.copy_(p.cum[N - 1:N], non_blocking=True)
+        p.depths = depths
+
+        def count():
+            L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
+                   block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.big_list), L.ptr(p.spans), L.ptr(ws), ws_bytes,
+                   L.stream())
+        p.count = count
+        count()
+        # the one host read-back of the pipeline: the list length (sizes the sort buffers), the number of big splats and the
+        # error word of the depth sort / scan (a look-back that timed out: see bin_gaussians_end)
+        p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((3,), dtype=torch.int64).pin_memory()
+        p.host_count.copy_(p.cum[N - 1:N + 2], non_blocking=True)
         p.event = torch.cuda.Event()
         p.event.record()
         # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of
@@ -714,7 +720,20 @@ def bin_gaussians_end(p: _PendingBins):
     n_isects = 0
     if p.N > 0:
         p.event.synchronize()
-        n_isects = int(p.host_count[0])
+        n_isects, err = int(p.host_count[0]), int(p.host_count[2])
+        if err != 0:
+            # A look-back of the counter-free sort / scan timed out (its grid was neither co-resident nor dispatched in index
+            # order: another process or stream held the device).  Nothing hung or faulted; the order it produced is garbage.
+            # From now on every sort of this process draws its tiles from a counter (progress under any schedule); redo.
+            import warnings
+            warnings.warn("gspl_amd: a radix-sort look-back timed out under device contention; switching to the counter mode")
+            L.call("gspl_sort_force_ticket", 1)
+            p.count()
+            triple = p.cum[p.N - 1:p.N + 2].cpu()
+            n_isects, err = int(triple[0]), int(triple[2])
+            if err != 0:
+                raise RuntimeError("gspl_bin_count: the depth sort failed in the counter mode as well")
+            p.ws2 = None                              # a speculative emission used the garbage order
         _PINNED_WORDS.append(p.host_count)
         _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
     N, dev = p.N, p.dev

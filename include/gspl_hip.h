@@ -154,7 +154,7 @@ int gspl_sh_bwd_batched(int C, int N, int degree, int n_coeffs,
  *    to internal/utils/gaussian_projection.py:159-208: key = (tile_id << 32) | bits(depth),
  *    tile_id row-major, value = Gaussian index.  Single camera per call.
  *
- *    Step a: per-Gaussian tile counts + inclusive prefix sum (i64).  Host reads cum[N-1].
+ *    Step a: per-Gaussian tile counts + inclusive prefix sum (i64, one chained-look-back launch).  Host reads cum[N-1].
  *    Step b: emit keys, sort them (stable LSD radix, so equal-depth ties keep Gaussian order).
  *    Step c: offsets[t] = first sorted index whose tile id is >= t   (t in [0, tiles)).
  *    gspl_isect_workspace_bytes gives the scratch size for steps a and b.
@@ -197,9 +197,14 @@ int gspl_bin_count(int N, int mode,
                    const float* means2d, const int32_t* radii, const float* depths,
                    const float* conics /*nullable*/, const float* opacities /*nullable*/,
                    int tile_size, int tile_w, int tile_h,
-                   int32_t* order, int64_t* cum_tiles /* [N + 1]: inclusive scan of the tile counts in depth order, then
+                   int32_t* order, int64_t* cum_tiles /* [N + 2]: inclusive scan of the tile counts in depth order, then
                                                          n_big = the number of splats spanning more than 16 tile rows
-                                                         (radius > ~128 px: close-ups, sky blobs) or with a very wide row */,
+                                                         (radius > ~128 px: close-ups, sky blobs) or with a very wide row,
+                                                         then the ERROR WORD of the depth sort and the scan: non-zero when a
+                                                         look-back of their counter-free mode timed out (the device was
+                                                         shared and did not start the grid in index order) — `order` and the
+                                                         scan are then garbage, nothing hung or faulted; call
+                                                         gspl_sort_force_ticket(1) and repeat */,
                    int32_t* big_list /* [N]: the depth-order indices of those splats (n_big entries, ranked by the scan);
                                         the emission deals them out to its workgroups instead of leaving up to 64
                                         consecutive screen-filling splats to one wave */,
@@ -223,6 +228,10 @@ int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                   void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream);
+/* Sorts and scans of this library are in-tree one-sweep kernels (csrc/sort.hip).  Grids that fit an idle device take one tile per
+ * workgroup without a counter; everything else (and everything after this call with on = 1, or with GSPL_SORT_FORCE_TICKET set)
+ * draws its tiles from a counter, which makes progress under any dispatch order and any contention. */
+int gspl_sort_force_ticket(int on);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Tile compositing, forward.
@@ -405,7 +414,7 @@ int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host a
  * 10. Stable LSD radix sort of the binning stage, exported for the parity tests.
  *    The depth sort inside gspl_bin_count (depth keys + splat ids, u32 pairs, prepared by the key pass
  *    itself) runs on this one-sweep sort; the u64 keys-only entry point is the same kernel at the record
- *    width of the tile sort (which currently stays on rocPRIM: DESIGN.md §4).  Both stand in for the
+ *    width of the tile sort (gspl_bin_sort runs it with a last pass that writes ids + per-tile counts).  Both stand in for the
  *    cub::DeviceRadixSort::SortPairs calls of the reference's native rasterizers (gsplat `isect_tiles`
  *    behind gsplat_v1_renderer.py:524-556, the Inria rasterizer behind vanilla_renderer.py:111): stable,
  *    ascending on key bits [begin_bit, end_bit); at most 32 selected bits (4 passes of <= 8 bits), at most
