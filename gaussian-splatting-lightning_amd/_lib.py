@@ -38,6 +38,19 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+# `gspl_alloc_fn` / `gspl_inria_state` of include/gspl_hip.h (the fused Inria entry points)
+GSPL_BUF_GEOMETRY, GSPL_BUF_BINNING, GSPL_BUF_IMAGE, GSPL_BUF_LISTS_WORK, GSPL_BUF_LISTS = 1, 2, 3, 4, 5
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t)
+
+
+class InriaState(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("n_isects", ctypes.c_int64),
+                ("means2d", ctypes.c_void_p), ("depths", ctypes.c_void_p), ("conics", ctypes.c_void_p), ("colors", ctypes.c_void_p),
+                ("clamped", ctypes.c_void_p), ("cov3d", ctypes.c_void_p),
+                ("alphas", ctypes.c_void_p), ("final_Ts", ctypes.c_void_p), ("last_ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p),
+                ("flatten_ids", ctypes.c_void_p)]
+
+
 _P = c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -85,6 +98,12 @@ _SIGNATURES = {
     "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_float, c_float, c_float,
                                           _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "gspl_rasterize_inria_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float,
+                                         ALLOC_FN, _P, c_int64, _P, _P, ctypes.POINTER(InriaState), _P, _P]),
+    "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
+                                         _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_rasterize_inria_geometry_bytes": (c_size_t, [c_int]),
+    "gspl_rasterize_inria_image_bytes": (c_size_t, [c_int, c_int]),
     "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_float, c_float, c_float,
                                           _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -1,0 +1,219 @@
+// fused.hip — ONE C-ABI call per direction for the Inria rasterizer (`gspl_rasterize_inria_fwd/bwd`).
+//
+// Replaces the call `diff_gaussian_rasterization.GaussianRasterizer.forward/backward` makes into its native library
+// (reference call site: internal/renderers/vanilla_renderer.py:62-120; SURVEY.md §8b "fused gs_rasterize_vanilla_fwd/bwd,
+// Inria argument list").  The stage entry points of this library (preprocess, binning, compositing) are orchestrated
+// here, on the host side of the C boundary, instead of from Python: seven ctypes calls, two dozen torch allocations and
+// their bookkeeping per forward become one call and three allocation call-backs — the Inria library's own pattern (its
+// `resizeFunctional` lambdas grow three torch byte tensors: geometry, binning, image state).
+//
+// Nothing here launches kernels of its own; ownership stays with the caller: every buffer comes from `alloc(ctx, tag, bytes)`
+// (torch's caching allocator on the Python side), nothing is hipMalloc'ed, the only persistent host resource is a small
+// pinned word per thread for the one read-back of the frame (the list length that sizes the tile sort).
+#include <cstring>
+#include "gspl_device.h"
+#include "gspl_host.h"
+
+namespace gspl {
+
+static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// per-splat intermediates of one frame, carved out of ONE allocation (tag GSPL_BUF_GEOMETRY)
+struct GeomLayout {
+    size_t radii, means2d, depths, conics, colors, clamped, cov3d, order, cum, big_list, spans, total;
+};
+static GeomLayout geom_layout(size_t n) {
+    GeomLayout g;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
+    g.means2d = take(8 * n); g.depths = take(4 * n); g.conics = take(12 * n); g.colors = take(12 * n);
+    g.clamped = take(3 * n); g.cov3d = take(24 * n);
+    g.order = take(4 * n); g.cum = take(8 * (n + 2)); g.big_list = take(4 * n); g.spans = take((size_t)GSPL_BIN_SPAN_BYTES * n);
+    g.radii = 0;       // radii are an OUTPUT tensor of the call, not part of the block
+    g.total = off;
+    return g;
+}
+struct ImageLayout { size_t alphas, final_Ts, last_ids, offsets, total; };
+static ImageLayout image_layout(size_t pixels, size_t tiles) {
+    ImageLayout m;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
+    m.alphas = take(4 * pixels); m.final_Ts = take(4 * pixels); m.last_ids = take(4 * pixels); m.offsets = take(4 * tiles);
+    m.total = off;
+    return m;
+}
+
+// one pinned 32-byte block per host thread for the read-back (cum[N-1], n_big, error word)
+static int64_t* pinned_words() {
+    static thread_local int64_t* p = nullptr;
+    if (!p) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 4 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) return nullptr;
+        p = (int64_t*)q;
+    }
+    return p;
+}
+
+// three events per host thread (geometry done, colours done, count copied), created once
+struct FrameEvents { hipEvent_t geo = nullptr, col = nullptr, cnt = nullptr; bool ok = false; };
+static FrameEvents& frame_events() {
+    static thread_local FrameEvents ev;
+    if (!ev.ok)
+        ev.ok = hipEventCreateWithFlags(&ev.geo, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev.col, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ev.cnt, hipEventDisableTiming) == hipSuccess;
+    return ev;
+}
+
+}  // namespace gspl
+
+extern "C" size_t gspl_rasterize_inria_geometry_bytes(int N) { return gspl::geom_layout((size_t)(N > 0 ? N : 1)).total; }
+extern "C" size_t gspl_rasterize_inria_image_bytes(int width, int height) {
+    return gspl::image_layout((size_t)width * height, (size_t)((width + 15) / 16) * ((height + 15) / 16)).total;
+}
+
+extern "C" int gspl_rasterize_inria_fwd(
+    int N, int degree, int n_coeffs,
+    const float* means3D, const float* scales, const float* rotations, const float* cov3D_precomp,
+    const float* shs, const float* colors_precomp, const float* opacities,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+    int width, int height, float tanfovx, float tanfovy, float scale_modifier,
+    gspl_alloc_fn alloc, void* alloc_ctx, int64_t capacity_hint,
+    float* out_color, int32_t* radii, gspl_inria_state* st, void* stream, void* side_stream) {
+    using namespace gspl;
+    if (N < 0 || width <= 0 || height <= 0 || !alloc || !st || !out_color) return fail_arg("rasterize_inria_fwd: bad argument");
+    if (N > 0 && (!means3D || !opacities || !radii || !viewmatrix || !projmatrix || !campos)) return fail_arg("rasterize_inria_fwd: NULL required pointer");
+    const int tile = 16, tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
+    hipStream_t s = (hipStream_t)stream, ss = (hipStream_t)side_stream;
+    memset(st, 0, sizeof(*st));
+    st->N = N; st->width = width; st->height = height;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    const GeomLayout g = geom_layout(n);
+    const ImageLayout im = image_layout((size_t)width * height, (size_t)n_tiles);
+    char* geom = (char*)alloc(alloc_ctx, GSPL_BUF_GEOMETRY, g.total);
+    char* img = (char*)alloc(alloc_ctx, GSPL_BUF_IMAGE, im.total);
+    if (!geom || !img) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
+    st->means2d = (float*)(geom + g.means2d); st->depths = (float*)(geom + g.depths); st->conics = (float*)(geom + g.conics);
+    st->colors = (float*)(geom + g.colors); st->clamped = (uint8_t*)(geom + g.clamped); st->cov3d = (float*)(geom + g.cov3d);
+    st->alphas = (float*)(img + im.alphas); st->final_Ts = (float*)(img + im.final_Ts); st->last_ids = (int32_t*)(img + im.last_ids);
+    st->offsets = (int32_t*)(img + im.offsets);
+    int32_t* order = (int32_t*)(geom + g.order);
+    int64_t* cum = (int64_t*)(geom + g.cum);
+    int32_t* big_list = (int32_t*)(geom + g.big_list);
+    void* spans = geom + g.spans;
+    int rc = GSPL_OK;
+    int64_t n_isects = 0;
+    if (N > 0) {
+        // geometry; then two independent chains: the colour (SH) kernel on the side stream, the count / depth-sort half of the
+        // binning on the caller's stream; the host meanwhile waits for the one number that sizes the tile sort
+        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
+                                       campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
+                                       st->colors, st->clamped, st->cov3d, GSPL_INRIA_GEOMETRY, s);
+        if (rc != GSPL_OK) return rc;
+        FrameEvents& fe = frame_events();
+        if (!fe.ok) return check_hip(hipGetLastError(), "rasterize_inria_fwd: event");
+        hipEvent_t ev_geo = nullptr, ev_col = nullptr;
+        if (ss && ss != s) {
+            ev_geo = fe.geo; ev_col = fe.col;
+            (void)hipEventRecord(ev_geo, s);
+            (void)hipStreamWaitEvent(ss, ev_geo, 0);
+        }
+        hipStream_t cs = (ss && ss != s) ? ss : s;
+        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
+                                       campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
+                                       st->colors, st->clamped, st->cov3d, GSPL_INRIA_COLOURS, cs);
+        if (rc == GSPL_OK && ev_col) (void)hipEventRecord(ev_col, cs);
+        auto cleanup = [&]() {};
+        if (rc != GSPL_OK) { cleanup(); return rc; }
+        const size_t ws1_bytes = gspl_bin_workspace_bytes(N, 0);
+        char* ws1 = (char*)alloc(alloc_ctx, GSPL_BUF_BINNING, ws1_bytes);
+        if (!ws1) { cleanup(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+        int64_t* host = pinned_words();
+        if (!host) { cleanup(); return fail_arg("rasterize_inria_fwd: no pinned host word"); }
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            rc = gspl_bin_count(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
+                                spans, ws1, ws1_bytes, s);
+            if (rc != GSPL_OK) { cleanup(); return rc; }
+            hipEvent_t ev_cnt = fe.cnt;
+            (void)hipMemcpyAsync(host, cum + (N - 1), 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s);
+            (void)hipEventRecord(ev_cnt, s);
+            // speculative emission with the caller's guess of the list length, while the host waits for the real one
+            int64_t capacity = 0;
+            char* ws2 = nullptr;
+            size_t ws2_bytes = 0;
+            if (capacity_hint > 0 && attempt == 0) {
+                capacity = capacity_hint;
+                ws2_bytes = gspl_bin_workspace_bytes(N, capacity);
+                ws2 = (char*)alloc(alloc_ctx, GSPL_BUF_LISTS_WORK, ws2_bytes);
+                if (ws2) rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
+                                            capacity, ws2, ws2_bytes, s);
+                if (!ws2 || rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); cleanup(); return ws2 ? rc : fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+            }
+            (void)hipEventSynchronize(ev_cnt);
+            n_isects = host[0];
+            if (host[2] != 0) {      // a look-back of the counter-free depth sort timed out under contention: counter mode, once more
+                gspl_sort_force_ticket(1);
+                capacity_hint = 0;
+                if (attempt == 0) continue;
+                cleanup();
+                set_error("rasterize_inria_fwd", "the depth sort failed in the counter mode as well");
+                return GSPL_ERR_LAUNCH;
+            }
+            if (n_isects > 0 && (!ws2 || capacity < n_isects)) {
+                capacity = n_isects;
+                ws2_bytes = gspl_bin_workspace_bytes(N, capacity);
+                ws2 = (char*)alloc(alloc_ctx, GSPL_BUF_LISTS_WORK, ws2_bytes);
+                if (!ws2) { cleanup(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+                rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
+                                   capacity, ws2, ws2_bytes, s);
+                if (rc != GSPL_OK) { cleanup(); return rc; }
+            }
+            st->flatten_ids = n_isects > 0 ? (int32_t*)alloc(alloc_ctx, GSPL_BUF_LISTS, 4 * (size_t)n_isects) : nullptr;
+            if (n_isects > 0 && !st->flatten_ids) { cleanup(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+            rc = gspl_bin_sort(N, tile_w, tile_h, n_isects, capacity > n_isects ? capacity : n_isects, st->flatten_ids, st->offsets, ws2, ws2_bytes, s);
+            if (rc != GSPL_OK) { cleanup(); return rc; }
+            break;
+        }
+        if (ev_col) (void)hipStreamWaitEvent(s, ev_col, 0);      // colours are ready before compositing reads them
+        cleanup();
+    } else {
+        rc = gspl_bin_sort(0, tile_w, tile_h, 0, 0, nullptr, st->offsets, nullptr, 0, s);
+        if (rc != GSPL_OK) return rc;
+    }
+    st->n_isects = n_isects;
+    return gspl_composite_fwd(N, n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height, tile,
+                              tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
+}
+
+extern "C" int gspl_rasterize_inria_bwd(
+    int degree, int n_coeffs,
+    const float* means3D, const float* scales, const float* rotations, const float* shs, const float* opacities,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+    float tanfovx, float tanfovy, float scale_modifier,
+    const int32_t* radii, const gspl_inria_state* st, const float* v_out_color,
+    float* packed /* [N, 9] scratch */, uint8_t* hit_flags,
+    float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_colors_precomp, float* v_opacities,
+    float* v_scales, float* v_rotations, float* v_cov3D, void* stream) {
+    using namespace gspl;
+    if (!st || st->N < 0) return fail_arg("rasterize_inria_bwd: bad state");
+    const int N = st->N, width = st->width, height = st->height;
+    if (N == 0) return GSPL_OK;
+    if (!packed || !v_out_color || !v_means3D || !v_means2D_ndc || !v_opacities) return fail_arg("rasterize_inria_bwd: NULL required pointer");
+    const int tile = 16, tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(packed, 0, (size_t)N * 9 * sizeof(float), s);      // x y | a b c | opacity | r g b
+    if (e != hipSuccess) return check_hip(e, "rasterize_inria_bwd: clear");
+    if (hit_flags) {
+        e = hipMemsetAsync(hit_flags, 0, (size_t)N, s);
+        if (e != hipSuccess) return check_hip(e, "rasterize_inria_bwd: clear");
+    }
+    int rc = GSPL_OK;
+    if (st->n_isects > 0) {
+        rc = gspl_composite_bwd_packed(N, st->n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width,
+                                       height, tile, tile_w, tile_h, st->offsets, st->flatten_ids, st->final_Ts, st->last_ids, v_out_color, nullptr,
+                                       packed, 9, 0, hit_flags, s);
+        if (rc != GSPL_OK) return rc;
+    }
+    return gspl_inria_preprocess_bwd(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, viewmatrix, projmatrix, campos, width, height,
+                                     tanfovx, tanfovy, scale_modifier, radii, st->clamped, packed, packed + 2, packed + 6, 9, v_means3D, v_scales,
+                                     v_rotations, v_cov3D, v_shs, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, s);
+}

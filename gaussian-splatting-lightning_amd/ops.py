@@ -606,6 +606,7 @@ class _side_stream:
     already enqueued on the current stream; `s.join()` makes the current stream wait for them.  Set GSPL_SIDE_STREAM=0 to
     keep everything on the caller's stream."""
     _streams: dict = {}
+    _handles: dict = {}
 
     def __init__(self, dev):
         import os
@@ -896,6 +897,134 @@ class _InriaRasterizeFn(torch.autograd.Function):
         return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
 
 
+# ---- the same rasterizer through ONE C-ABI call per direction (gspl_rasterize_inria_fwd/bwd, csrc/fused.hip) -----------------
+FUSED_INRIA = os.environ.get("GSPL_FUSED_INRIA", "1") != "0"
+_ALLOC_TLS = __import__("threading").local()
+
+
+def _alloc_trampoline(_ctx, tag, nbytes):
+    """`gspl_alloc_fn`: hand the library a block of torch-owned device memory; the tensors stay with the caller's holder."""
+    holder = _ALLOC_TLS.holder
+    try:
+        t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=holder["device"])
+        holder.setdefault(tag, []).append(t)
+        return t.data_ptr()
+    except Exception as e:      # an exception must not cross the C boundary: NULL = failure, re-raised by the caller
+        holder["error"] = e
+        return 0
+
+
+_ALLOC_CB = L.ALLOC_FN(_alloc_trampoline)
+
+
+def _view(buf: Tensor, ptr: int, shape, dtype) -> Tensor:
+    """Typed view of a region of a byte buffer the library carved up (ptr = device address inside `buf`)."""
+    import math
+    off = ptr - buf.data_ptr()
+    nbytes = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype).view(shape)
+
+
+class _InriaFusedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+        import ctypes
+        s: GaussianRasterizationSettings = settings
+        dev = means3D.device
+        means3D = _f32c(means3D)
+        N = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        sh, colors_precomp, scales, rotations, cov3D_precomp = map(_f32c, (sh, colors_precomp, scales, rotations, cov3D_precomp))
+        opac = _f32c(opacities).reshape(-1)
+        viewm, projm, campos, bg = _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos), _f32c(s.bg)
+        n_coeffs = sh.shape[1] if sh is not None else 0
+        out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((N,), dtype=torch.int32, device=dev)
+        tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
+        key = (dev.index, tile_w, tile_h)
+        guess = _LAST_ISECTS.get(key, 0)
+        hint = (int(guess * 1.25) + 65536) if (SPECULATIVE_EMIT and guess > 0) else 0
+        state = L.InriaState()
+        holder = {"device": dev}
+        _ALLOC_TLS.holder = holder
+        side = _side_stream(dev)
+        with torch.cuda.device(dev):
+            side_handle = None
+            if side.enabled:
+                hk = (dev.type, dev.index)
+                raw = _side_stream._handles.get(hk)
+                if raw is None:
+                    raw = _side_stream._handles[hk] = side.stream.cuda_stream      # (~10 us of Python per look-up: cached)
+                side_handle = ctypes.c_void_p(raw)
+            try:
+                L.call("gspl_rasterize_inria_fwd", N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                       L.ptr(cov3D_precomp), L.ptr(sh), L.ptr(colors_precomp), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg),
+                       W, H, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), _ALLOC_CB, None, hint,
+                       L.ptr(out), L.ptr(radii), ctypes.byref(state), L.stream(), side_handle)
+            except RuntimeError:
+                if "error" in holder:
+                    raise holder["error"]
+                raise
+            finally:
+                _ALLOC_TLS.holder = None
+        if side.enabled:
+            # blocks the colour kernel used on the side stream are freed by the caller's stream: tell the allocator
+            for t in holder.get(L.GSPL_BUF_GEOMETRY, []):
+                t.record_stream(side.stream)
+        _LAST_ISECTS[key] = int(state.n_isects)
+        holder.pop(L.GSPL_BUF_BINNING, None)           # scratch of the count half and of the tile sort: not needed again
+        holder.pop(L.GSPL_BUF_LISTS_WORK, None)
+        ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii)
+        ctx.holder, ctx.state = holder, state
+        ctx.cfg = (H, W, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), colors_precomp is not None,
+                   cov3D_precomp is not None, opacities.shape)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        ctx.means2D_ref = means2D
+        if KEEP_LAST_RASTER:
+            global LAST_RASTER
+            geom, lists = holder[L.GSPL_BUF_GEOMETRY][0], holder.get(L.GSPL_BUF_LISTS, [None])[0]
+            img = holder[L.GSPL_BUF_IMAGE][0]
+            nI = int(state.n_isects)
+            LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=_view(geom, state.means2d, (N, 2), torch.float32),
+                               conics=_view(geom, state.conics, (N, 3), torch.float32), opacities=opac,
+                               flatten_ids=(lists[:4 * nI].view(torch.int32) if lists is not None else torch.empty(0, dtype=torch.int32, device=dev)),
+                               offsets=_view(img, state.offsets, (tile_w * tile_h,), torch.int32), radii=radii,
+                               depths=_view(geom, state.depths, (N,), torch.float32))
+        return out, radii
+
+    @staticmethod
+    def backward(ctx, v_out, _v_radii):
+        import ctypes
+        means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii = ctx.saved_tensors
+        H, W, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, use_cov, opac_shape = ctx.cfg
+        N = means3D.shape[0]
+        dev = means3D.device
+        v_out = _grad_or_zeros(v_out, (3, H, W), dev)
+        E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        packed = E(N, 9)
+        hit = torch.empty((N,), dtype=torch.uint8, device=dev) if TRACK_HIT_PIXELS else None
+        v_means, v_ndc, v_opac = E(N, 3), E(N, 3), E(N)
+        v_scales = None if use_cov else E(N, 3)
+        v_quats = None if use_cov else E(N, 4)
+        v_cov = E(N, 6) if use_cov else None
+        v_sh = None if has_precomp_colors else torch.empty_like(sh)
+        v_cp = E(N, 3) if has_precomp_colors else None
+        if N > 0:
+            with torch.cuda.device(dev):
+                L.call("gspl_rasterize_inria_bwd", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh), L.ptr(opac),
+                       L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
+                       ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_cp),
+                       L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
+            if hit is not None and ctx.means2D_ref is not None:
+                ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
+        else:
+            for t in (v_means, v_ndc, v_opac):
+                t.zero_()
+        ctx.holder = None
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
+
+
 class GaussianRasterizer(torch.nn.Module):
     """Drop-in for `diff_gaussian_rasterization.GaussianRasterizer` as the reference uses it
     (internal/renderers/vanilla_renderer.py:79,111-120): returns (color [3,H,W], radii [N] i32);
@@ -912,8 +1041,9 @@ class GaussianRasterizer(torch.nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        return _InriaRasterizeFn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                       self.raster_settings)
+        # one C-ABI call per direction (csrc/fused.hip) unless GSPL_FUSED_INRIA=0 selects the stage-by-stage orchestration
+        fn = _InriaFusedFn if FUSED_INRIA else _InriaRasterizeFn
+        return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings)
 
 
 # =============================================================================================

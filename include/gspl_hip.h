@@ -347,6 +347,50 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 6b. The WHOLE Inria rasterizer in one call per direction ("fused gs_rasterize_vanilla_fwd/bwd, Inria
+ *    argument list"): what `diff_gaussian_rasterization`'s `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` are to
+ *    the reference's wrapper (call site internal/renderers/vanilla_renderer.py:62-120).  Preprocess (geometry, then colours on
+ *    `side_stream` next to the depth sort), list-only binning with lossless tile culling and the one host read-back of the
+ *    frame (waited for INSIDE the call), compositing.  Memory comes from the caller through `alloc` — the Inria library's own
+ *    resize-call-back pattern: the returned device pointers must stay valid until the matching backward has run (the Python
+ *    side keeps the torch byte tensors in the autograd context).  Tags tell the call-back what a block is for; one block per tag
+ *    and call, except GSPL_BUF_LISTS_WORK which may be asked for twice (speculative emission with `capacity_hint` = a guess of
+ *    the list length, e.g. the previous frame's x 1.25; 0 = no speculation).  No hipMalloc, no global state.
+ *    out_color [3,H,W], radii [N] are caller-allocated outputs; `state` receives the pointers the backward needs and
+ *    n_isects (the list length — feed it back as the next frame's hint).
+ * ---------------------------------------------------------------------------------------- */
+enum { GSPL_BUF_GEOMETRY = 1, GSPL_BUF_BINNING = 2, GSPL_BUF_IMAGE = 3, GSPL_BUF_LISTS_WORK = 4, GSPL_BUF_LISTS = 5 };
+typedef void* (*gspl_alloc_fn)(void* ctx, int tag, size_t bytes);      /* device memory, 256-byte aligned; NULL = failure */
+typedef struct gspl_inria_state {
+    int N, width, height;
+    int64_t n_isects;
+    float* means2d; float* depths; float* conics; float* colors; uint8_t* clamped; float* cov3d;      /* GSPL_BUF_GEOMETRY */
+    float* alphas; float* final_Ts; int32_t* last_ids; int32_t* offsets;                               /* GSPL_BUF_IMAGE */
+    int32_t* flatten_ids;                                                                              /* GSPL_BUF_LISTS */
+} gspl_inria_state;
+size_t gspl_rasterize_inria_geometry_bytes(int N);
+size_t gspl_rasterize_inria_image_bytes(int width, int height);
+int gspl_rasterize_inria_fwd(int N, int degree, int n_coeffs,
+                             const float* means3D, const float* scales /*nullable*/, const float* rotations /*nullable*/,
+                             const float* cov3D_precomp /*nullable*/, const float* shs /*nullable*/, const float* colors_precomp /*nullable*/,
+                             const float* opacities,
+                             const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+                             int width, int height, float tanfovx, float tanfovy, float scale_modifier,
+                             gspl_alloc_fn alloc, void* alloc_ctx, int64_t capacity_hint,
+                             float* out_color, int32_t* radii, gspl_inria_state* state,
+                             void* stream, void* side_stream /*nullable: colours on `stream`*/);
+/*    Backward: packed [N,9] f32 scratch and hit_flags [N] u8 (nullable) are cleared inside; every v_* is caller-allocated
+ *    ([N,3], [N,3] NDC-scaled, [N,n_coeffs,3] | [N,3], [N], [N,3], [N,4] | [N,6]; the ones that do not apply are NULL). */
+int gspl_rasterize_inria_bwd(int degree, int n_coeffs,
+                             const float* means3D, const float* scales, const float* rotations, const float* shs, const float* opacities,
+                             const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+                             float tanfovx, float tanfovy, float scale_modifier,
+                             const int32_t* radii, const gspl_inria_state* state, const float* v_out_color,
+                             float* packed, uint8_t* hit_flags /*nullable*/,
+                             float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_colors_precomp, float* v_opacities,
+                             float* v_scales, float* v_rotations, float* v_cov3D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 7. Mean squared distance to the 3 nearest neighbours ("next" row SURVEY.md §8f rank 1).
  *    Replaces `simple_knn._C.distCUDA2` at its one call site, the initial scales of
  *    `VanillaGaussianModel.setup_from_pcd` (internal/models/vanilla_gaussian.py:122-125):
