@@ -217,6 +217,29 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+class device_guard:
+    """`with device_guard(tensor):` makes the tensor's device current for the enclosed launches (so that `stream()` hands
+    out THAT device's current stream) and restores the previous one; free when it already is the current device."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        dev = t.device if hasattr(t, "device") else t
+        self.idx = dev.index if dev.index is not None else (_raw_device() if _raw_device is not None else torch.cuda.current_device())
+        self.prev = -1
+
+    def __enter__(self):
+        cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def stream():
     """Raw handle of torch's current stream on the current device.  `torch.cuda.current_stream().cuda_stream` costs ~10 us
     of Python per call (device-index plumbing, a Stream object) and every op wrapper needs it: the C accessors do the

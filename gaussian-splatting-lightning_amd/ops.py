@@ -32,6 +32,27 @@ def _packed_row_stride(nv: int) -> int:
     return max(nv, _PACKED_ROW_STRIDE)
 
 
+def _guarded(pos: int):
+    """Decorator: run the function with the device of its `pos`-th positional argument (a tensor, or for a backward the
+    autograd context whose first saved tensor decides) made current, so that kernels are enqueued on THAT device's current
+    stream even when the caller's current device is another one (single-process multi-GPU, viewer / eval helpers)."""
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            a = args[pos]
+            if not isinstance(a, Tensor):
+                saved = getattr(a, "saved_tensors", None)
+                a = next((t for t in (saved or ()) if isinstance(t, Tensor)), None)
+            if a is None or not a.is_cuda:
+                return fn(*args, **kwargs)
+            with L.device_guard(a):
+                return fn(*args, **kwargs)
+        return wrapper
+    return deco
+
+
 def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
     if t is None:
         return None
@@ -74,6 +95,7 @@ def _grad_or_zeros(g: Optional[Tensor], like_shape, device) -> Tensor:
 # =============================================================================================
 class _ProjectFn(torch.autograd.Function):
     @staticmethod
+    @_guarded(1)
     def forward(ctx, means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier,
                 eps2d, near_plane, far_plane, radius_clip, calc_compensations, want_tiles):
         lib = L.lib()
@@ -103,6 +125,7 @@ class _ProjectFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @_guarded(0)
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, _v_tiles):
         lib = L.lib()
         means, scales, quats, viewmats, Ks, radii = ctx.saved_tensors
@@ -215,6 +238,7 @@ def project_gaussians(
 # =============================================================================================
 class _SHFn(torch.autograd.Function):
     @staticmethod
+    @_guarded(2)
     def forward(ctx, degree, dirs, origin, dc, rest, masks, flags):
         """dc: [N,K,3] merged (rest is None) or [N,1,3]; rest: [N,K-1,3] or None."""
         lib = L.lib()
@@ -248,6 +272,7 @@ class _SHFn(torch.autograd.Function):
         return colors
 
     @staticmethod
+    @_guarded(0)
     def backward(ctx, v_colors):
         lib = L.lib()
         dirs, origin, dc, rest, mask8, clamped = ctx.saved_tensors
@@ -356,6 +381,7 @@ def sh_view_colors_batched(degree: int, means: Tensor, camera_centers: Tensor, d
 # =============================================================================================
 # tile binning
 # =============================================================================================
+@_guarded(1)
 def _isect(mode: int, means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_w: int, tile_h: int):
     lib = L.lib()
     means2d, depths = _f32c(means2d.detach()), _f32c(depths.detach())
@@ -402,6 +428,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     return tiles[None], ids, flat
 
 
+@_guarded(0)
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     """gsplat-v1 signature (gsplat_v1_renderer.py:458) -> offsets [n_cameras, tile_height, tile_width] i32."""
     if n_cameras != 1:
@@ -429,6 +456,7 @@ LAST_RASTER: Optional[dict] = None
 
 class _CompositeFn(torch.autograd.Function):
     @staticmethod
+    @_guarded(1)
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, offsets, flatten_ids,
                 absgrad, mode, layout, track_hits=False):
         lib = L.lib()
@@ -468,6 +496,7 @@ class _CompositeFn(torch.autograd.Function):
         return out, alphas
 
     @staticmethod
+    @_guarded(0)
     def backward(ctx, v_out, v_alphas):
         lib = L.lib()
         means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids = ctx.saved_tensors
@@ -649,6 +678,7 @@ _LAST_ISECTS: dict = {}       # (device, tile grid) -> list length of the last f
 SPECULATIVE_EMIT = os.environ.get("GSPL_SPECULATIVE_EMIT", "1") != "0"
 
 
+@_guarded(0)
 def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, img_width: int, block_width: int = 16,
                         mode: int = L.GSPL_MODE_GSPLAT, conics: Optional[Tensor] = None,
                         opacities: Optional[Tensor] = None) -> _PendingBins:
@@ -717,6 +747,11 @@ def _emit(p: "_PendingBins"):
 def bin_gaussians_end(p: _PendingBins):
     """Second half: waits for the count, then (emits and) sorts the (tile, Gaussian) lists.
     Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
+    with L.device_guard(p.dev):
+        return _bin_gaussians_end(p)
+
+
+def _bin_gaussians_end(p: _PendingBins):
     lib = L.lib()
     n_isects = 0
     if p.N > 0:
@@ -797,6 +832,7 @@ class GaussianRasterizationSettings(NamedTuple):
 
 class _InriaRasterizeFn(torch.autograd.Function):
     @staticmethod
+    @_guarded(1)
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
         lib = L.lib()
         s: GaussianRasterizationSettings = settings
@@ -858,6 +894,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
         return out, radii
 
     @staticmethod
+    @_guarded(0)
     def backward(ctx, v_out, _v_radii):
         lib = L.lib()
         (means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
@@ -927,6 +964,7 @@ def _view(buf: Tensor, ptr: int, shape, dtype) -> Tensor:
 
 class _InriaFusedFn(torch.autograd.Function):
     @staticmethod
+    @_guarded(1)
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
         import ctypes
         s: GaussianRasterizationSettings = settings
@@ -994,6 +1032,7 @@ class _InriaFusedFn(torch.autograd.Function):
         return out, radii
 
     @staticmethod
+    @_guarded(0)
     def backward(ctx, v_out, _v_radii):
         import ctypes
         means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii = ctx.saved_tensors

@@ -20,9 +20,19 @@ from . import _lib as L
 class _FusedAdamBase(torch.optim.Optimizer):
     _bias_correction = True
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False, maximize: bool = False, **unsupported):
+        """The keyword arguments of `torch.optim.Adam` are accepted so that configurations written for it construct this
+        class; the ones the kernel does not implement must keep their default values."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
+        if weight_decay != 0.0 or amsgrad or maximize:
+            raise NotImplementedError("fused Adam: weight_decay / amsgrad / maximize are not implemented (the reference never sets them)")
+        for k, v in unsupported.items():      # foreach / capturable / differentiable / fused: execution hints of torch.optim.Adam
+            if k not in ("foreach", "capturable", "differentiable", "fused"):
+                raise TypeError(f"fused Adam: unexpected argument {k!r}")
+            if k in ("capturable", "differentiable") and v:
+                raise NotImplementedError(f"fused Adam: {k}=True is not implemented")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     def _launch(self, visibility: Optional[torch.Tensor]):
@@ -43,7 +53,8 @@ class _FusedAdamBase(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                # a state loaded from a `torch.optim.Adam` checkpoint keeps `step` as a tensor: a python int from here on
+                st["step"] = int(st["step"]) + 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 N = p.shape[0] if p.dim() > 0 else 1
                 row = p.numel() // max(N, 1)
@@ -61,10 +72,12 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 chunk = items[i:i + L.GSPL_ADAM_MAX_TENSORS]
                 table = (L.AdamTensor * len(chunk))()
                 for k, (p, g, m, v, lr, row) in enumerate(chunk):
+                    if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous() or m.dtype != torch.float32:
+                        raise RuntimeError("fused Adam: exp_avg / exp_avg_sq must be contiguous fp32 tensors of the parameter's shape")
                     table[k] = L.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr, row)
                 with torch.cuda.device(dev):
                     L.call("gspl_selective_adam", len(chunk), ctypes.cast(table, ctypes.c_void_p), N, L.ptr(vis),
-                           b1, b2, eps, bc1, bc2s, L.stream())
+                           float(b1), float(b2), float(eps), float(bc1), float(bc2s), L.stream())
 
 
 class SelectiveAdam(_FusedAdamBase):

@@ -26,13 +26,20 @@ def _project(means3D, scales, rotations, viewpoint_camera, scaling_modifier, blo
     kernel_size = extra.pop("filter_2d_kernel_size", kernel_size)
     # the full, contiguous 4x4 world->camera matrix, built once per camera object (the reference hands the kernel a [3,4]
     # transposed view per frame; completing and copying it is a launch per frame)
-    vm = getattr(viewpoint_camera, "_gspl_viewmat", None)
-    if vm is None or vm.device != means3D.device:
-        vm = viewpoint_camera.world_to_camera.T.to(device=means3D.device, dtype=torch.float32).contiguous()
-        try:
-            viewpoint_camera._gspl_viewmat = vm
-        except Exception:      # a frozen camera type: no cache
-            pass
+    # (the cache is keyed on the source tensor's identity AND version counter: a pose updated in place — pose refinement,
+    # viewer edits — or replaced is seen; a pose that takes part in autograd is never cached)
+    w2c = viewpoint_camera.world_to_camera
+    cached = getattr(viewpoint_camera, "_gspl_viewmat", None)
+    if (cached is not None and cached[0] is w2c and cached[1] == w2c._version and cached[2].device == means3D.device
+            and not w2c.requires_grad):
+        vm = cached[2]
+    else:
+        vm = w2c.T.to(device=means3D.device, dtype=torch.float32).contiguous()
+        if not w2c.requires_grad:
+            try:
+                viewpoint_camera._gspl_viewmat = (w2c, w2c._version, vm.detach())
+            except Exception:      # a frozen camera type: no cache
+                pass
     return ops.project_gaussians(
         means3d=means3D, scales=scales, glob_scale=scaling_modifier, quats=rotations,
         viewmat=vm,

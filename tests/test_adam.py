@@ -86,3 +86,36 @@ def test_selective_adam_rejects_bad_inputs():
     cpu.grad = torch.ones_like(cpu)
     with pytest.raises(RuntimeError):
         SelectiveAdam([cpu]).step(torch.ones(8, dtype=torch.bool))
+
+
+def test_fused_adam_resumes_a_torch_adam_state_and_accepts_its_kwargs():
+    """A reference checkpoint's optimizer state (torch.optim.Adam: `step` is a tensor) loads into HipFusedAdam's optimizer and
+    the next steps match torch.optim.Adam's; Adam's keyword arguments are accepted at their defaults, refused otherwise."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import optimizers as gopt
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(1000, 3, generator=g)
+    grads = [torch.randn(1000, 3, generator=g) for _ in range(4)]
+    ref_p = p0.clone().cuda().requires_grad_(True)
+    ref = torch.optim.Adam([{"params": [ref_p], "name": "means"}], lr=1e-2, eps=1e-15)
+    for k in range(2):
+        ref_p.grad = grads[k].cuda()
+        ref.step()
+    sd = ref.state_dict()                         # what a checkpoint holds: state[0]["step"] is a tensor
+    assert isinstance(sd["state"][0]["step"], torch.Tensor)
+    my_p = ref_p.detach().clone().requires_grad_(True)
+    mine = gopt.HipFusedAdam().instantiate([{"params": [my_p], "name": "means"}], lr=1e-2, eps=1e-15, weight_decay=0.0, amsgrad=False)
+    mine.load_state_dict(sd)
+    for k in range(2, 4):
+        ref_p.grad = grads[k].cuda()
+        my_p.grad = grads[k].cuda()
+        ref.step()
+        mine.step()
+    assert float((ref_p - my_p).abs().max()) <= 2e-6
+    assert mine.state[my_p]["step"] == 4 and isinstance(mine.state[my_p]["step"], int)
+    with pytest.raises(NotImplementedError):
+        gopt.FusedAdam([my_p], lr=1e-3, weight_decay=0.1)
+    with pytest.raises(NotImplementedError):
+        gopt.FusedAdam([my_p], lr=1e-3, amsgrad=True)
+    with pytest.raises(TypeError):
+        gopt.FusedAdam([my_p], lr=1e-3, nonsense=1)

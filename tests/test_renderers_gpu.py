@@ -217,3 +217,29 @@ def test_concurrent_streams_are_reentrant():
     for th in threads:
         th.join()
     assert not bad
+
+
+def test_gsplat_renderer_sees_pose_updates_and_other_devices_current():
+    """The per-camera view-matrix cache is keyed on the pose tensor's identity and version: an in-place pose update (pose
+    refinement, viewer edits) changes the render.  And a render with tensors on cuda:0 is unaffected by what the caller's
+    current device is (checked with the guard's bookkeeping: one device on the test boxes)."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import _lib as L
+    from gspl_amd.renderers import HipGSplatRenderer
+    params, cam, wimg, bg = _scene(seed=35, n=2000)
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    camera = FakeCamera(cam, DEV)
+    r = HipGSplatRenderer()
+    with torch.no_grad():
+        a = r(camera, model, bg.to(DEV))["render"].clone()
+        b = r(camera, model, bg.to(DEV))["render"]
+        assert torch.equal(a, b)
+        camera.world_to_camera[3, 0] += 0.25                       # in place: same tensor object, new version
+        c = r(camera, model, bg.to(DEV))["render"]
+        assert float((a - c).abs().max()) > 1e-3
+        camera.world_to_camera = camera.world_to_camera.clone()    # replaced: same values
+        d = r(camera, model, bg.to(DEV))["render"]
+        assert torch.equal(c, d)
+    g = L.device_guard(params[0].to(DEV))
+    with g:
+        assert g.prev == -1 and torch.cuda.current_device() == 0      # already current: nothing switched, nothing to restore
