@@ -102,6 +102,8 @@ _SIGNATURES = {
                                          ALLOC_FN, _P, c_int64, _P, _P, ctypes.POINTER(InriaState), _P, _P]),
     "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
                                          _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_profile_enable": (c_int, [c_int]),
+    "gspl_profile_read": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),
     "gspl_rasterize_inria_geometry_bytes": (c_size_t, [c_int]),
     "gspl_rasterize_inria_image_bytes": (c_size_t, [c_int, c_int]),
     "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -167,16 +169,24 @@ def profile_start(names=None):
     global _PROFILE, _PROFILE_NAMES
     _PROFILE = []
     _PROFILE_NAMES = None if names is None else frozenset(names)
+    lib().gspl_profile_enable(1)
 
 
 def profile_stop():
-    """Returns {name: [ms, ...]} (synchronises)."""
+    """Returns {name: [ms, ...]} (synchronises).  The compositing launches made inside the fused Inria calls are reported
+    under the names of their stage entry points (as one entry holding the mean, repeated per launch)."""
     global _PROFILE
     rec, _PROFILE = _PROFILE, None
     torch.cuda.synchronize()
     out = {}
     for name, e0, e1 in rec or []:
         out.setdefault(name, []).append(e0.elapsed_time(e1))
+    for which, name in ((0, "gspl_composite_fwd"), (1, "gspl_composite_bwd_packed")):
+        n, ms = c_int(0), c_float(0.0)
+        check(lib().gspl_profile_read(which, ctypes.byref(n), ctypes.byref(ms)), "gspl_profile_read")
+        if n.value > 0 and (_PROFILE_NAMES is None or name in _PROFILE_NAMES):
+            out.setdefault(name, []).extend([ms.value / n.value] * n.value)
+    lib().gspl_profile_enable(0)
     return out
 
 

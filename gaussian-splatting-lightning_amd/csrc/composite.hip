@@ -944,6 +944,322 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, third structure: phase 1 of composite_bwd2_kernel (two pixels per lane, packed fp32), a phase 2 that works on
+// 8x8 QUADRANT entries and raw moments.
+//   * A candidate of the 16x8 half tile touches its left quadrant (the lanes' pixels A), its right one (pixels B) or both
+//     (64 % on the metric workload).  Phase 1 emits one slab ENTRY per touched quadrant — decided by "some pixel of the
+//     quadrant really takes the splat", not by the coarser reachability mask — instead of one 128-pixel slot per candidate whose
+//     other half is zeros a third of the time.
+//   * Phase 2 lanes are (quadrant q = l >> 5, entry e of 4, column c of 8): lanes 0-31 serve left-quadrant entries, lanes
+//     32-63 right-quadrant ones, so that each lane's dL/dout column stays in registers.  A batch closes when either side has
+//     4 entries: on average 7.3 entries = 4.45 candidates per batch (4 before), the cross-lane reduction spans 8 lanes
+//     (three DPP levels) instead of 16.
+//   * The reduction carries RAW moments about the splat centre (sum sp, sp dx, sp dy, sp dx^2, sp dx dy, sp dy^2) and colour
+//     sums; the conversion to gradients (linear in them) happens once per (tile, splat) at the flush instead of once per
+//     (wave, candidate, lane).  No `live` branch, no zero-initialised accumulators: lanes of unused entries compute on stale
+//     slab contents and simply do not add (the reduction never crosses an entry).
+#ifndef GSPL_BWD3_WAVES
+#define GSPL_BWD3_WAVES 5
+#endif
+template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
+__global__ __launch_bounds__(128, GSPL_BWD3_WAVES) void composite_bwd3_kernel(
+    int n_tiles, int tile_w, int width, int height, int64_t n_isects,
+    const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+    const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
+    float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride,
+    uint8_t* __restrict__ hit_flags) {
+    using TR = ModeTraits<MODE>;
+    constexpr int NV = BwdVals<D, ABS>::N;            // s_acc row: Sx Sy Sxx Sxy Syy S0 colour[D] (abs x, abs y)
+    constexpr int RS = BwdRec<D>::STRIDE;
+    constexpr bool VO_REGS = D <= 4;
+    constexpr int QE = 4;                             // entries per quadrant side and batch
+    constexpr int PLANE = 2 * QE * 64;                // floats of one plane (fac or sp) of a wave's slab
+    constexpr int SLAB = 2 * PLANE;
+    static_assert(NV <= 16, "kept[] covers 16 values");
+    __shared__ int s_id[B2CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_rec[B2CHUNK * RS];
+    __shared__ float s_acc[B2CHUNK * NV];
+    __shared__ __attribute__((aligned(16))) float s_slab[2 * SLAB];
+    __shared__ __attribute__((aligned(16))) float s_vo_keep[VO_REGS ? 4 : 2 * 128 * D];
+    static_assert(!VO_REGS || 2 * 128 * D <= 2 * SLAB, "s_vo alias too small");
+    float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column 0..15][channel][row]
+    __shared__ int s_last;
+
+    const int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int tx = (tile % tile_w) * TILE, ty = (tile / tile_w) * TILE;
+    const int pxA = tx + (l & 7), pxB = pxA + 8;
+    const int py = ty + w * 8 + (l >> 3);
+    const bool insideA = (pxA < width) && (py < height), insideB = (pxB < width) && (py < height);
+    const v2f pxf2 = {(float)pxA + TR::kPixelCentre, (float)pxB + TR::kPixelCentre};
+    const float pyf = (float)py + TR::kPixelCentre;
+    const float hx0 = (float)tx + TR::kPixelCentre;
+    const float hy0 = (float)(ty + w * 8) + TR::kPixelCentre;
+    const int64_t pixA = (int64_t)py * width + pxA, pixB = pixA + 8;
+    const int tl = (l & 7) * 8 + (l >> 3);            // the pixel's place inside an entry (column-major 8x8)
+    const int pq = l >> 5, pe = (l >> 3) & 3, pc = l & 7;      // phase-2 role: quadrant side, entry, column
+    float* slab = s_slab + w * SLAB;
+
+    int start, end;
+    tile_range(tile, n_tiles, n_isects, offsets, start, end);
+
+    const int lastA = insideA ? last_ids[pixA] : start, lastB = insideB ? last_ids[pixB] : start;
+    v2f T2 = {insideA ? final_Ts[pixA] : 1.f, insideB ? final_Ts[pixB] : 1.f};
+    v2f vo[D];
+    v2f bgdot = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        vo[c] = (v2f){0.f, 0.f};
+        if (insideA) vo[c].x = CHW ? v_out_colors[(int64_t)c * width * height + pixA] : v_out_colors[pixA * D + c];
+        if (insideB) vo[c].y = CHW ? v_out_colors[(int64_t)c * width * height + pixB] : v_out_colors[pixB * D + c];
+        if (backgrounds) bgdot += backgrounds[c] * vo[c];
+        s_vo[((w * 16 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].x;
+        s_vo[((w * 16 + 8 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].y;
+    }
+    const v2f v_out_a = {(insideA && v_out_alphas) ? v_out_alphas[pixA] : 0.f, (insideB && v_out_alphas) ? v_out_alphas[pixB] : 0.f};
+    v2f R2 = T2 * (v_out_a - bgdot);
+
+    if (t == 0) s_last = start;
+    for (int q = t; q < B2CHUNK * NV; q += 128) s_acc[q] = 0.f;
+    __syncthreads();
+    v2f vo2[VO_REGS ? 4 : 1][VO_REGS ? D : 1];        // phase-2 view of dL/dout: column pq * 8 + pc, rows in pairs
+    if constexpr (VO_REGS) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const float4* vp = reinterpret_cast<const float4*>(s_vo + ((w * 16 + pq * 8 + pc) * D + c) * 8);
+            const float4 v0 = vp[0], v1 = vp[1];
+            vo2[0][c] = (v2f){v0.x, v0.y}; vo2[1][c] = (v2f){v0.z, v0.w};
+            vo2[2][c] = (v2f){v1.x, v1.y}; vo2[3][c] = (v2f){v1.z, v1.w};
+        }
+    }
+    int wl = max(lastA, lastB);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl = max(wl, __shfl_xor(wl, off));
+    if (l == 0) atomicMax(&s_last, wl);
+    __syncthreads();
+    const int block_last = s_last;
+    const int wave_last = wl;
+
+    int nbA = 0, nbB = 0;                    // entries waiting on the left / right side (wave-uniform)
+    int batch_j = 0;                         // lane q * 4 + e holds the staged slot index of entry (q, e)
+
+    auto phase2 = [&](int countA, int countB) {
+        __builtin_amdgcn_wave_barrier();
+        const int j = __builtin_amdgcn_ds_bpermute((pq * QE + pe) << 2, batch_j);
+        const bool live = pe < (pq ? countB : countA);
+        const float* rec = s_rec + j * RS;
+        const float2 xy = *reinterpret_cast<const float2*>(rec);
+        const float dx = xy.x - (hx0 + (float)(pq * 8 + pc));
+        const float dy0 = xy.y - hy0;
+        const v2f dy0v = {dy0, dy0};
+        const float4* Fp = reinterpret_cast<const float4*>(slab + (pq * QE + pe) * 64 + pc * 8);
+        const float4* Sp = reinterpret_cast<const float4*>(slab + PLANE + (pq * QE + pe) * 64 + pc * 8);
+        const float4 f0 = Fp[0], f1 = Fp[1], q0 = Sp[0], q1 = Sp[1];
+        const v2f F2[4] = {{f0.x, f0.y}, {f0.z, f0.w}, {f1.x, f1.y}, {f1.z, f1.w}};
+        const v2f S2[4] = {{q0.x, q0.y}, {q0.z, q0.w}, {q1.x, q1.y}, {q1.z, q1.w}};
+        v2f s02 = {0.f, 0.f}, sy2 = {0.f, 0.f}, syy2 = {0.f, 0.f};
+        v2f rgb2[D];
+        float ax = 0.f, ay = 0.f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) rgb2[c] = (v2f){0.f, 0.f};
+        float ca = 0.f, cb = 0.f, cc_ = 0.f;
+        if constexpr (ABS) { ca = 2.f * rec[2]; cc_ = 2.f * rec[3]; cb = rec[4]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const v2f dy2 = dy0v - (v2f){(float)(2 * k), (float)(2 * k + 1)};
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                v2f vv;
+                if constexpr (VO_REGS) vv = vo2[k][c];
+                else vv = *reinterpret_cast<const v2f*>(s_vo + ((w * 16 + pq * 8 + pc) * D + c) * 8 + 2 * k);
+                rgb2[c] = __builtin_elementwise_fma(F2[k], vv, rgb2[c]);
+            }
+            s02 += S2[k];
+            const v2f tq = S2[k] * dy2;
+            sy2 += tq;
+            syy2 = __builtin_elementwise_fma(tq, dy2, syy2);
+            if constexpr (ABS) {
+                ax += fabsf(S2[k].x * (ca * dx + cb * dy2.x)) + fabsf(S2[k].y * (ca * dx + cb * dy2.y));
+                ay += fabsf(S2[k].x * (cb * dx + cc_ * dy2.x)) + fabsf(S2[k].y * (cb * dx + cc_ * dy2.y));
+            }
+        }
+        float vals[NV];
+        const float S0 = s02.x + s02.y, Sy = sy2.x + sy2.y;
+        const float Sx = S0 * dx;
+        vals[0] = Sx;                        // sum sp dx
+        vals[1] = Sy;                        // sum sp dy
+        vals[2] = Sx * dx;                   // sum sp dx^2
+        vals[3] = Sy * dx;                   // sum sp dx dy
+        vals[4] = syy2.x + syy2.y;           // sum sp dy^2
+        vals[5] = S0;                        // sum sp
+#pragma unroll
+        for (int c = 0; c < D; ++c) vals[6 + c] = rgb2[c].x + rgb2[c].y;
+        if constexpr (ABS) { vals[6 + D] = ax; vals[7 + D] = ay; }
+        // 8 lanes per entry: two quad levels on every value, then lane k of the first quad keeps the values k, k + 4, ... and
+        // its mirror lane 7 - k of the second quad keeps the same ones; one row_half_mirror add finishes them
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            vals[k] = dpp_add<0xB1, 0xF>(vals[k]);    // quad_perm [1,0,3,2]
+            vals[k] = dpp_add<0x4E, 0xF>(vals[k]);    // quad_perm [2,3,0,1]
+        }
+        constexpr int NK = (NV + 3) / 4;
+        const int idx = (pc & 4) ? 3 - (pc & 3) : (pc & 3);
+        float kept[NK];
+#pragma unroll
+        for (int m = 0; m < NK; ++m) {
+            float v = vals[4 * m];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) v = (idx == q) ? ((4 * m + q < NV) ? vals[(4 * m + q < NV) ? 4 * m + q : 0] : 0.f) : v;
+            kept[m] = dpp_add<0x141, 0xF>(v);         // row_half_mirror
+        }
+#pragma unroll
+        for (int m = 0; m < NK; ++m)
+            if (live && pc < 4 && 4 * m + pc < NV) atomicAdd(&s_acc[j * NV + 4 * m + pc], kept[m]);
+    };
+
+    int g_next = (block_last - 1 - t >= start && t < B2CHUNK) ? flatten_ids[block_last - 1 - t] : 0;
+    for (int hi = block_last; hi > start; hi -= B2CHUNK) {
+        const int lo = max(start, hi - B2CHUNK);
+        const int cnt = hi - lo;
+        const int g = g_next;
+        {
+            const int i_next = hi - B2CHUNK - 1 - t;
+            if (i_next >= start && t < B2CHUNK) g_next = flatten_ids[i_next];
+        }
+        if (t < cnt) {
+            s_id[t] = g;
+            const float ca = conics[g * 3 + 0], cb = conics[g * 3 + 1], cc = conics[g * 3 + 2], op = opacities[g];
+            const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
+            const unsigned qm = quadrant_mask(mx, my, ca, cb, cc, op, (float)tx + TR::kPixelCentre, (float)ty + TR::kPixelCentre);
+            float* rec = s_rec + t * RS;
+            *reinterpret_cast<float4*>(rec) = make_float4(mx, my, 0.5f * ca, 0.5f * cc);
+            *reinterpret_cast<float4*>(rec + 4) = make_float4(cb, op, __uint_as_float(qm), 0.f);
+#pragma unroll
+            for (int c = 0; c < D; ++c) rec[8 + c] = colors[(int64_t)g * D + c];
+        }
+        __syncthreads();
+        if (wave_last > lo) {
+#pragma unroll 1
+            for (int kk = 0; kk < (B2CHUNK + 63) / 64; ++kk) {
+                const int slot = kk * 64 + l;
+                const unsigned qm = (slot < B2CHUNK) ? __float_as_uint(s_rec[slot * RS + 6]) : 0u;
+                const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && ((qm >> (2 * w)) & 3u);
+                unsigned long long mask = __ballot(cand);
+                while (mask) {
+                    const int j = kk * 64 + (int)__builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int idx = hi - 1 - j;
+                    const float* rec = s_rec + j * RS;
+                    const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 c/2
+                    const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // b opacity
+                    float col[D];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) col[c] = rec[8 + c];
+                    const v2f dx2 = (v2f){r0.x, r0.x} - pxf2;
+                    const float dy = r0.y - pyf;
+                    const float hcdy = r0.w * dy;
+                    const v2f dy2 = {dy, dy};
+                    const v2f inner = __builtin_elementwise_fma((v2f){hcdy, hcdy}, dy2, ((v2f){r1.x, r1.x} * dx2) * dy2);
+                    const v2f sigma2 = __builtin_elementwise_fma((v2f){r0.z, r0.z} * dx2, dx2, inner);
+                    const v2f arg2 = sigma2 * (v2f){-1.4426950408889634f, -1.4426950408889634f};
+                    const v2f vis2 = {__builtin_amdgcn_exp2f(arg2.x), __builtin_amdgcn_exp2f(arg2.y)};
+                    const v2f raw2 = (v2f){r1.y, r1.y} * vis2;
+                    const bool validA = (idx < lastA) && (sigma2.x >= 0.f) && (raw2.x >= kAlphaMin);
+                    const bool validB = (idx < lastB) && (sigma2.y >= 0.f) && (raw2.y >= kAlphaMin);
+                    const bool anyA = __ballot(validA) != 0ull, anyB = __ballot(validB) != 0ull;      // wave-uniform
+                    if (!(anyA || anyB)) continue;
+                    if (hit_flags && l == 0) atomicOr(&s_id[j], (int)0x80000000);
+                    // a side without room closes the batch first
+                    if ((anyA && nbA == QE) || (anyB && nbB == QE)) { phase2(nbA, nbB); nbA = nbB = 0; }
+                    const v2f rv2 = {validA ? raw2.x : 0.f, validB ? raw2.y : 0.f};
+                    // rv >= 0: the median of (rv, 0, alpha_max) is min(alpha_max, rv) in one instruction
+                    const v2f a2 = {__builtin_amdgcn_fmed3f(rv2.x, 0.f, TR::kAlphaMax), __builtin_amdgcn_fmed3f(rv2.y, 0.f, TR::kAlphaMax)};
+                    v2f rw2 = rv2;
+                    if (TR::kClampKillsGrad) rw2 = (v2f){(rv2.x <= TR::kAlphaMax) ? rv2.x : 0.f, (rv2.y <= TR::kAlphaMax) ? rv2.y : 0.f};
+                    const v2f om2 = (v2f){1.f, 1.f} - a2;
+                    const v2f ra2 = {__builtin_amdgcn_rcpf(om2.x), __builtin_amdgcn_rcpf(om2.y)};
+                    T2 *= ra2;
+                    const v2f fac2 = a2 * T2;
+                    v2f cdot2 = (v2f){col[0], col[0]} * vo[0];
+#pragma unroll
+                    for (int c = 1; c < D; ++c) cdot2 = __builtin_elementwise_fma((v2f){col[c], col[c]}, vo[c], cdot2);
+                    const v2f v_alpha2 = __builtin_elementwise_fma(cdot2, T2, R2 * ra2);
+                    R2 = __builtin_elementwise_fma(-cdot2, fac2, R2);
+                    const v2f sp2 = -rw2 * v_alpha2;
+                    if (anyA) {
+                        float* F = slab + nbA * 64 + tl;
+                        F[0] = fac2.x; F[PLANE] = sp2.x;
+                        batch_j = gspl_writelane_i32(j, nbA, batch_j);
+                        nbA = __builtin_amdgcn_readfirstlane(nbA + 1);      // (keeps the counter in a scalar register)
+                    }
+                    if (anyB) {
+                        float* F = slab + (QE + nbB) * 64 + tl;
+                        F[0] = fac2.y; F[PLANE] = sp2.y;
+                        batch_j = gspl_writelane_i32(j, QE + nbB, batch_j);
+                        nbB = __builtin_amdgcn_readfirstlane(nbB + 1);
+                    }
+                }
+            }
+            if (nbA | nbB) { phase2(nbA, nbB); nbA = nbB = 0; }
+        }
+        __syncthreads();
+        // raw moments -> gradients, once per staged splat and in place (thread = row: no divergence, rows are 9 floats apart:
+        // no bank conflicts); then the flush of composite_bwd2_kernel: one fp32 L2 atomic per non-zero value
+        if (t < cnt) {
+            float* a = s_acc + t * NV;
+            const float* rec = s_rec + t * RS;
+            const float ca = 2.f * rec[2], cc = 2.f * rec[3], cb = rec[4], op = rec[5];
+            const float Sx = a[0], Sy = a[1];
+            a[0] = ca * Sx + cb * Sy;                                              // dL/dx
+            a[1] = cb * Sx + cc * Sy;                                              // dL/dy
+            a[2] *= 0.5f;                                                          // dL/da   (a[3] = dL/db as is)
+            a[4] *= 0.5f;                                                          // dL/dc
+            a[5] = (op != 0.f) ? -a[5] * __builtin_amdgcn_rcpf(op) : 0.f;          // dL/dopacity = -sum(sp) / o
+        }
+        __syncthreads();
+        if constexpr (PACKED) {
+            float* __restrict__ v_packed = v_means2d;
+            for (int e = t; e < cnt * NV; e += 128) {
+                const float v = s_acc[e];
+                s_acc[e] = 0.f;
+                const int row = e / NV;
+                if (v != 0.f) atomicAdd(&v_packed[(int64_t)(s_id[row] & 0x7fffffff) * packed_stride + (e - row * NV)], v);
+            }
+        } else if (t < cnt) {
+            const int g = s_id[t] & 0x7fffffff;
+            float v[NV];
+            bool any_nz = false;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                v[q] = s_acc[t * NV + q];
+                s_acc[t * NV + q] = 0.f;
+                any_nz = any_nz || (v[q] != 0.f);
+            }
+            if (any_nz) {
+                atomicAdd(&v_means2d[g * 2 + 0], v[0]);
+                atomicAdd(&v_means2d[g * 2 + 1], v[1]);
+                atomicAdd(&v_conics[g * 3 + 0], v[2]);
+                atomicAdd(&v_conics[g * 3 + 1], v[3]);
+                atomicAdd(&v_conics[g * 3 + 2], v[4]);
+                atomicAdd(&v_opacities[g], v[5]);
+#pragma unroll
+                for (int c = 0; c < D; ++c) atomicAdd(&v_colors[(int64_t)g * D + c], v[6 + c]);
+                if constexpr (ABS) {
+                    atomicAdd(&v_means2d_abs[g * 2 + 0], v[6 + D]);
+                    atomicAdd(&v_means2d_abs[g * 2 + 1], v[7 + D]);
+                }
+            }
+        }
+        if (hit_flags && t < cnt && s_id[t] < 0) hit_flags[s_id[t] & 0x7fffffff] = 1;
+        __syncthreads();
+    }
+}
+
 template <int D, int MODE, bool CHW>
 static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
@@ -968,6 +1284,19 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
                       hipStream_t s, int packed_stride = 0, uint8_t* hit_flags = nullptr) {
+#ifdef GSPL_BWD_V3       // quadrant-entry phase 2, raw moments (A/B builds until it is the default)
+    if (absgrad)
+        hipLaunchKernelGGL((composite_bwd3_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
+                           n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
+                           offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
+    else
+        hipLaunchKernelGGL((composite_bwd3_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(128), 0, s,
+                           n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
+                           offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
+                           v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
+    return check_launch("composite_bwd");
+#endif
 #ifndef GSPL_BWD_V2      // default: the two-pixels-per-lane kernel; -DGSPL_BWD_V2 selects the one-pixel-per-lane kernel (A/B builds)
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
@@ -1197,7 +1526,9 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
 
 // Name of the kernel template gspl_composite_bwd / gspl_composite_bwd_packed launch in this build (for profile look-ups).
 extern "C" const char* gspl_composite_bwd_kernel_name(void) {
-#ifndef GSPL_BWD_V2
+#if defined(GSPL_BWD_V3)
+    return "composite_bwd3_kernel";
+#elif !defined(GSPL_BWD_V2)
     return "composite_bwd2_kernel";
 #else
     return "composite_bwd_kernel";

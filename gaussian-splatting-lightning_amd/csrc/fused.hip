@@ -11,6 +11,9 @@
 // (torch's caching allocator on the Python side), nothing is hipMalloc'ed, the only persistent host resource is a small
 // pinned word per thread for the one read-back of the frame (the list length that sizes the tile sort).
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "gspl_device.h"
 #include "gspl_host.h"
 
@@ -64,7 +67,55 @@ static FrameEvents& frame_events() {
     return ev;
 }
 
+// Optional timing of the two compositing launches INSIDE the fused calls (bench.py's roofline: the launches cannot be bracketed
+// from Python any more).  Events are recorded on the launch stream; durations are read after a synchronisation.
+struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static ProfSlot g_prof[2];      // 0: composite forward, 1: composite backward
+struct ProfScope {
+    int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int w, hipStream_t st) : which(w), s(st) {
+        if (!g_prof_on) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof[which].ev.emplace_back(a, b);
+    }
+};
+
 }  // namespace gspl
+
+extern "C" int gspl_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(gspl::g_prof_mu);
+    gspl::g_prof_on = on != 0;
+    for (auto& slot : gspl::g_prof) {
+        for (auto& e : slot.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        slot.ev.clear();
+    }
+    return GSPL_OK;
+}
+
+// which: 0 = composite forward, 1 = composite backward launches of the fused calls since gspl_profile_enable(1).
+// Synchronises with the recorded events; returns the number of launches and their total duration.
+extern "C" int gspl_profile_read(int which, int* count, float* total_ms) {
+    using namespace gspl;
+    if (which < 0 || which > 1 || !count || !total_ms) return fail_arg("profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    float tot = 0.f;
+    for (auto& e : g_prof[which].ev) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.second) != hipSuccess || hipEventElapsedTime(&ms, e.first, e.second) != hipSuccess) return check_hip(hipGetLastError(), "profile_read");
+        tot += ms;
+    }
+    *count = (int)g_prof[which].ev.size();
+    *total_ms = tot;
+    return GSPL_OK;
+}
 
 extern "C" size_t gspl_rasterize_inria_geometry_bytes(int N) { return gspl::geom_layout((size_t)(N > 0 ? N : 1)).total; }
 extern "C" size_t gspl_rasterize_inria_image_bytes(int width, int height) {
@@ -180,6 +231,7 @@ extern "C" int gspl_rasterize_inria_fwd(
         if (rc != GSPL_OK) return rc;
     }
     st->n_isects = n_isects;
+    ProfScope prof(0, s);
     return gspl_composite_fwd(N, n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height, tile,
                               tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
 }
@@ -208,6 +260,7 @@ extern "C" int gspl_rasterize_inria_bwd(
     }
     int rc = GSPL_OK;
     if (st->n_isects > 0) {
+        ProfScope prof(1, s);
         rc = gspl_composite_bwd_packed(N, st->n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width,
                                        height, tile, tile_w, tile_h, st->offsets, st->flatten_ids, st->final_Ts, st->last_ids, v_out_color, nullptr,
                                        packed, 9, 0, hit_flags, s);

@@ -390,6 +390,13 @@ int gspl_rasterize_inria_bwd(int degree, int n_coeffs,
                              float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_colors_precomp, float* v_opacities,
                              float* v_scales, float* v_rotations, float* v_cov3D, void* stream);
 
+/* Timing of the compositing launches inside the fused calls (bench.py: the roofline of the graded kernel needs its launch
+ * duration from HIP events on the launch stream, and the launches are no longer visible from the host language).
+ * gspl_profile_enable(1) starts recording (and drops what was recorded), gspl_profile_read synchronises and returns the count
+ * and the summed duration of the forward (which = 0) or backward (1) compositing launches since then; enable(0) stops. */
+int gspl_profile_enable(int on);
+int gspl_profile_read(int which, int* count, float* total_ms);
+
 /* ------------------------------------------------------------------------------------------
  * 7. Mean squared distance to the 3 nearest neighbours ("next" row SURVEY.md §8f rank 1).
  *    Replaces `simple_knn._C.distCUDA2` at its one call site, the initial scales of
