@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -70,7 +70,6 @@ _SIGNATURES = {
     "gspl_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, _P, _P]),
     "gspl_bin_workspace_bytes": (c_size_t, [c_int, c_int64]),
-    "gspl_sort_force_ticket": (c_int, [c_int]),
     "gspl_loss_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gspl_loss_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_loss_photometric_fwd": (c_int, [c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -127,7 +127,7 @@ static int plan_workspace(int N, int64_t n_isects, int key_bits_total, IsectWork
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     w.counts_off = take(4 * n);
-    w.scan_off = take(scan_state_bytes(n) + 64);          // states + one counter word
+    w.scan_off = take(scan_workspace_bytes(n));
     w.total_count = off;
     w.keys_off = take(8 * ni);
     w.vals_off = take(4 * ni);
@@ -233,8 +233,7 @@ static_assert(sizeof(SpanRecord) == 32, "span record is one 32-byte line");
 static constexpr int EMIT_ROWS = 16;
 static constexpr uint16_t SPAN_BIG = 0xFFFFu;
 
-// HEADER: the kernel also prepares the depth sort (gspl_sort_device.h): digit histograms of the keys it writes, look-back
-// states cleared.
+// HEADER: the kernel also prepares the depth sort (gspl_sort_device.h): digit histograms of the keys it writes.
 template <int MODE, bool HEADER>
 __global__ __launch_bounds__(256) void bin_keys_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
@@ -300,7 +299,6 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
         radix_hist_add<uint32_t>(s_hist, hdr, key, valid);
         __syncthreads();
         radix_hist_flush(s_hist, hdr);
-        radix_states_clear(hdr, (size_t)g, (size_t)gridDim.x * blockDim.x);
     }
 }
 
@@ -325,10 +323,9 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, const int32_t* __restrict__ big_list,
     int tile_size, int tile_w, int tile_h, uint64_t* __restrict__ tile_keys, int64_t capacity, RadixHeader hdr) {
-    // the kernel also prepares the tile sort (gspl_sort_device.h): digit histograms of the tile ids it writes, rows cleared
+    // the kernel also prepares the tile sort (gspl_sort_device.h): digit histograms of the tile ids it writes
     __shared__ uint32_t s_hist[RADIX_MAX_PASSES * RADIX_BINS];
     radix_hist_clear(s_hist);
-    radix_states_clear(hdr, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
     __syncthreads();
     // consecutive output slots carry different tile ids: one LDS atomic per record and pass (no wave-uniform shortcut)
     auto count_tile = [&](uint32_t tile_id) {
@@ -487,8 +484,8 @@ static int plan_bin(int N, int64_t n_isects, int n_tiles, BinWorkspace& w) {
     w.keys_off = take(4 * n); w.ids_off = take(4 * n); w.keys2_off = take(4 * n);
     w.counts_off = take(4 * n);
     if (!radix_plan(n, 0, 32, 8, RADIX_TILE_U32, w.depth)) return fail_arg("bin: depth sort plan");
-    w.scan_states_off = w.depth.total_bytes;          // the scan's state words follow the sort's rows (one clear covers both)
-    w.sort1_bytes = w.depth.total_bytes + scan_state_bytes(n);
+    w.scan_states_off = w.depth.total_bytes;          // the scan's block sums follow the sort's tables
+    w.sort1_bytes = w.depth.total_bytes + scan_workspace_bytes(n);
     w.sort1_off = take(w.sort1_bytes);
     w.total_count = off;
     w.tkeys_off = take(8 * ni); w.tkeys2_off = take(8 * ni);
@@ -539,7 +536,6 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     const RadixPlan& dp = w.depth;
     RadixHeader hdr;
     radix_header_args(dp, ws + w.sort1_off, hdr);
-    hdr.state_vec4 = (uint32_t)((dp.total_bytes - dp.states_off + scan_state_bytes((size_t)N)) / 16);      // + the scan's words
     hipError_t e = hipMemsetAsync(ws + w.sort1_off + dp.hist_off, 0, dp.header_bytes, s);
     if (e != hipSuccess) return check_hip(e, "bin_count: histogram clear");
     if (mode == GSPL_MODE_GSPLAT)
@@ -552,18 +548,9 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     uint32_t* const vbuf[2] = {(uint32_t*)order, ids};
     rc = radix_sort_u32(dp, ws + w.sort1_off, kbuf, vbuf, true, s);
     if (rc != GSPL_OK) return rc;
-    // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many, and copies the sorts'
-    // error word to cum_tiles[N + 1] — one 24-byte read-back gives the host the list length, the big count and the health
-    uint32_t* ctr = (uint32_t*)(ws + w.sort1_off + dp.ticket_off);
-    return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off,
-                                ctr + RADIX_MAX_PASSES, big_list, ctr + RADIX_ERR_WORD, s);
-}
-
-// Process-wide switch of every sort and scan to tiles drawn from a counter (what the host does after cum_tiles[N + 1] reported a
-// look-back time-out; also GSPL_SORT_FORCE_TICKET=1).
-extern "C" int gspl_sort_force_ticket(int on) {
-    gspl::radix_force_ticket(on != 0);
-    return GSPL_OK;
+    // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte read-back
+    // gives the host both numbers
+    return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s);
 }
 
 // Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has
@@ -589,11 +576,10 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
-    // the tile sort's header for a list of `capacity` records: the real list is not longer (else the emission is repeated), so its
-    // look-back rows lie inside the cleared range; the histograms count exactly the records written
+    // the tile sort's header: the histograms count exactly the records written (the real list is not longer than `capacity`,
+    // else the emission is repeated)
     RadixHeader hdr;
     radix_header_args(w.tile, ws + w.sort2_off, hdr);
-    hdr.state_vec4 = (uint32_t)((w.tile.total_bytes - w.tile.states_off) / 16);
     hipError_t e = hipMemsetAsync(ws + w.sort2_off + w.tile.hist_off, 0, w.tile.header_bytes, s);
     if (e != hipSuccess) return check_hip(e, "bin_emit: histogram clear");
     if (mode == GSPL_MODE_GSPLAT)
@@ -668,17 +654,14 @@ extern "C" int gspl_isect_count(int N, int mode, const float* means2d, const int
     int32_t* counts = (int32_t*)(ws + w.counts_off);
     const int grid = (N + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ws + w.scan_off, 0, scan_state_bytes((size_t)N) + 64, s);
-    if (e != hipSuccess) return check_hip(e, "isect_count: state clear");
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL(isect_count_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, tile_size, tile_w, tile_h, tiles_per_gauss, counts);
     else
         hipLaunchKernelGGL(isect_count_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, tile_size, tile_w, tile_h, tiles_per_gauss, counts);
     rc = check_launch("isect_count");
     if (rc != GSPL_OK) return rc;
-    // inclusive scan of the counts in memory order: the chained-look-back scan of sort.hip with the identity gather
-    uint32_t* ctr = (uint32_t*)(ws + w.scan_off + scan_state_bytes((size_t)N));
-    return scan_gathered_counts(nullptr, counts, cum_tiles, (size_t)N, ws + w.scan_off, ctr, nullptr, ctr + 1, s);
+    // inclusive scan of the counts in memory order: the scan of sort.hip with the identity gather
+    return scan_gathered_counts(nullptr, counts, cum_tiles, (size_t)N, ws + w.scan_off, nullptr, s);
 }
 
 extern "C" int gspl_isect_emit_sort(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,

@@ -31,7 +31,7 @@ static GeomLayout geom_layout(size_t n) {
     auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
     g.means2d = take(8 * n); g.depths = take(4 * n); g.conics = take(12 * n); g.colors = take(12 * n);
     g.clamped = take(3 * n); g.cov3d = take(24 * n);
-    g.order = take(4 * n); g.cum = take(8 * (n + 2)); g.big_list = take(4 * n); g.spans = take((size_t)GSPL_BIN_SPAN_BYTES * n);
+    g.order = take(4 * n); g.cum = take(8 * (n + 1)); g.big_list = take(4 * n); g.spans = take((size_t)GSPL_BIN_SPAN_BYTES * n);
     g.radii = 0;       // radii are an OUTPUT tensor of the call, not part of the block
     g.total = off;
     return g;
@@ -46,7 +46,7 @@ static ImageLayout image_layout(size_t pixels, size_t tiles) {
     return m;
 }
 
-// one pinned 32-byte block per host thread for the read-back (cum[N-1], n_big, error word)
+// one pinned 32-byte block per host thread for the read-back (cum[N-1] = the list length, cum[N] = n_big)
 static int64_t* pinned_words() {
     static thread_local int64_t* p = nullptr;
     if (!p) {
@@ -173,59 +173,48 @@ extern "C" int gspl_rasterize_inria_fwd(
                                        campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
                                        st->colors, st->clamped, st->cov3d, GSPL_INRIA_COLOURS, cs);
         if (rc == GSPL_OK && ev_col) (void)hipEventRecord(ev_col, cs);
-        auto cleanup = [&]() {};
-        if (rc != GSPL_OK) { cleanup(); return rc; }
+        if (rc != GSPL_OK) return rc;
         const size_t ws1_bytes = gspl_bin_workspace_bytes(N, 0);
         char* ws1 = (char*)alloc(alloc_ctx, GSPL_BUF_BINNING, ws1_bytes);
-        if (!ws1) { cleanup(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+        if (!ws1) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
         int64_t* host = pinned_words();
-        if (!host) { cleanup(); return fail_arg("rasterize_inria_fwd: no pinned host word"); }
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!host) return fail_arg("rasterize_inria_fwd: no pinned host word");
+        {
             rc = gspl_bin_count(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
                                 spans, ws1, ws1_bytes, s);
-            if (rc != GSPL_OK) { cleanup(); return rc; }
+            if (rc != GSPL_OK) return rc;
             hipEvent_t ev_cnt = fe.cnt;
-            (void)hipMemcpyAsync(host, cum + (N - 1), 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(host, cum + (N - 1), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s);
             (void)hipEventRecord(ev_cnt, s);
             // speculative emission with the caller's guess of the list length, while the host waits for the real one
             int64_t capacity = 0;
             char* ws2 = nullptr;
             size_t ws2_bytes = 0;
-            if (capacity_hint > 0 && attempt == 0) {
+            if (capacity_hint > 0) {
                 capacity = capacity_hint;
                 ws2_bytes = gspl_bin_workspace_bytes(N, capacity);
                 ws2 = (char*)alloc(alloc_ctx, GSPL_BUF_LISTS_WORK, ws2_bytes);
                 if (ws2) rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
                                             capacity, ws2, ws2_bytes, s);
-                if (!ws2 || rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); cleanup(); return ws2 ? rc : fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+                if (!ws2 || rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return ws2 ? rc : fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
             }
             (void)hipEventSynchronize(ev_cnt);
             n_isects = host[0];
-            if (host[2] != 0) {      // a look-back of the counter-free depth sort timed out under contention: counter mode, once more
-                gspl_sort_force_ticket(1);
-                capacity_hint = 0;
-                if (attempt == 0) continue;
-                cleanup();
-                set_error("rasterize_inria_fwd", "the depth sort failed in the counter mode as well");
-                return GSPL_ERR_LAUNCH;
-            }
             if (n_isects > 0 && (!ws2 || capacity < n_isects)) {
                 capacity = n_isects;
                 ws2_bytes = gspl_bin_workspace_bytes(N, capacity);
                 ws2 = (char*)alloc(alloc_ctx, GSPL_BUF_LISTS_WORK, ws2_bytes);
-                if (!ws2) { cleanup(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+                if (!ws2) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
                 rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
                                    capacity, ws2, ws2_bytes, s);
-                if (rc != GSPL_OK) { cleanup(); return rc; }
+                if (rc != GSPL_OK) return rc;
             }
             st->flatten_ids = n_isects > 0 ? (int32_t*)alloc(alloc_ctx, GSPL_BUF_LISTS, 4 * (size_t)n_isects) : nullptr;
-            if (n_isects > 0 && !st->flatten_ids) { cleanup(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+            if (n_isects > 0 && !st->flatten_ids) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
             rc = gspl_bin_sort(N, tile_w, tile_h, n_isects, capacity > n_isects ? capacity : n_isects, st->flatten_ids, st->offsets, ws2, ws2_bytes, s);
-            if (rc != GSPL_OK) { cleanup(); return rc; }
-            break;
+            if (rc != GSPL_OK) return rc;
         }
         if (ev_col) (void)hipStreamWaitEvent(s, ev_col, 0);      // colours are ready before compositing reads them
-        cleanup();
     } else {
         rc = gspl_bin_sort(0, tile_w, tile_h, 0, 0, nullptr, st->offsets, nullptr, 0, s);
         if (rc != GSPL_OK) return rc;

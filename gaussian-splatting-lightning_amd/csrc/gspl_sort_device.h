@@ -1,9 +1,9 @@
-// gspl_sort_device.h — device-side half of the radix sort "header" (digit histograms of every pass + cleared look-back
-// states), for kernels that PRODUCE the keys: they touch every key anyway, so the sort needs no header kernel of its own.
+// gspl_sort_device.h — device-side half of the radix sort "header" (the global digit histograms of every pass), for kernels
+// that PRODUCE the keys: they touch every key anyway, so the sort needs no header kernel of its own.
 //   __shared__ uint32_t h[RADIX_MAX_PASSES * RADIX_BINS];
 //   radix_hist_clear(h);  __syncthreads();
 //   ... radix_hist_add(h, hdr, key, valid) for every key (called by whole waves) ...
-//   __syncthreads();  radix_hist_flush(h, hdr);  radix_states_clear(hdr, global thread id, global thread count);
+//   __syncthreads();  radix_hist_flush(h, hdr);
 // The global histogram has RADIX_HIST_COPIES copies (selected by workgroup index, summed by the pass kernels): thousands
 // of workgroups flushing onto 1024 addresses would queue ~16 ns per atomic and address.
 #pragma once
@@ -14,8 +14,6 @@ namespace gspl {
 
 struct RadixHeader {
     uint32_t* hist;            // [RADIX_HIST_COPIES][RADIX_MAX_PASSES][RADIX_BINS], zero on entry
-    uint4* states;             // look-back rows of every pass
-    uint32_t state_vec4;       // their size in 16-byte words
     int passes;
     int shift[RADIX_MAX_PASSES];
     uint32_t mask[RADIX_MAX_PASSES];
@@ -53,10 +51,6 @@ __device__ __forceinline__ void radix_hist_flush(const uint32_t* h, const RadixH
         const uint32_t c = h[j];
         if (c) atomicAdd(dst + j, c);
     }
-}
-
-__device__ __forceinline__ void radix_states_clear(const RadixHeader& hdr, size_t gid, size_t gcount) {
-    for (size_t j = gid; j < hdr.state_vec4; j += gcount) hdr.states[j] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 }  // namespace gspl

@@ -704,7 +704,7 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     p.capacity = p.ws2_bytes = 0
     if N > 0:
         p.order = torch.empty((N,), dtype=torch.int32, device=dev)
-        p.cum = torch.empty((N + 2,), dtype=torch.int64, device=dev)      # scan [N] + the number of big splats + the sorts' error word
+        p.cum = torch.empty((N + 1,), dtype=torch.int64, device=dev)      # scan [N] + the number of big splats
         p.big_list = torch.empty((N,), dtype=torch.int32, device=dev)     # depth-order indices of the splats taller than 16 tile rows
         p.spans = torch.empty((N, L.GSPL_BIN_SPAN_BYTES // 4), dtype=torch.int32, device=dev)
         ws_bytes = lib.gspl_bin_workspace_bytes(N, 0)
@@ -719,10 +719,9 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
                    L.stream())
         p.count = count
         count()
-        # the one host read-back of the pipeline: the list length (sizes the sort buffers), the number of big splats and the
-        # error word of the depth sort / scan (a look-back that timed out: see bin_gaussians_end)
-        p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((3,), dtype=torch.int64).pin_memory()
-        p.host_count.copy_(p.cum[N - 1:N + 2], non_blocking=True)
+        # the one host read-back of the pipeline: the list length (sizes the sort buffers) and the number of big splats
+        p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((2,), dtype=torch.int64).pin_memory()
+        p.host_count.copy_(p.cum[N - 1:N + 1], non_blocking=True)
         p.event = torch.cuda.Event()
         p.event.record()
         # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of
@@ -756,20 +755,7 @@ def _bin_gaussians_end(p: _PendingBins):
     n_isects = 0
     if p.N > 0:
         p.event.synchronize()
-        n_isects, err = int(p.host_count[0]), int(p.host_count[2])
-        if err != 0:
-            # A look-back of the counter-free sort / scan timed out (its grid was neither co-resident nor dispatched in index
-            # order: another process or stream held the device).  Nothing hung or faulted; the order it produced is garbage.
-            # From now on every sort of this process draws its tiles from a counter (progress under any schedule); redo.
-            import warnings
-            warnings.warn("gspl_amd: a radix-sort look-back timed out under device contention; switching to the counter mode")
-            L.call("gspl_sort_force_ticket", 1)
-            p.count()
-            triple = p.cum[p.N - 1:p.N + 2].cpu()
-            n_isects, err = int(triple[0]), int(triple[2])
-            if err != 0:
-                raise RuntimeError("gspl_bin_count: the depth sort failed in the counter mode as well")
-            p.ws2 = None                              # a speculative emission used the garbage order
+        n_isects = int(p.host_count[0])
         _PINNED_WORDS.append(p.host_count)
         _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
     N, dev = p.N, p.dev

@@ -197,14 +197,9 @@ int gspl_bin_count(int N, int mode,
                    const float* means2d, const int32_t* radii, const float* depths,
                    const float* conics /*nullable*/, const float* opacities /*nullable*/,
                    int tile_size, int tile_w, int tile_h,
-                   int32_t* order, int64_t* cum_tiles /* [N + 2]: inclusive scan of the tile counts in depth order, then
+                   int32_t* order, int64_t* cum_tiles /* [N + 1]: inclusive scan of the tile counts in depth order, then
                                                          n_big = the number of splats spanning more than 16 tile rows
-                                                         (radius > ~128 px: close-ups, sky blobs) or with a very wide row,
-                                                         then the ERROR WORD of the depth sort and the scan: non-zero when a
-                                                         look-back of their counter-free mode timed out (the device was
-                                                         shared and did not start the grid in index order) — `order` and the
-                                                         scan are then garbage, nothing hung or faulted; call
-                                                         gspl_sort_force_ticket(1) and repeat */,
+                                                         (radius > ~128 px: close-ups, sky blobs) or with a very wide row */,
                    int32_t* big_list /* [N]: the depth-order indices of those splats (n_big entries, ranked by the scan);
                                         the emission deals them out to its workgroups instead of leaving up to 64
                                         consecutive screen-filling splats to one wave */,
@@ -228,10 +223,9 @@ int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                   void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream);
-/* Sorts and scans of this library are in-tree one-sweep kernels (csrc/sort.hip).  Grids that fit an idle device take one tile per
- * workgroup without a counter; everything else (and everything after this call with on = 1, or with GSPL_SORT_FORCE_TICKET set)
- * draws its tiles from a counter, which makes progress under any dispatch order and any contention. */
-int gspl_sort_force_ticket(int on);
+/* Sorts and scans of this library are in-tree kernels (csrc/sort.hip): every radix pass is count -> digit-row scan -> scatter
+ * over contiguous tile ranges, the scans are block sums -> scan of the sums -> per-block scan.  No workgroup waits for another,
+ * so they make progress under any dispatch order and contention, and their output is bit-reproducible. */
 
 /* ------------------------------------------------------------------------------------------
  * 4. Tile compositing, forward.

@@ -88,6 +88,7 @@ def test_selective_adam_rejects_bad_inputs():
         SelectiveAdam([cpu]).step(torch.ones(8, dtype=torch.bool))
 
 
+@pytest.mark.gpu
 def test_fused_adam_resumes_a_torch_adam_state_and_accepts_its_kwargs():
     """A reference checkpoint's optimizer state (torch.optim.Adam: `step` is a tensor) loads into HipFusedAdam's optimizer and
     the next steps match torch.optim.Adam's; Adam's keyword arguments are accepted at their defaults, refused otherwise."""
