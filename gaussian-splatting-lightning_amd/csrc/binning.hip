@@ -233,16 +233,16 @@ static_assert(sizeof(SpanRecord) == 32, "span record is one 32-byte line");
 static constexpr int EMIT_ROWS = 16;
 static constexpr uint16_t SPAN_BIG = 0xFFFFu;
 
-// HEADER: the kernel also prepares the depth sort (gspl_sort_device.h): digit histograms of the keys it writes.
+// HEADER: the kernel also prepares the depth sort (gspl_sort_device.h): the first pass's digit counts of the keys it writes.
 template <int MODE, bool HEADER>
 __global__ __launch_bounds__(256) void bin_keys_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     int tile_size, int tile_w, int tile_h, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, int32_t* __restrict__ counts,
-    SpanRecord* __restrict__ spans, RadixHeader hdr) {
-    __shared__ uint32_t s_hist[HEADER ? RADIX_MAX_PASSES * RADIX_BINS : 1];
+    SpanRecord* __restrict__ spans, RadixProducer hdr) {
+    __shared__ uint32_t s_hist[HEADER ? RADIX_BINS : 1];
     if (HEADER) {
-        radix_hist_clear(s_hist);
+        radix_producer_clear(s_hist);
         __syncthreads();
     }
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256) void bin_keys_kernel(
         }
     }
     if (HEADER) {
-        radix_hist_add<uint32_t>(s_hist, hdr, key, valid);
+        radix_producer_add<uint32_t>(s_hist, hdr, key, valid);
         __syncthreads();
-        radix_hist_flush(s_hist, hdr);
+        radix_producer_flush(s_hist, hdr, (size_t)blockIdx.x * blockDim.x);
     }
 }
 
@@ -322,17 +322,40 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii, const uint32_t* __restrict__ order,
     const float* __restrict__ conics, const float* __restrict__ opacities,
     const int64_t* __restrict__ cum_sorted, const SpanRecord* __restrict__ spans, const int32_t* __restrict__ big_list,
-    int tile_size, int tile_w, int tile_h, uint64_t* __restrict__ tile_keys, int64_t capacity, RadixHeader hdr) {
-    // the kernel also prepares the tile sort (gspl_sort_device.h): digit histograms of the tile ids it writes
-    __shared__ uint32_t s_hist[RADIX_MAX_PASSES * RADIX_BINS];
-    radix_hist_clear(s_hist);
-    __syncthreads();
-    // consecutive output slots carry different tile ids: one LDS atomic per record and pass (no wave-uniform shortcut)
-    auto count_tile = [&](uint32_t tile_id) {
-#pragma unroll
-        for (int p = 0; p < RADIX_MAX_PASSES; ++p)
-            if (p < hdr.passes) atomicAdd(&s_hist[p * RADIX_BINS + ((tile_id >> (hdr.shift[p] - 32)) & hdr.mask[p])], 1u);
+    int tile_size, int tile_w, int tile_h, uint64_t* __restrict__ tile_keys, int64_t capacity, RadixProducer hdr) {
+    // The kernel also prepares the tile sort (gspl_sort_device.h): the first pass's digit counts per sort workgroup.  A sort
+    // workgroup owns hdr.span_items consecutive records; the records a workgroup emits in one phase start in one span (`home`) and
+    // almost always end in it or the next: those are counted in LDS (two rows), the stragglers straight in memory.
+    __shared__ uint32_t s_hist[2 * RADIX_BINS];
+    auto hist_clear = [&]() { for (int j = threadIdx.x; j < 2 * RADIX_BINS; j += 256) s_hist[j] = 0u; };
+    auto hist_flush = [&](uint32_t home) {
+        for (int j = threadIdx.x; j < 2 * RADIX_BINS; j += 256) {
+            const uint32_t c = s_hist[j];
+            if (c) {
+                const size_t g = (size_t)home + (uint32_t)(j >> 8);
+                atomicAdd(hdr.counts0 + g * RADIX_BINS + (j & 255), c);
+                atomicAdd(hdr.groups0 + (g / RADIX_GROUP) * RADIX_BINS + (j & 255), c);
+            }
+        }
     };
+    // consecutive output slots carry different tile ids: one LDS atomic per record (no wave-uniform shortcut)
+    auto count_tile = [&](uint32_t tile_id, uint32_t out, uint32_t home_first) {
+        const uint32_t d = (tile_id >> (hdr.shift - 32)) & hdr.mask;
+        const uint32_t rel = out - home_first;
+        if (rel < 2u * hdr.span_items) {
+            atomicAdd(&s_hist[(rel >= hdr.span_items ? RADIX_BINS : 0) + d], 1u);
+        } else {
+            const size_t g = out / hdr.span_items;
+            atomicAdd(hdr.counts0 + g * RADIX_BINS + d, 1u);
+            atomicAdd(hdr.groups0 + (g / RADIX_GROUP) * RADIX_BINS + d, 1u);
+        }
+    };
+    hist_clear();
+    __syncthreads();
+    // the workgroup's first output slot (phase A); slots at or past `capacity` are never written
+    const int64_t wg_base = blockIdx.x == 0 ? 0 : cum_sorted[(size_t)blockIdx.x * 256 - 1];
+    const uint32_t home_a = (uint32_t)((wg_base < capacity ? wg_base : 0) / hdr.span_items);
+    const uint32_t home_a_first = home_a * hdr.span_items;
     __shared__ int s_start[4][65];
     __shared__ int s_out[4][64];
     __shared__ uint32_t s_gid[4][64];
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
             if (out < capacity) {    // a speculative launch may have guessed the list length too low (the host redoes it)
                 const uint32_t tile_id = (uint32_t)(ty * tile_w + tx);
                 tile_keys[out] = ((uint64_t)tile_id << 32) | s_gid[w][o];
-                count_tile(tile_id);
+                count_tile(tile_id, (uint32_t)out, home_a_first);
             }
         }
     }
@@ -418,6 +441,8 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
     // screen-filling splats one after the other.)  `big_list` / cum_sorted[N]: their depth-order indices and number, ranked
     // by the scan of the counts.  All 256 threads work on one splat: rows in chunks of 256 (one per thread: exact column
     // span, scan), then every output slot of the chunk by one thread (row by binary search in the chunk's prefix).
+    __syncthreads();
+    hist_flush(home_a);
     const int n_big = (int)cum_sorted[N];
     __shared__ int s_bpre[257];
     __shared__ int s_bc0[256];
@@ -426,6 +451,9 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
         const int bi = big_list[b];
         const int g = (int)order[bi];
         int64_t out = (bi == 0) ? 0 : cum_sorted[bi - 1];
+        const uint32_t home_b = (uint32_t)((out < capacity ? out : 0) / hdr.span_items), home_b_first = home_b * hdr.span_items;
+        __syncthreads();                               // the flush before is done with the table
+        hist_clear();                                  // (the chunk loop below synchronises before its first record)
         int minx, miny, maxx, maxy;
         const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
         tile_rect<MODE>(mx, my, radii[g], tile_size, tile_w, tile_h, minx, miny, maxx, maxy);
@@ -456,14 +484,14 @@ __global__ __launch_bounds__(256) void bin_emit_lb_kernel(
                 if (out + k < capacity) {
                     const uint32_t tile_id = (uint32_t)((rbase + r) * tile_w + tx);
                     tile_keys[out + k] = ((uint64_t)tile_id << 32) | (uint32_t)g;
-                    count_tile(tile_id);
+                    count_tile(tile_id, (uint32_t)(out + k), home_b_first);
                 }
             }
             out += total;
         }
+        __syncthreads();
+        hist_flush(home_b);
     }
-    __syncthreads();
-    radix_hist_flush(s_hist, hdr);
 }
 
 struct BinWorkspace {
@@ -473,9 +501,9 @@ struct BinWorkspace {
     RadixPlan depth, tile;
 };
 
-// Workspace of the list-only binning.  Count half: depth keys / ids (x2 for the ping-pong), counts, the depth sort's header and
-// look-back rows followed by the scan's state words.  Emit/sort half (sized by the list length or a guess of it): the 8-byte
-// records (x2) and the tile sort's header and rows.
+// Workspace of the list-only binning.  Count half: depth keys / ids (x2 for the ping-pong), counts, the depth sort's tables
+// followed by the scan's block sums.  Emit/sort half (sized by the list length or a guess of it): the 8-byte records (x2) and
+// the tile sort's tables.
 static int plan_bin(int N, int64_t n_isects, int n_tiles, BinWorkspace& w) {
     const size_t n = (size_t)(N > 0 ? N : 1), ni = (size_t)(n_isects > 0 ? n_isects : 1);
     if (n > RADIX_MAX_ITEMS || ni > RADIX_MAX_ITEMS) { set_error("bin", "more than 2^30-1 splats or intersections"); return GSPL_ERR_UNSUPPORTED; }
@@ -531,13 +559,13 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     int32_t* counts = (int32_t*)(ws + w.counts_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
-    // Depth sort on the own one-sweep sort, prepared by the key pass itself (digit histograms, cleared look-back rows).  Four
-    // 8-bit passes: the sorted sequence ends where it started, so the key pass writes the ids straight into `order`.
+    // Depth sort (sort.hip), prepared by the key pass itself (the first pass's counts).  Four 8-bit passes: the sorted sequence
+    // ends where it started, so the key pass writes the ids straight into `order`.
     const RadixPlan& dp = w.depth;
-    RadixHeader hdr;
-    radix_header_args(dp, ws + w.sort1_off, hdr);
-    hipError_t e = hipMemsetAsync(ws + w.sort1_off + dp.hist_off, 0, dp.header_bytes, s);
-    if (e != hipSuccess) return check_hip(e, "bin_count: histogram clear");
+    RadixProducer hdr;
+    radix_producer_args(dp, ws + w.sort1_off, hdr);
+    hipError_t e = hipMemsetAsync(ws + w.sort1_off, 0, dp.header_bytes, s);
+    if (e != hipSuccess) return check_hip(e, "bin_count: sort tables clear");
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
     else
@@ -546,17 +574,18 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     if (rc != GSPL_OK) return rc;
     uint32_t* const kbuf[2] = {keys, keys2};
     uint32_t* const vbuf[2] = {(uint32_t*)order, ids};
-    rc = radix_sort_u32(dp, ws + w.sort1_off, kbuf, vbuf, true, s);
+    // the last pass leaves the tile counts in depth order where the sorted keys would go
+    rc = radix_sort_u32(dp, ws + w.sort1_off, kbuf, vbuf, true, s, (const uint32_t*)counts);
     if (rc != GSPL_OK) return rc;
     // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte read-back
     // gives the host both numbers
-    return scan_gathered_counts((const uint32_t*)order, counts, cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s);
+    return scan_gathered_counts(nullptr, (const int32_t*)kbuf[dp.passes & 1], cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s);
 }
 
 // Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has
 // room for: it may be a GUESS of the list length, launched before the host knows the real one — records past it are
 // dropped, and the caller repeats the call with the real length when the guess was too low.
-// The kernel also prepares the tile sort: digit histograms of the records it writes, look-back rows cleared.
+// The kernel also prepares the tile sort: the first pass's digit counts of the records it writes.
 extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                              const float* conics, const float* opacities,
                              const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
@@ -576,12 +605,12 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     uint64_t* tkeys = (uint64_t*)(ws + w.tkeys_off);
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
-    // the tile sort's header: the histograms count exactly the records written (the real list is not longer than `capacity`,
-    // else the emission is repeated)
-    RadixHeader hdr;
-    radix_header_args(w.tile, ws + w.sort2_off, hdr);
-    hipError_t e = hipMemsetAsync(ws + w.sort2_off + w.tile.hist_off, 0, w.tile.header_bytes, s);
-    if (e != hipSuccess) return check_hip(e, "bin_emit: histogram clear");
+    // the tile sort's first-pass counts: exactly the records written, by the spans of the plan for `capacity` records (the real
+    // list is not longer, else the emission is repeated; gspl_bin_sort keeps the spans)
+    RadixProducer hdr;
+    radix_producer_args(w.tile, ws + w.sort2_off, hdr);
+    hipError_t e = hipMemsetAsync(ws + w.sort2_off, 0, w.tile.header_bytes, s);
+    if (e != hipSuccess) return check_hip(e, "bin_emit: sort tables clear");
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity, hdr);
     else
@@ -590,7 +619,7 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
 }
 
 // Sort half: the first n_isects (<= capacity) records of the workspace gspl_bin_emit filled -> flatten_ids, offsets.
-// Two (for more than 65536 tiles: three) one-sweep passes on the tile id; the last one writes the splat ids alone and counts
+// Two (for more than 65536 tiles: three) passes on the tile id; the last one writes the splat ids alone and counts
 // the records per tile, a one-workgroup scan turns the counts into `offsets`.
 extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
                              int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
@@ -611,7 +640,7 @@ extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, in
     if (workspace_bytes < w.total) return fail_ws("bin_sort");
     char* ws = (char*)workspace;
     uint64_t* const tk[2] = {(uint64_t*)(ws + w.tkeys_off), (uint64_t*)(ws + w.tkeys2_off)};
-    // same bit split as the emission's histograms, tile count of the REAL list length
+    // same bit split and spans as the emission's counts, tile count of the REAL list length
     RadixPlan tp = w.tile;
     radix_replan_items(tp, (size_t)n_isects);
     rc = radix_sort_tiles(tp, ws + w.sort2_off, tk, true, (uint32_t*)flatten_ids, (uint32_t*)offsets, (uint32_t)n_tiles, s);

@@ -3,11 +3,11 @@
 // The two sorts of a frame (the splats' depth keys with their ids; the (tile | splat) records, ~7 records per splat) are small
 // next to what a general-purpose device sort is tuned for, and a library sort spends as long in per-pass bookkeeping launches as
 // in moving keys.  This sort:
-//   * takes its digit histograms from the kernel that PRODUCES the keys (`prepared`; gspl_sort_device.h) — or from one header
-//     kernel for keys that come from elsewhere;
-//   * runs every pass as count -> rowscan -> scatter over contiguous tile ranges per workgroup (sort.hip): no communication
-//     between running workgroups, hence no forward-progress assumptions, no polling and bit-reproducible output;
-//   * can finish the tile sort with a pass that writes the splat ids alone and counts the records per tile id.
+//   * runs every pass as count -> scatter over contiguous tile ranges per workgroup (sort.hip): no workgroup waits for another,
+//     hence no forward-progress assumptions, no polling and bit-reproducible output;
+//   * can take the first pass's counts from the kernel that PRODUCES the keys (`prepared`; gspl_sort_device.h);
+//   * can finish the depth sort with a pass that writes gather[value] in place of the keys nobody reads, and the tile sort with
+//     a pass that writes the splat ids alone and counts the records per tile id.
 // Up to 2^30 - 1 items (callers report GSPL_ERR_UNSUPPORTED above).
 #pragma once
 #include <cstddef>
@@ -28,8 +28,8 @@ static constexpr int RADIX_BINS = 256;                 // row width of the histo
 #endif
 static constexpr int RADIX_TILE_U32 = GSPL_RS_TILE_U32;   // items per tile of the (u32 key, u32 value) sort: 512 threads x 4
 static constexpr int RADIX_TILE_U64 = GSPL_RS_TILE_U64;   // items per tile of the u64 sorts: 512 threads x 8
-static constexpr int RADIX_HIST_COPIES = 8;             // copies of the global histogram (gspl_sort_device.h)
-static constexpr int RADIX_MAX_WG = 2048;               // workgroups per pass at most (one wave scans a digit row: 64 x 32)
+static constexpr int RADIX_MAX_WG = 2048;               // workgroups per pass at most
+static constexpr int RADIX_GROUP = 32;                  // workgroups per group row (two-level prefix over the workgroups)
 static constexpr size_t RADIX_MAX_ITEMS = (1u << 30) - 1u;
 
 struct RadixPlan {
@@ -41,23 +41,28 @@ struct RadixPlan {
     uint32_t ntiles;
     uint32_t nwg;                                      // workgroups of a pass
     uint32_t tiles_per_wg;                             // consecutive tiles each of them owns
-    // workspace layout (byte offsets): [hist: 8 copies x 4 passes x 256 u32][counts: 256 x RADIX_MAX_WG u32]
-    size_t hist_off, counts_off, header_bytes, total_bytes;
+    uint32_t wg_cap;                                   // workgroups the tables below were sized for (replanning keeps them)
+    // workspace layout (byte offsets; rows of 256 u32):
+    //   [groups: 4 passes x ceil(wg_cap / 32) rows][counts0: wg_cap rows]   <- header_bytes: zero before a PREPARED sort
+    //   [counts: wg_cap rows]                                                 (an unprepared sort clears its group rows itself)
+    size_t groups_off, groups_bytes, counts0_off, header_bytes, counts_off, total_bytes;
 };
 
 // Plan a sort of key bits [begin_bit, end_bit).  digit_bits = widest digit (<= 8); passes = ceil(bits / digit_bits),
 // the bits are spread evenly over the passes.  Returns false if the request is not representable.
 bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_items, RadixPlan& plan);
-void radix_replan_items(RadixPlan& plan, size_t n);      // the same plan (bit split, workspace) for another item count
+void radix_replan_items(RadixPlan& plan, size_t n);      // the same plan (bit split, workspace, keys per workgroup) for FEWER items
 
 // Sort.  keys[0]/vals[0] hold the input; buffer 1 is scratch of the same size.  The sorted sequence ends in buffer
-// (plan.passes & 1).  vals may be nullptr (keys only).  `prepared`: the caller already zeroed the header
-// (plan.header_bytes at workspace + plan.hist_off) and accumulated the histograms of every pass.
-// What a key-producing kernel needs to prepare a sort (struct RadixHeader of gspl_sort_device.h, filled on the host).
-struct RadixHeader;
-void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr);
+// (plan.passes & 1).  vals may be nullptr (keys only).  `prepared`: the caller zeroed plan.header_bytes at workspace and its
+// key-producing kernel accumulated the pass-0 rows (struct RadixProducer of gspl_sort_device.h, filled on the host by
+// radix_producer_args).
+struct RadixProducer;
+void radix_producer_args(const RadixPlan& plan, void* workspace, RadixProducer& rp);
 
-int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
+// gather (nullable; needs vals): the last pass writes gather[value] where the sorted keys would go.
+int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream,
+                   const uint32_t* gather = nullptr);
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 // Tile sort of the binning: records (tile id << 32 | splat id) sorted on plan's bits (inside the high word); the sorted low
 // words land in ids_out, tile_counts[0, n_tile_counts) receives the number of records per tile id (plan.passes >= 2).

@@ -1,55 +1,44 @@
-// gspl_sort_device.h — device-side half of the radix sort "header" (the global digit histograms of every pass), for kernels
-// that PRODUCE the keys: they touch every key anyway, so the sort needs no header kernel of its own.
-//   __shared__ uint32_t h[RADIX_MAX_PASSES * RADIX_BINS];
-//   radix_hist_clear(h);  __syncthreads();
-//   ... radix_hist_add(h, hdr, key, valid) for every key (called by whole waves) ...
-//   __syncthreads();  radix_hist_flush(h, hdr);
-// The global histogram has RADIX_HIST_COPIES copies (selected by workgroup index, summed by the pass kernels): thousands
-// of workgroups flushing onto 1024 addresses would queue ~16 ns per atomic and address.
+// gspl_sort_device.h — device-side half of a PREPARED radix sort (gspl_sort.h), for kernels that produce the keys: they touch
+// every key anyway, so they count the first pass's digits and the sort's first launch is already a scatter.
+//   __shared__ uint32_t h[RADIX_BINS];
+//   radix_producer_clear(h);  __syncthreads();
+//   ... radix_producer_add(h, rp, key, valid) for every key (called by whole waves) ...
+//   __syncthreads();  radix_producer_flush(h, rp, index of the workgroup's first key);
+// The keys of one producer workgroup must fall into ONE span of the sort (rp.span_items consecutive keys, a multiple of 2048):
+// its row is added to that sort workgroup's pass-0 row and to the row of its group.  Both live in zeroed memory
+// (plan.header_bytes, cleared by the caller before the producer runs).
 #pragma once
 #include "gspl_sort.h"
 #include <hip/hip_runtime.h>
 
 namespace gspl {
 
-struct RadixHeader {
-    uint32_t* hist;            // [RADIX_HIST_COPIES][RADIX_MAX_PASSES][RADIX_BINS], zero on entry
-    int passes;
-    int shift[RADIX_MAX_PASSES];
-    uint32_t mask[RADIX_MAX_PASSES];
+struct RadixProducer {
+    uint32_t* counts0;         // [sort workgroup][RADIX_BINS]
+    uint32_t* groups0;         // [sort workgroup / RADIX_GROUP][RADIX_BINS]
+    uint32_t span_items;       // keys per sort workgroup
+    int shift;                 // pass-0 digit = (key >> shift) & mask
+    uint32_t mask;
 };
 
-__device__ __forceinline__ void radix_hist_clear(uint32_t* h) {
-    for (int j = threadIdx.x; j < RADIX_MAX_PASSES * RADIX_BINS; j += blockDim.x) h[j] = 0u;
+__device__ __forceinline__ void radix_producer_clear(uint32_t* h) {
+    for (int j = threadIdx.x; j < RADIX_BINS; j += blockDim.x) h[j] = 0u;
 }
 
-// One key per lane (valid: the lane holds a key); must be called by all lanes of the wave.  A wave whose keys share the
-// digit — the usual case for the high digits — adds its count with one atomic instead of 64 on one address.
+// One key per lane (valid: the lane holds a key); must be called by all lanes of the wave.
 template <typename KeyT>
-__device__ __forceinline__ void radix_hist_add(uint32_t* h, const RadixHeader& hdr, KeyT key, bool valid) {
-    const unsigned long long act = __ballot(valid);
-    if (act == 0ull) return;
-    const int first = (int)__builtin_ctzll(act);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#pragma unroll
-    for (int p = 0; p < RADIX_MAX_PASSES; ++p) {
-        if (p < hdr.passes) {
-            const uint32_t d = (uint32_t)(key >> hdr.shift[p]) & hdr.mask[p];
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-            if (__ballot(valid && d != d0) == 0ull) {
-                if (lane == first) atomicAdd(&h[p * RADIX_BINS + d0], (uint32_t)__builtin_popcountll(act));
-            } else if (valid) {
-                atomicAdd(&h[p * RADIX_BINS + d], 1u);
-            }
-        }
-    }
+__device__ __forceinline__ void radix_producer_add(uint32_t* h, const RadixProducer& rp, KeyT key, bool valid) {
+    if (valid) atomicAdd(&h[(uint32_t)(key >> rp.shift) & rp.mask], 1u);
 }
 
-__device__ __forceinline__ void radix_hist_flush(const uint32_t* h, const RadixHeader& hdr) {
-    uint32_t* dst = hdr.hist + (size_t)(blockIdx.x % RADIX_HIST_COPIES) * (RADIX_MAX_PASSES * RADIX_BINS);
-    for (int j = threadIdx.x; j < hdr.passes * RADIX_BINS; j += blockDim.x) {
+__device__ __forceinline__ void radix_producer_flush(const uint32_t* h, const RadixProducer& rp, size_t first_key) {
+    const size_t g = first_key / rp.span_items;
+    for (int j = threadIdx.x; j < RADIX_BINS; j += blockDim.x) {
         const uint32_t c = h[j];
-        if (c) atomicAdd(dst + j, c);
+        if (c) {
+            atomicAdd(rp.counts0 + g * RADIX_BINS + j, c);
+            atomicAdd(rp.groups0 + (g / RADIX_GROUP) * RADIX_BINS + j, c);
+        }
     }
 }
 

@@ -5,18 +5,19 @@
 // `cub::DeviceRadixSort::SortPairs(point_list_keys...)` (call sites: reference gsplat_v1_renderer.py:524-556,
 // vanilla_renderer.py:111).  Ordering contract: stable, ascending on the selected key bits — identical to those.
 //
-// One pass = three launches WITHOUT any communication between running workgroups:
-//   count    workgroup g owns a CONTIGUOUS range of tiles and histograms the pass's digit over it -> counts[digit][g]
-//   rowscan  exclusive prefix of every digit row over the workgroups (one wave per digit)
-//   scatter  workgroup g walks its range tile by tile: in-wave ranks by digit matching, tile permuted through LDS into digit
-//            order, written out as runs; the position of a digit's next item is  base[digit] (exclusive scan of the global
-//            digit histogram) + counts[digit][g] (items of lower workgroups) + what the workgroup has placed so far.
+// One pass = two launches WITHOUT any waiting between running workgroups:
+//   count    workgroup g owns a CONTIGUOUS range of tiles and histograms the pass's digit over it -> counts[g][digit], and adds
+//            the row to its GROUP's row (groups[g / 32][digit], atomics on zeroed memory).  The pass-0 rows can come from the
+//            kernel that produced the keys instead (`prepared`, gspl_sort_device.h).
+//   scatter  workgroup g first sums, per digit, the group rows (all of them: the digit totals, whose exclusive scan is the digit's
+//            base; those below its own group: items of lower workgroups) and the rows of the lower workgroups of its own group —
+//            at most 64 + 31 coalesced 1 KB reads — then walks its range tile by tile: in-wave ranks by digit matching, tile
+//            permuted through LDS into digit order, written out as runs.
 // The first version was a one-sweep sort (single read of the keys per pass, decoupled look-back between tiles).  Its look-back
 // walks as many predecessor states as there are tiles in flight — ~770 on this part — so above one resident wave of tiles a pass of
 // 6 M pairs ran at 0.7 TB/s (135 us; rocPRIM's one-sweep ~100 us), it needed tile counters or residency assumptions for forward
-// progress, and a time-out path.  Reading the keys twice costs less than that: no polling, no ordering assumptions, no inter-
-// workgroup dependencies at all (nothing to dead-lock under contention from side streams, other processes or RCCL kernels),
-// bit-reproducible by construction.
+// progress, and a time-out path.  Reading the keys twice costs less than that: no polling, no ordering assumptions, nothing to
+// dead-lock under contention from side streams, other processes or RCCL kernels, bit-reproducible by construction.
 #include "gspl_device.h"
 #include "gspl_host.h"
 #include "gspl_sort.h"
@@ -28,6 +29,16 @@ namespace gspl {
 
 static constexpr int RS_WAVES = 8;
 static constexpr int RS_THREADS = RS_WAVES * 64;
+
+// the keys and values of a pass are read once: streaming loads
+template <typename T>
+__device__ __forceinline__ T load_once(const T* p) {
+#ifdef GSPL_RS_PLAIN_LOAD
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
 
 // Exclusive scan of 256 LDS words (src -> dst) by the first wave, four words per lane.
 __device__ __forceinline__ void scan256_excl(const uint32_t* src, uint32_t* dst) {
@@ -45,29 +56,10 @@ __device__ __forceinline__ void scan256_excl(const uint32_t* src, uint32_t* dst)
     }
 }
 
-// Header kernel, for sorts whose keys were not produced by one of our kernels: the global digit histograms of every pass
-// (gspl_sort_device.h applied to an array).
-template <typename KeyT>
-__global__ __launch_bounds__(RS_THREADS) void radix_header_kernel(const KeyT* __restrict__ keys, uint32_t n, RadixHeader hdr) {
-    __shared__ uint32_t h[RADIX_MAX_PASSES * RADIX_BINS];
-    const int t = threadIdx.x;
-    radix_hist_clear(h);
-    __syncthreads();
-    const size_t stride = (size_t)gridDim.x * RS_THREADS;
-    const size_t rounds = ((size_t)n + stride - 1) / stride;
-    for (size_t r = 0; r < rounds; ++r) {
-        const size_t i = r * stride + (size_t)blockIdx.x * RS_THREADS + t;
-        const bool valid = i < n;
-        radix_hist_add<KeyT>(h, hdr, valid ? keys[i] : (KeyT)0, valid);
-    }
-    __syncthreads();
-    radix_hist_flush(h, hdr);
-}
-
-// ---- count: counts[digit * nwg + g] = items of workgroup g's tile range whose digit of this pass is `digit` ----------------------
+// ---- count: counts[g][digit] = items of workgroup g's tile range whose digit of this pass is `digit`; groups[g / 32][digit] += ----
 template <typename KeyT, int IPT>
 __global__ __launch_bounds__(RS_THREADS) void radix_count_kernel(const KeyT* __restrict__ keys, uint32_t n, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                                 int shift, int nbits, uint32_t* __restrict__ counts) {
+                                                                 int shift, int nbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ groups) {
     constexpr uint32_t TILE = RS_THREADS * IPT;
     __shared__ uint32_t cnt[RS_WAVES][RADIX_BINS];      // per-wave counters: no inter-wave contention on hot digits
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -80,7 +72,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_count_kernel(const KeyT* __r
     for (size_t i = lo + (size_t)t; i < hi; i += (size_t)RS_THREADS * 4) {
         KeyT k[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const size_t j = i + (size_t)u * RS_THREADS; k[u] = j < hi ? keys[j] : (KeyT)0; }
+        for (int u = 0; u < 4; ++u) { const size_t j = i + (size_t)u * RS_THREADS; k[u] = j < hi ? load_once(keys + j) : (KeyT)0; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const size_t j = i + (size_t)u * RS_THREADS;
@@ -105,25 +97,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_count_kernel(const KeyT* __r
         uint32_t c = 0u;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; ++k) c += cnt[k][t];
-        counts[(size_t)t * gridDim.x + blockIdx.x] = c;
-    }
-}
-
-// ---- rowscan: counts[d][0..nwg) -> exclusive prefix over the workgroups, one wave per digit row (nwg <= 64 * 32) ------------------
-__global__ __launch_bounds__(RS_THREADS) void radix_rowscan_kernel(uint32_t* __restrict__ counts, uint32_t nwg, int nd) {
-    const int row = blockIdx.x * RS_WAVES + (threadIdx.x >> 6), l = threadIdx.x & 63;
-    if (row >= nd) return;
-    uint32_t* r = counts + (size_t)row * nwg;
-    const uint32_t per = (nwg + 63u) / 64u;              // consecutive entries per lane
-    const uint32_t b = (uint32_t)l * per;
-    uint32_t mine = 0u;
-    for (uint32_t k = 0; k < per; ++k) mine += (b + k < nwg) ? r[b + k] : 0u;
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (l >= d) incl += up; }
-    uint32_t run = incl - mine;
-    for (uint32_t k = 0; k < per; ++k) {
-        if (b + k < nwg) { const uint32_t c = r[b + k]; r[b + k] = run; run += c; }
+        counts[(size_t)blockIdx.x * RADIX_BINS + t] = c;
+        if (c) atomicAdd(groups + (size_t)(blockIdx.x / RADIX_GROUP) * RADIX_BINS + t, c);
     }
 }
 
@@ -134,27 +109,39 @@ struct RadixShared {
     uint32_t tilecnt[RADIX_BINS];             // the tile's digit histogram
     uint32_t dstart[RADIX_BINS];              // first in-tile slot of each digit
     uint32_t gbase[RADIX_BINS];               // global position of in-tile slot 0 as seen by each digit (modular)
-    KeyT xkey[RS_THREADS * IPT];
-    uint32_t xval[VALUES ? RS_THREADS * IPT : 1];
+    // the permutation buffer; during the ranking (when it is free) its head holds the match masks: match[wave][digit] = the lanes
+    // of the wave whose current item has that digit
+    union {
+        struct {
+            KeyT xkey[RS_THREADS * IPT];
+            uint32_t xval[VALUES ? RS_THREADS * IPT : 1];
+        };
+        unsigned long long match[RS_WAVES][RADIX_BINS];
+    };
 };
 
 // ---- scatter ------------------------------------------------------------------------------------------------------------------
 // A tile = 512 x IPT items held in (wave, round, lane) = memory order.  Per tile:
-//   1. in-wave ranks by digit matching (one ballot per digit bit), per-wave digit counters in LDS
+//   1. in-wave ranks by digit matching (lanes OR their bit into the digit's mask in LDS and read the mask back: ~10 VALU
+//      instructions per 64 items where a ballot per digit bit costs ~70), per-wave digit counters in LDS
 //   2. counters -> tile histogram; exclusive scan -> first in-tile slot per digit
 //   3. permute the tile through LDS into digit order
 //   4. write out: consecutive lanes hold consecutive items of a digit run -> runs of consecutive addresses
-// FINAL (u64 keys, no values; the LAST pass of the tile sort of the binning): the sorted records leave as their low words only
-//   (vals_out = the per-tile lists of splat ids), and the number of records per tile id (the key's high word) is counted into
-//   aux[tile id].  The pass before left the records ordered by the low digit, so after the in-tile permutation equal tile ids are
-//   contiguous runs in LDS: one atomic pair per run (subtract its first slot, add one past its last).
+// FINAL = FINAL_TILES (u64 keys, no values; the LAST pass of the tile sort of the binning): the sorted records leave as their low
+//   words only (vals_out = the per-tile lists of splat ids), and the number of records per tile id (the key's high word) is counted
+//   into aux[tile id].  The pass before left the records ordered by the low digit, so after the in-tile permutation equal tile ids
+//   are contiguous runs in LDS: one atomic pair per run (subtract its first slot, add one past its last).
+// FINAL = FINAL_GATHER (u32 keys with values; the LAST pass of the depth sort of the binning): nobody reads the sorted keys, so
+//   keys_out receives gather[value] instead — the per-splat tile counts in depth order, which the scan then reads contiguously.
 // aux_zero > 0: workgroup 0 clears aux[0, aux_zero) (the pass BEFORE the final one prepares the counters).
-template <typename KeyT, bool VALUES, int IPT, bool FINAL>
+enum { FINAL_NONE = 0, FINAL_TILES = 1, FINAL_GATHER = 2 };
+template <typename KeyT, bool VALUES, int IPT, int FINAL>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                                    KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                    uint32_t ntiles, uint32_t tiles_per_wg, int shift, int nbits,
-                                                                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ counts,
-                                                                   uint32_t* __restrict__ aux, uint32_t aux_zero) {
+                                                                   const uint32_t* __restrict__ groups, const uint32_t* __restrict__ counts,
+                                                                   uint32_t* __restrict__ aux, uint32_t aux_zero,
+                                                                   const uint32_t* __restrict__ gather) {
     constexpr uint32_t TILE = RS_THREADS * IPT;
     __shared__ RadixShared<KeyT, VALUES, IPT> sh;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
@@ -170,41 +157,69 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
         for (int r = 0; r < IPT; ++r) {
             const uint32_t slot = (uint32_t)(w * (64 * IPT) + r * 64 + l);
             const bool valid = slot < tn;
-            k[r] = valid ? keys_in[b0 + slot] : (KeyT)0;
+            k[r] = valid ? load_once(keys_in + b0 + slot) : (KeyT)0;
             v[r] = 0u;
-            if (VALUES) v[r] = valid ? vals_in[b0 + slot] : 0u;
+            if (VALUES) v[r] = valid ? load_once(vals_in + b0 + slot) : 0u;
         }
     };
     if (aux_zero != 0u && blockIdx.x == 0)
         for (uint32_t j = (uint32_t)t; j < aux_zero; j += RS_THREADS) aux[j] = 0u;
     if (t0 >= t1) return;
     load_tile(t0, key, val);
-    // the pass's digit bases (exclusive scan of the global histogram = sum of its copies) + the items of lower workgroups
+    // digit totals (all group rows) -> digit bases; + the items of lower workgroups (lower groups' rows, then the lower rows of
+    // the own group).  Thread = digit: every read is a coalesced 1 KB row.
+    // All row reads of a batch are issued back to back (fixed trip counts, clamped row index): one memory latency per batch, not
+    // one per row — this prologue is on the critical path of every workgroup.
+    uint32_t below = 0u;
     if (t < RADIX_BINS) {
-        uint32_t c = 0u;
+        uint32_t total = 0u;
         if (t < nd) {
+            const uint32_t ngroups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP, gq = blockIdx.x / RADIX_GROUP;
+            for (uint32_t j0 = 0; j0 < ngroups; j0 += 32u) {
+                uint32_t v[32];
 #pragma unroll
-            for (int k = 0; k < RADIX_HIST_COPIES; ++k) c += hist[k * (RADIX_MAX_PASSES * RADIX_BINS) + t];
+                for (uint32_t k = 0; k < 32u; ++k) v[k] = groups[(size_t)min(j0 + k, ngroups - 1u) * RADIX_BINS + t];
+#pragma unroll
+                for (uint32_t k = 0; k < 32u; ++k) {
+                    const uint32_t j = j0 + k;
+                    total += j < ngroups ? v[k] : 0u;
+                    below += j < gq ? v[k] : 0u;
+                }
+            }
+            {
+                const uint32_t first = gq * RADIX_GROUP;      // rows [first, blockIdx.x) of the own group; RADIX_GROUP - 1 at most
+                uint32_t v[RADIX_GROUP - 1];
+#pragma unroll
+                for (uint32_t k = 0; k < RADIX_GROUP - 1; ++k) v[k] = counts[(size_t)min(first + k, (uint32_t)blockIdx.x) * RADIX_BINS + t];
+#pragma unroll
+                for (uint32_t k = 0; k < RADIX_GROUP - 1; ++k) below += first + k < blockIdx.x ? v[k] : 0u;
+            }
         }
-        sh.tilecnt[t] = c;
+        sh.tilecnt[t] = total;
     }
     __syncthreads();
     scan256_excl(sh.tilecnt, sh.next);
     __syncthreads();
-    if (t < nd) sh.next[t] += counts[(size_t)t * gridDim.x + blockIdx.x];
+    if (t < nd) sh.next[t] += below;
 
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint32_t base = tile * TILE;
         const uint32_t tile_n = min(TILE, n - base);
         // ---- 1: rank (wave w owns slots [w*64*IPT, (w+1)*64*IPT) of the tile, 64 per round) ------------------------------
 #pragma unroll
-        for (int k = l; k < RADIX_BINS; k += 64) sh.wcnt[w][k] = 0u;
+        for (int k = l; k < RADIX_BINS; k += 64) {
+            sh.wcnt[w][k] = 0u;
+#ifndef GSPL_RS_MATCH_BALLOT
+            sh.match[w][k] = 0ull;
+#endif
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < IPT; ++r) {
             const uint32_t slot = (uint32_t)(w * (64 * IPT) + r * 64 + l);
             const bool valid = slot < tile_n;
             const uint32_t d = (uint32_t)(key[r] >> shift) & mask;
+#ifdef GSPL_RS_MATCH_BALLOT
             unsigned long long peers = __ballot(valid);
             for (int b = 0; b < nbits; ++b) {
                 const bool bit = (d >> b) & 1u;
@@ -218,6 +233,24 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
             const int leader = valid ? (int)__builtin_ctzll(peers) : l;
             old = __shfl(old, leader);
             rk[r] = old + below;
+#else
+            // LDS operations of one wave execute in program order: every lane's OR lands before the reads below
+            unsigned long long peers = 0ull;
+            uint32_t old = 0u;
+            if (valid) {
+                atomicOr(&sh.match[w][d], 1ull << l);
+                __builtin_amdgcn_wave_barrier();
+                peers = sh.match[w][d];
+                old = sh.wcnt[w][d];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            if (valid && below == 0u) {                 // the digit's first lane: advance the counter, clear the mask for the next round
+                sh.wcnt[w][d] = old + (uint32_t)__builtin_popcountll(peers);
+                sh.match[w][d] = 0ull;
+            }
+            rk[r] = old + below;
+#endif
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
@@ -259,7 +292,11 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
                 const KeyT k = sh.xkey[i];
                 const uint32_t d = (uint32_t)(k >> shift) & mask;
                 const uint32_t gpos = sh.gbase[d] + i;
-                if constexpr (FINAL) {
+                if constexpr (FINAL == FINAL_GATHER) {
+                    const uint32_t v = sh.xval[i];
+                    vals_out[gpos] = v;
+                    keys_out[gpos] = (KeyT)gather[v];
+                } else if constexpr (FINAL == FINAL_TILES) {
                     vals_out[gpos] = (uint32_t)k;
                     const uint32_t id = (uint32_t)((unsigned long long)k >> 32);
                     const bool run_first = (i == 0u) || ((uint32_t)((unsigned long long)sh.xkey[i - 1] >> 32) != id);
@@ -279,8 +316,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
     }
 }
 
-// Workgroups a pass runs with: GSPL_RS_WG_PER_CU per CU, never more than there are tiles or than one wave can scan (64 x 32).
-// The value is part of the plan (the workspace is sized for the maximum).
+// Workgroups a pass runs with: GSPL_RS_WG_PER_CU per CU, never more than there are tiles or than RADIX_MAX_WG.
 static unsigned pass_workgroups(uint32_t ntiles) {
     static unsigned cus = 0;
     if (cus == 0) {
@@ -294,6 +330,15 @@ static unsigned pass_workgroups(uint32_t ntiles) {
     if (g > (unsigned)RADIX_MAX_WG) g = (unsigned)RADIX_MAX_WG;
     if (g > ntiles) g = ntiles;
     return g ? g : 1u;
+}
+
+static void plan_items(RadixPlan& plan, size_t n) {
+    plan.n = (uint32_t)n;
+    plan.ntiles = (uint32_t)((n + plan.tile_items - 1) / plan.tile_items);
+    plan.nwg = pass_workgroups(plan.ntiles);
+    plan.tiles_per_wg = (plan.ntiles + plan.nwg - 1) / plan.nwg;
+    if (plan.tiles_per_wg == 0) plan.tiles_per_wg = 1;
+    plan.nwg = plan.ntiles ? (plan.ntiles + plan.tiles_per_wg - 1) / plan.tiles_per_wg : 1u;      // no empty workgroups at the end
 }
 
 bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_items, RadixPlan& plan) {
@@ -312,83 +357,85 @@ bool radix_plan(size_t n, int begin_bit, int end_bit, int digit_bits, int tile_i
     }
     for (int p = passes; p < RADIX_MAX_PASSES; ++p) { plan.shift[p] = 0; plan.bits[p] = 0; }
     plan.tile_items = (uint32_t)tile_items;
-    plan.hist_off = 0;
-    plan.header_bytes = (size_t)RADIX_HIST_COPIES * RADIX_MAX_PASSES * RADIX_BINS * sizeof(uint32_t);
+    plan_items(plan, n);
+    // tables sized for THIS item count (replanning for fewer items keeps them): group rows of every pass, the pass-0 rows a
+    // preparing producer accumulates (both zero before use), the rows of the other passes
+    plan.wg_cap = plan.nwg;
+    const size_t rows = (size_t)RADIX_BINS * sizeof(uint32_t);
+    plan.groups_off = 0;
+    plan.groups_bytes = (size_t)RADIX_MAX_PASSES * ((plan.wg_cap + RADIX_GROUP - 1) / RADIX_GROUP) * rows;
+    plan.counts0_off = plan.groups_bytes;
+    plan.header_bytes = plan.counts0_off + plan.wg_cap * rows;
     plan.counts_off = plan.header_bytes;
-    // counts: one row of `nwg` words per digit, reused by every pass; sized for the largest workgroup count
-    plan.total_bytes = plan.counts_off + (size_t)RADIX_BINS * RADIX_MAX_WG * sizeof(uint32_t);
-    radix_replan_items(plan, n);
+    plan.total_bytes = plan.counts_off + plan.wg_cap * rows;
     return true;
 }
 
-// Same bit split and workspace, another item count.
+// Same bit split, workspace and SPANS (keys per workgroup: a producer may already have counted by them), fewer items.
 void radix_replan_items(RadixPlan& plan, size_t n) {
     plan.n = (uint32_t)n;
     plan.ntiles = (uint32_t)((n + plan.tile_items - 1) / plan.tile_items);
-    plan.nwg = pass_workgroups(plan.ntiles);
-    plan.tiles_per_wg = (plan.ntiles + plan.nwg - 1) / plan.nwg;
-    if (plan.tiles_per_wg == 0) plan.tiles_per_wg = 1;
-    plan.nwg = plan.ntiles ? (plan.ntiles + plan.tiles_per_wg - 1) / plan.tiles_per_wg : 1u;      // no empty workgroups at the end
+    plan.nwg = plan.ntiles ? (plan.ntiles + plan.tiles_per_wg - 1) / plan.tiles_per_wg : 1u;
 }
 
-void radix_header_args(const RadixPlan& plan, void* workspace, RadixHeader& hdr) {
+void radix_producer_args(const RadixPlan& plan, void* workspace, RadixProducer& rp) {
     char* ws = (char*)workspace;
-    hdr.hist = (uint32_t*)(ws + plan.hist_off);
-    hdr.passes = plan.passes;
-    for (int p = 0; p < RADIX_MAX_PASSES; ++p) { hdr.shift[p] = plan.shift[p]; hdr.mask[p] = plan.bits[p] ? ((1u << plan.bits[p]) - 1u) : 0u; }
+    rp.counts0 = (uint32_t*)(ws + plan.counts0_off);
+    rp.groups0 = (uint32_t*)(ws + plan.groups_off);
+    rp.span_items = plan.tile_items * plan.tiles_per_wg;
+    rp.shift = plan.shift[0];
+    rp.mask = (1u << plan.bits[0]) - 1u;
 }
 
 template <typename KeyT, int IPT>
 static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const keys[2], uint32_t* const vals[2], bool prepared, void* stream,
-                           uint32_t* final_ids = nullptr, uint32_t* tile_counts = nullptr, uint32_t n_tile_counts = 0) {
+                           uint32_t* final_ids = nullptr, uint32_t* tile_counts = nullptr, uint32_t n_tile_counts = 0,
+                           const uint32_t* gather = nullptr) {
     if (plan.n == 0) return GSPL_OK;
     if (plan.tile_items != (uint32_t)(RS_THREADS * IPT)) return fail_arg("radix_sort: plan made for another tile size");
+    if (plan.nwg > plan.wg_cap) return fail_arg("radix_sort: plan replanned for more items than its tables hold");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    uint32_t* hist = (uint32_t*)(ws + plan.hist_off);
-    uint32_t* counts = (uint32_t*)(ws + plan.counts_off);
+    const size_t group_rows = (plan.wg_cap + RADIX_GROUP - 1) / RADIX_GROUP;
     if (!prepared) {
-        hipError_t e = hipMemsetAsync(ws + plan.hist_off, 0, plan.header_bytes, s);
-        if (e != hipSuccess) return check_hip(e, "radix_sort: header clear");
-        RadixHeader hdr;
-        radix_header_args(plan, workspace, hdr);
-        const size_t want = ((size_t)plan.n + RS_THREADS * 4 - 1) / (RS_THREADS * 4);
-        const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
-        hipLaunchKernelGGL(radix_header_kernel<KeyT>, dim3(grid ? grid : 1), dim3(RS_THREADS), 0, s, (const KeyT*)keys[0], plan.n, hdr);
-        int rc = check_launch("radix_sort(header)");
-        if (rc != GSPL_OK) return rc;
+        hipError_t e = hipMemsetAsync(ws + plan.groups_off, 0, plan.groups_bytes, s);
+        if (e != hipSuccess) return check_hip(e, "radix_sort: group rows clear");
     }
     for (int p = 0; p < plan.passes; ++p) {
         const KeyT* kin = keys[p & 1];
         const uint32_t* vin = vals ? vals[p & 1] : nullptr;
         KeyT* kout = keys[(p + 1) & 1];
-        const int nd = 1 << plan.bits[p];
-        hipLaunchKernelGGL((radix_count_kernel<KeyT, IPT>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, plan.n, plan.ntiles, plan.tiles_per_wg,
-                           plan.shift[p], plan.bits[p], counts);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3((nd + RS_WAVES - 1) / RS_WAVES), dim3(RS_THREADS), 0, s, counts, plan.nwg, nd);
+        uint32_t* groups = (uint32_t*)(ws + plan.groups_off) + (size_t)p * group_rows * RADIX_BINS;
+        uint32_t* counts = (uint32_t*)(ws + ((p == 0 && prepared) ? plan.counts0_off : plan.counts_off));
+        if (!(p == 0 && prepared))
+            hipLaunchKernelGGL((radix_count_kernel<KeyT, IPT>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, plan.n, plan.ntiles, plan.tiles_per_wg,
+                               plan.shift[p], plan.bits[p], counts, groups);
         const bool last = p == plan.passes - 1;
         uint32_t* aux = final_ids ? tile_counts : nullptr;
         const uint32_t aux_zero = (final_ids && p == plan.passes - 2) ? n_tile_counts : 0u;
+#define GSPL_SCATTER(VALUES, FINAL, VIN, VOUT)                                                                                              \
+        hipLaunchKernelGGL((radix_scatter_kernel<KeyT, VALUES, IPT, FINAL>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, VIN, kout, VOUT, plan.n, \
+                           plan.ntiles, plan.tiles_per_wg, plan.shift[p], plan.bits[p], groups, counts, aux, aux_zero, gather)
         if (final_ids && last) {
-            if constexpr (sizeof(KeyT) == 8) {
-                hipLaunchKernelGGL((radix_scatter_kernel<KeyT, false, IPT, true>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, nullptr, kout, final_ids,
-                                   plan.n, plan.ntiles, plan.tiles_per_wg, plan.shift[p], plan.bits[p], hist + p * RADIX_BINS, counts, aux, aux_zero);
-            }
+            if constexpr (sizeof(KeyT) == 8) GSPL_SCATTER(false, FINAL_TILES, nullptr, final_ids);
+        } else if (gather && last) {
+            if constexpr (sizeof(KeyT) == 4) GSPL_SCATTER(true, FINAL_GATHER, vin, vals[(p + 1) & 1]);
         } else if (vals) {
-            hipLaunchKernelGGL((radix_scatter_kernel<KeyT, true, IPT, false>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, vin, kout, vals[(p + 1) & 1],
-                               plan.n, plan.ntiles, plan.tiles_per_wg, plan.shift[p], plan.bits[p], hist + p * RADIX_BINS, counts, aux, aux_zero);
+            GSPL_SCATTER(true, FINAL_NONE, vin, vals[(p + 1) & 1]);
         } else {
-            hipLaunchKernelGGL((radix_scatter_kernel<KeyT, false, IPT, false>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, nullptr, kout, nullptr,
-                               plan.n, plan.ntiles, plan.tiles_per_wg, plan.shift[p], plan.bits[p], hist + p * RADIX_BINS, counts, aux, aux_zero);
+            GSPL_SCATTER(false, FINAL_NONE, nullptr, nullptr);
         }
+#undef GSPL_SCATTER
         int rc = check_launch("radix_sort(pass)");
         if (rc != GSPL_OK) return rc;
     }
     return GSPL_OK;
 }
 
-int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
-    return radix_sort_impl<uint32_t, RADIX_TILE_U32 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream);
+int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream,
+                   const uint32_t* gather) {
+    if (gather && !vals) return fail_arg("radix_sort_u32: gather needs values");
+    return radix_sort_impl<uint32_t, RADIX_TILE_U32 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream, nullptr, nullptr, 0, gather);
 }
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream) {
     return radix_sort_impl<uint64_t, RADIX_TILE_U64 / RS_THREADS>(plan, workspace, keys, vals, prepared, stream);
