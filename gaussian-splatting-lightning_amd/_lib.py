@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
@@ -83,7 +83,7 @@ _SIGNATURES = {
     "gspl_densify_stats": (c_int, [c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_knn_workspace_bytes": (c_size_t, [c_int]),
     "gspl_knn3_mean_dist2": (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
-    "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_emit": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, c_size_t, _P]),
     "gspl_bin_sort": (c_int, [c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),

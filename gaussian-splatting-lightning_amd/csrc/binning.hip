@@ -538,8 +538,8 @@ extern "C" size_t gspl_bin_workspace_bytes(int N, int64_t n_isects) {
 extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
                               const float* conics, const float* opacities,
                               int tile_size, int tile_w, int tile_h,
-                              int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, void* workspace, size_t workspace_bytes,
-                              void* stream) {
+                              int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
+                              void* workspace, size_t workspace_bytes, void* stream) {
     using namespace gspl;
     if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_count: bad sizes");
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_count: bad mode");
@@ -579,7 +579,7 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     if (rc != GSPL_OK) return rc;
     // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte read-back
     // gives the host both numbers
-    return scan_gathered_counts(nullptr, (const int32_t*)kbuf[dp.passes & 1], cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s);
+    return scan_gathered_counts(nullptr, (const int32_t*)kbuf[dp.passes & 1], cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s, host_counts);
 }
 
 // Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has

@@ -181,10 +181,9 @@ extern "C" int gspl_rasterize_inria_fwd(
         if (!host) return fail_arg("rasterize_inria_fwd: no pinned host word");
         {
             rc = gspl_bin_count(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
-                                spans, ws1, ws1_bytes, s);
+                                spans, host, ws1, ws1_bytes, s);      // the scan kernel stores the two numbers into `host` itself
             if (rc != GSPL_OK) return rc;
             hipEvent_t ev_cnt = fe.cnt;
-            (void)hipMemcpyAsync(host, cum + (N - 1), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s);
             (void)hipEventRecord(ev_cnt, s);
             // speculative emission with the caller's guess of the list length, while the host waits for the real one
             int64_t capacity = 0;

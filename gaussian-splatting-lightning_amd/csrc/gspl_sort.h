@@ -77,8 +77,11 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* worksp
 // the sums, per-block scan).  workspace: scan_workspace_bytes(n), 8-byte aligned, no initialisation needed.
 // Counts with bit 31 set are TAGGED: the bit is not part of the count, and with `tagged_list` (nullable) the scan also writes
 // the positions i of the tagged items in order to tagged_list[0..) and their number to cum[n] (cum then has n + 1 entries).
+// host_words (nullable): device-accessible HOST memory (pinned) for two int64 — the kernel itself stores the total and the tagged
+// count there, so a host that waits for an event after the scan reads them without a copy launch.
 static constexpr int SCAN_TILE = 2048;
 size_t scan_workspace_bytes(size_t n);
-int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* workspace, int32_t* tagged_list, void* stream);
+int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* workspace, int32_t* tagged_list, void* stream,
+                         int64_t* host_words = nullptr);
 
 }  // namespace gspl

@@ -700,7 +700,7 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     if conics is not None and opacities is not None:
         p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
     p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
-    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = p.big_list = p.depths = p.count = None
+    p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = p.big_list = p.depths = None
     p.capacity = p.ws2_bytes = 0
     if N > 0:
         p.order = torch.empty((N,), dtype=torch.int32, device=dev)
@@ -713,15 +713,12 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         p.depths = depths
 
-        def count():
-            L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
-                   block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.big_list), L.ptr(p.spans), L.ptr(ws), ws_bytes,
-                   L.stream())
-        p.count = count
-        count()
-        # the one host read-back of the pipeline: the list length (sizes the sort buffers) and the number of big splats
+        # the one host read-back of the pipeline: the list length (sizes the sort buffers) and the number of big splats, stored into
+        # pinned host memory by the scan kernel itself (no copy launch)
         p.host_count = _PINNED_WORDS.pop() if _PINNED_WORDS else torch.empty((2,), dtype=torch.int64).pin_memory()
-        p.host_count.copy_(p.cum[N - 1:N + 1], non_blocking=True)
+        L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
+               block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.big_list), L.ptr(p.spans), p.host_count.data_ptr(),
+               L.ptr(ws), ws_bytes, L.stream())
         p.event = torch.cuda.Event()
         p.event.record()
         # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of

@@ -204,6 +204,9 @@ int gspl_bin_count(int N, int mode,
                                         the emission deals them out to its workgroups instead of leaving up to 64
                                         consecutive screen-filling splats to one wave */,
                    void* spans /* GSPL_BIN_SPAN_BYTES * N, 16-byte aligned */,
+                   int64_t* host_counts /* nullable: two int64 of device-accessible HOST memory (hipHostMalloc / a pinned tensor);
+                                           the last kernel stores cum_tiles[N-1] (the list length) and n_big there itself, so a
+                                           host that records an event after this call and waits for it needs no copy */,
                    void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_emit_sort(int N, int mode,
                        const float* means2d, const int32_t* radii,

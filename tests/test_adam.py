@@ -102,7 +102,9 @@ def test_fused_adam_resumes_a_torch_adam_state_and_accepts_its_kwargs():
     for k in range(2):
         ref_p.grad = grads[k].cuda()
         ref.step()
-    sd = ref.state_dict()                         # what a checkpoint holds: state[0]["step"] is a tensor
+    import copy
+    sd = copy.deepcopy(ref.state_dict())          # what a checkpoint holds: state[0]["step"] is a tensor (a copy: load_state_dict
+                                                  # keeps same-device tensors by reference, the two optimizers must not share moments)
     assert isinstance(sd["state"][0]["step"], torch.Tensor)
     my_p = ref_p.detach().clone().requires_grad_(True)
     mine = gopt.HipFusedAdam().instantiate([{"params": [my_p], "name": "means"}], lr=1e-2, eps=1e-15, weight_decay=0.0, amsgrad=False)
