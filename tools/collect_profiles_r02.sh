@@ -13,7 +13,7 @@ b --no-cpu-baseline --optimizer none > $O/${tag}_bench_no_optimizer.json
 for w in S-800-100k S-1080p-6M S-garden-6M S-4k-2M S-1080p-1M-inside; do b --no-cpu-baseline --stage-times --workload $w >> $O/${tag}_bench_other_workloads.jsonl; done
 b --no-cpu-baseline --parallelism sharded > $O/${tag}_bench_sharded_1gpu.json
 for m in replicated sharded; do
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 2951$RANDOM bench.py --gpus 2 --steps 20 --warmup 5 \
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29510 + RANDOM % 400)) bench.py --gpus 2 --steps 20 --warmup 5 \
       --dist-backend gloo --share-device --parallelism $m 2>/dev/null | tail -1 > $O/${tag}_bench_${m}_2ranks_shared_gpu_gloo.json
 done
 cd /tmp && export TMPDIR=/tmp
