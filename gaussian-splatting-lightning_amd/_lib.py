@@ -16,8 +16,10 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 24
+ABI_VERSION = 25
 
+GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
+CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
 GSPL_MODE_GSPLAT = 0
 GSPL_MODE_INRIA = 1
 GSPL_LAYOUT_HWC = 0
@@ -58,8 +60,8 @@ _SIGNATURES = {
     "gspl_last_error": (ctypes.c_char_p, []),
     "gspl_composite_bwd_kernel_name": (ctypes.c_char_p, []),
     "gspl_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int,
-                                 c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
-    "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float,
+                                 c_float, c_float, c_float, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int,
                                  _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "gspl_sh_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),

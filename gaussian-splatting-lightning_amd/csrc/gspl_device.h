@@ -177,6 +177,153 @@ __device__ __forceinline__ void ewa_bwd(const float pc[3], const float S6[6], co
     v_pc[2] += vz;
 }
 
+// ---- camera models other than the pinhole (gsplat v1 `camera_model`: "ortho", "fisheye"; reference option
+//      internal/renderers/gsplat_v1_renderer.py:50,154) ------------------------------------------------------------------
+// The fork's kernels are un-vendored; the models are restated from the published gsplat definitions:
+//   ortho    mean2d = (fx x + cx, fy y + cy),  J = [[fx, 0, 0], [0, fy, 0]]
+//   fisheye  (equidistant)  r = |(x, y)| + eps, theta = atan2(r, z + eps), mean2d = (fx x theta / r + cx, fy y theta / r + cy),
+//            J = d(mean2d)/d(x, y, z) in the closed form below (eps = 1e-7 exactly where the published code has it).
+// No 1.3 tan(fov) clamp in these models.  EWA with a general 2x3 Jacobian: T = J W, cov2d = T Sigma T^T.
+enum { GSPL_CAM_PINHOLE_ = 0, GSPL_CAM_ORTHO_ = 1, GSPL_CAM_FISHEYE_ = 2 };
+static constexpr float FISHEYE_EPS = 1e-7f;
+
+struct FisheyeTerms { float x, y, z, r, x2, y2, xy, s, q, theta, a, b; };
+
+__device__ __forceinline__ void fisheye_terms(const float pc[3], FisheyeTerms& t) {
+    t.x = pc[0]; t.y = pc[1]; t.z = pc[2];
+    t.r = sqrtf(t.x * t.x + t.y * t.y) + FISHEYE_EPS;
+    t.x2 = t.x * t.x + FISHEYE_EPS;
+    t.y2 = t.y * t.y;
+    t.xy = t.x * t.y;
+    t.s = t.x2 + t.y2;
+    t.q = 1.f / (t.s + t.z * t.z);
+    t.theta = atan2f(t.r, t.z);
+    t.b = t.theta / t.r / t.s;
+    t.a = t.z * t.q / t.s;
+}
+
+// J (row-major 2x3) and the projected mean WITHOUT the principal point.
+template <int CAM>
+__device__ __forceinline__ void cam_project(const float pc[3], float fx, float fy, float J[6], float& mx, float& my) {
+    if (CAM == GSPL_CAM_ORTHO_) {
+        J[0] = fx; J[1] = 0.f; J[2] = 0.f; J[3] = 0.f; J[4] = fy; J[5] = 0.f;
+        mx = fx * pc[0]; my = fy * pc[1];
+    } else {
+        FisheyeTerms t;
+        fisheye_terms(pc, t);
+        const float thm = atan2f(t.r, t.z + FISHEYE_EPS);
+        mx = t.x * fx * thm / t.r;
+        my = t.y * fy * thm / t.r;
+        J[0] = fx * (t.x2 * t.a + t.y2 * t.b); J[1] = fx * t.xy * (t.a - t.b); J[2] = -fx * t.x * t.q;
+        J[3] = fy * t.xy * (t.a - t.b); J[4] = fy * (t.y2 * t.a + t.x2 * t.b); J[5] = -fy * t.y * t.q;
+    }
+}
+
+// v_pc += (d mean / d pc)^T (vmx, vmy) + (d J / d pc)^T vJ
+template <int CAM>
+__device__ __forceinline__ void cam_project_bwd(const float pc[3], float fx, float fy, const float vJ[6], float vmx, float vmy, float v_pc[3]) {
+    if (CAM == GSPL_CAM_ORTHO_) {
+        v_pc[0] += fx * vmx;
+        v_pc[1] += fy * vmy;
+        return;
+    }
+    FisheyeTerms t;
+    fisheye_terms(pc, t);
+    const float x = t.x, y = t.y, z = t.z, r = t.r;
+    const float r0 = fmaxf(r - FISHEYE_EPS, 1e-30f);          // |(x, y)|: d r / d x = x / r0
+    const float drdx = x / r0, drdy = y / r0;
+    // mean: m = f * c * g(r, z) with g = atan2(r, z + eps) / r
+    {
+        const float ze = z + FISHEYE_EPS;
+        const float den = 1.f / (r * r + ze * ze);
+        const float thm = atan2f(r, ze);
+        const float g = thm / r;
+        const float dg_dr = (ze * den) / r - thm / (r * r);
+        const float dg_dz = (-r * den) / r;
+        const float wx = fx * vmx, wy = fy * vmy;
+        const float common = (wx * x + wy * y) * dg_dr;
+        v_pc[0] += wx * g + common * drdx;
+        v_pc[1] += wy * g + common * drdy;
+        v_pc[2] += (wx * x + wy * y) * dg_dz;
+    }
+    // Jacobian entries
+    const float s = t.s, q = t.q, a = t.a, b = t.b, th = t.theta;
+    const float den = 1.f / (r * r + z * z);
+    const float dth_dr = z * den, dth_dz = -r * den;
+    const float dq[3] = {-q * q * 2.f * x, -q * q * 2.f * y, -q * q * 2.f * z};
+    const float ds[3] = {2.f * x, 2.f * y, 0.f};
+    const float dr[3] = {drdx, drdy, 0.f};
+    float da[3], db[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        da[k] = z * dq[k] / s - z * q / (s * s) * ds[k];
+        db[k] = dth_dr * dr[k] / (r * s) - th / (r * r * s) * dr[k] - th / (r * s * s) * ds[k];
+    }
+    da[2] += q / s;
+    db[2] += dth_dz / (r * s);
+    const float amb = a - b;
+    const float dx2[3] = {2.f * x, 0.f, 0.f}, dy2[3] = {0.f, 2.f * y, 0.f}, dxy[3] = {y, x, 0.f};
+    const float dxk[3] = {1.f, 0.f, 0.f}, dyk[3] = {0.f, 1.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float dJ00 = fx * (dx2[k] * a + t.x2 * da[k] + dy2[k] * b + t.y2 * db[k]);
+        const float dJ01 = fx * (dxy[k] * amb + t.xy * (da[k] - db[k]));
+        const float dJ02 = -fx * (dxk[k] * q + x * dq[k]);
+        const float dJ10 = fy * (dxy[k] * amb + t.xy * (da[k] - db[k]));
+        const float dJ11 = fy * (dy2[k] * a + t.y2 * da[k] + dx2[k] * b + t.x2 * db[k]);
+        const float dJ12 = -fy * (dyk[k] * q + y * dq[k]);
+        v_pc[k] += vJ[0] * dJ00 + vJ[1] * dJ01 + vJ[2] * dJ02 + vJ[3] * dJ10 + vJ[4] * dJ11 + vJ[5] * dJ12;
+    }
+}
+
+// cov2d (a0, b0, c0) = (J W) Sigma (J W)^T for a general J; T0 / T1 = the rows of J W.
+__device__ __forceinline__ void ewa_fwd_general(const float J[6], const float S6[6], const float W[9],
+                                                float& a0, float& b0, float& c0, float T0[3], float T1[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        T0[j] = J[0] * W[0 * 3 + j] + J[1] * W[1 * 3 + j] + J[2] * W[2 * 3 + j];
+        T1[j] = J[3] * W[0 * 3 + j] + J[4] * W[1 * 3 + j] + J[5] * W[2 * 3 + j];
+    }
+    const float s0x = S6[0] * T0[0] + S6[1] * T0[1] + S6[2] * T0[2];
+    const float s0y = S6[1] * T0[0] + S6[3] * T0[1] + S6[4] * T0[2];
+    const float s0z = S6[2] * T0[0] + S6[4] * T0[1] + S6[5] * T0[2];
+    const float s1x = S6[0] * T1[0] + S6[1] * T1[1] + S6[2] * T1[2];
+    const float s1y = S6[1] * T1[0] + S6[3] * T1[1] + S6[4] * T1[2];
+    const float s1z = S6[2] * T1[0] + S6[4] * T1[1] + S6[5] * T1[2];
+    a0 = T0[0] * s0x + T0[1] * s0y + T0[2] * s0z;
+    b0 = T0[0] * s1x + T0[1] * s1y + T0[2] * s1z;
+    c0 = T1[0] * s1x + T1[1] * s1y + T1[2] * s1z;
+}
+
+// (va, vb, vc) as in ewa_bwd -> vJ (row-major 2x3) and G6.
+__device__ __forceinline__ void ewa_bwd_general(const float S6[6], const float W[9], const float T0[3], const float T1[3],
+                                                float va, float vb, float vc, float vJ[6], float G6[6]) {
+    const float hb = 0.5f * vb;
+    G6[0] = va * T0[0] * T0[0] + vb * T0[0] * T1[0] + vc * T1[0] * T1[0];
+    G6[3] = va * T0[1] * T0[1] + vb * T0[1] * T1[1] + vc * T1[1] * T1[1];
+    G6[5] = va * T0[2] * T0[2] + vb * T0[2] * T1[2] + vc * T1[2] * T1[2];
+    G6[1] = va * T0[0] * T0[1] + hb * (T0[0] * T1[1] + T1[0] * T0[1]) + vc * T1[0] * T1[1];
+    G6[2] = va * T0[0] * T0[2] + hb * (T0[0] * T1[2] + T1[0] * T0[2]) + vc * T1[0] * T1[2];
+    G6[4] = va * T0[1] * T0[2] + hb * (T0[1] * T1[2] + T1[1] * T0[2]) + vc * T1[1] * T1[2];
+    const float s0[3] = {S6[0] * T0[0] + S6[1] * T0[1] + S6[2] * T0[2],
+                         S6[1] * T0[0] + S6[3] * T0[1] + S6[4] * T0[2],
+                         S6[2] * T0[0] + S6[4] * T0[1] + S6[5] * T0[2]};
+    const float s1[3] = {S6[0] * T1[0] + S6[1] * T1[1] + S6[2] * T1[2],
+                         S6[1] * T1[0] + S6[3] * T1[1] + S6[4] * T1[2],
+                         S6[2] * T1[0] + S6[4] * T1[1] + S6[5] * T1[2]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            v0 += (2.f * va * s0[j] + vb * s1[j]) * W[k * 3 + j];
+            v1 += (2.f * vc * s1[j] + vb * s0[j]) * W[k * 3 + j];
+        }
+        vJ[k] = v0;
+        vJ[3 + k] = v1;
+    }
+}
+
 // conic (A,B,C) = inverse of [[a,b],[b,c]]; given dL/d(A,B,C) (vB w.r.t. the single parameter B)
 // return dL/d(a,b,c).
 __device__ __forceinline__ void conic_bwd(float a, float b, float c, float vA, float vB, float vC,

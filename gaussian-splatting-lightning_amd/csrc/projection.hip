@@ -35,6 +35,7 @@ __device__ __forceinline__ void load_cam(const float* __restrict__ viewmats, con
     c.fx = K[0]; c.cx = K[2]; c.fy = K[4]; c.cy = K[5];
 }
 
+template <int CAM>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int C, int N,
     const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
@@ -68,11 +69,17 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         quat_to_rotmat(q, R);
         cov3d_from_scale_rot(s, R, S6);
 
-        const float limx = 1.3f * (0.5f * (float)width / c.fx);
-        const float limy = 1.3f * (0.5f * (float)height / c.fy);
-        float a0, b0, c0;
-        EwaCtx ctx;
-        ewa_fwd(pc, S6, c.W, c.fx, c.fy, limx, limy, a0, b0, c0, ctx);
+        float a0, b0, c0, mx = 0.f, my = 0.f;
+        if constexpr (CAM == GSPL_CAM_PINHOLE_) {
+            const float limx = 1.3f * (0.5f * (float)width / c.fx);
+            const float limy = 1.3f * (0.5f * (float)height / c.fy);
+            EwaCtx ctx;
+            ewa_fwd(pc, S6, c.W, c.fx, c.fy, limx, limy, a0, b0, c0, ctx);
+        } else {
+            float J[6], T0[3], T1[3];
+            cam_project<CAM>(pc, c.fx, c.fy, J, mx, my);
+            ewa_fwd_general(J, S6, c.W, a0, b0, c0, T0, T1);
+        }
 
         const float det0 = a0 * c0 - b0 * b0;
         const float a = a0 + eps2d, cc = c0 + eps2d, b = b0;
@@ -81,9 +88,15 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         if (ok) {
             const float comp = sqrtf(fmaxf(det0 / det, 0.f));
             const float inv_det = 1.f / det;
-            const float rz = 1.f / (pc[2] + 1e-6f);
-            const float x2d = c.fx * (pc[0] * rz) + c.cx;
-            const float y2d = c.fy * (pc[1] * rz) + c.cy;
+            float x2d, y2d;
+            if constexpr (CAM == GSPL_CAM_PINHOLE_) {
+                const float rz = 1.f / (pc[2] + 1e-6f);
+                x2d = c.fx * (pc[0] * rz) + c.cx;
+                y2d = c.fy * (pc[1] * rz) + c.cy;
+            } else {
+                x2d = mx + c.cx;
+                y2d = my + c.cy;
+            }
             const float mid = 0.5f * (a + cc);
             const float lambda = mid + sqrtf(fmaxf(mid * mid - det, 0.1f));
             const int radius = (int)ceilf(3.f * sqrtf(lambda));
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     if (tiles_hit) tiles_hit[idx] = o_tiles;
 }
 
-template <bool ATOMIC>
+template <bool ATOMIC, int CAM>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int C, int N,
     const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
@@ -142,11 +155,18 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float R[9], S6[6];
         quat_to_rotmat(q, R);
         cov3d_from_scale_rot(s, R, S6);
-        const float limx = 1.3f * (0.5f * (float)width / c.fx);
-        const float limy = 1.3f * (0.5f * (float)height / c.fy);
         float a0, b0, c0;
         EwaCtx ctx;
-        ewa_fwd(pc, S6, c.W, c.fx, c.fy, limx, limy, a0, b0, c0, ctx);
+        float T0[3], T1[3];
+        if constexpr (CAM == GSPL_CAM_PINHOLE_) {
+            const float limx = 1.3f * (0.5f * (float)width / c.fx);
+            const float limy = 1.3f * (0.5f * (float)height / c.fy);
+            ewa_fwd(pc, S6, c.W, c.fx, c.fy, limx, limy, a0, b0, c0, ctx);
+        } else {
+            float J[6], mx, my;
+            cam_project<CAM>(pc, c.fx, c.fy, J, mx, my);
+            ewa_fwd_general(J, S6, c.W, a0, b0, c0, T0, T1);
+        }
         const float a = a0 + eps2d, cc = c0 + eps2d, b = b0;
         const float det0 = a0 * c0 - b0 * b0;
         const float det = a * cc - b * b;
@@ -167,13 +187,19 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         }
         float vpc[3] = {0.f, 0.f, 0.f};
         float G6[6];
-        ewa_bwd<true>(pc, S6, c.W, c.fx, c.fy, ctx, va, vb, vc, vpc, G6);
-        // 2D mean: x2d = fx * x / (z + 1e-6) + cx
-        const float rz = 1.f / (pc[2] + 1e-6f);
         const float vx2 = v_means2d[idx * s2 + 0], vy2 = v_means2d[idx * s2 + 1];
-        vpc[0] += vx2 * c.fx * rz;
-        vpc[1] += vy2 * c.fy * rz;
-        vpc[2] += -(vx2 * c.fx * pc[0] + vy2 * c.fy * pc[1]) * rz * rz;
+        if constexpr (CAM == GSPL_CAM_PINHOLE_) {
+            ewa_bwd<true>(pc, S6, c.W, c.fx, c.fy, ctx, va, vb, vc, vpc, G6);
+            // 2D mean: x2d = fx * x / (z + 1e-6) + cx
+            const float rz = 1.f / (pc[2] + 1e-6f);
+            vpc[0] += vx2 * c.fx * rz;
+            vpc[1] += vy2 * c.fy * rz;
+            vpc[2] += -(vx2 * c.fx * pc[0] + vy2 * c.fy * pc[1]) * rz * rz;
+        } else {
+            float vJ[6];
+            ewa_bwd_general(S6, c.W, T0, T1, va, vb, vc, vJ, G6);
+            cam_project_bwd<CAM>(pc, c.fx, c.fy, vJ, vx2, vy2, vpc);
+        }
         if (v_depths) vpc[2] += v_depths[idx];
         // p_c = W p + t
 #pragma unroll
@@ -204,33 +230,39 @@ extern "C" int gspl_project_fwd(int C, int N,
                                 const float* viewmats, const float* Ks,
                                 int width, int height, int tile_size,
                                 float scale_modifier, float eps2d, float near_plane, float far_plane,
-                                float radius_clip,
+                                float radius_clip, int camera_model,
                                 int32_t* radii, float* means2d, float* depths, float* conics,
                                 float* compensations, int32_t* tiles_hit, void* stream) {
     if (C < 0 || N < 0 || width <= 0 || height <= 0 || tile_size <= 0) return gspl::fail_arg("project_fwd: bad sizes");
+    if (camera_model < GSPL_CAMERA_PINHOLE || camera_model > GSPL_CAMERA_FISHEYE) return gspl::fail_arg("project_fwd: unknown camera model");
     if ((int64_t)C * N == 0) return GSPL_OK;
     if (!means || !scales || !quats || !viewmats || !Ks || !radii || !means2d || !depths || !conics)
         return gspl::fail_arg("project_fwd: NULL required pointer");
     const int64_t total = (int64_t)C * N;
     const int block = 256;
     const int64_t grid = (total + block - 1) / block;
-    hipLaunchKernelGGL(gspl::project_fwd_kernel, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream,
-                       C, N, means, scales, quats, viewmats, Ks, width, height, tile_size,
-                       scale_modifier, eps2d, near_plane, far_plane, radius_clip,
-                       radii, means2d, depths, conics, compensations, tiles_hit);
+#define GSPL_PROJECT_FWD(CAM)                                                                                              \
+    hipLaunchKernelGGL(gspl::project_fwd_kernel<CAM>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, C, N, means,   \
+                       scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier, eps2d, near_plane, far_plane,   \
+                       radius_clip, radii, means2d, depths, conics, compensations, tiles_hit)
+    if (camera_model == GSPL_CAMERA_ORTHO) GSPL_PROJECT_FWD(gspl::GSPL_CAM_ORTHO_);
+    else if (camera_model == GSPL_CAMERA_FISHEYE) GSPL_PROJECT_FWD(gspl::GSPL_CAM_FISHEYE_);
+    else GSPL_PROJECT_FWD(gspl::GSPL_CAM_PINHOLE_);
+#undef GSPL_PROJECT_FWD
     return gspl::check_launch("project_fwd");
 }
 
 extern "C" int gspl_project_bwd(int C, int N,
                                 const float* means, const float* scales, const float* quats,
                                 const float* viewmats, const float* Ks,
-                                int width, int height, float scale_modifier, float eps2d,
+                                int width, int height, float scale_modifier, float eps2d, int camera_model,
                                 const int32_t* radii,
                                 const float* v_means2d, int v_means2d_stride, const float* v_depths,
                                 const float* v_conics, int v_conics_stride,
                                 const float* v_compensations,
                                 float* v_means, float* v_scales, float* v_quats, void* stream) {
     if (C < 0 || N < 0 || width <= 0 || height <= 0) return gspl::fail_arg("project_bwd: bad sizes");
+    if (camera_model < GSPL_CAMERA_PINHOLE || camera_model > GSPL_CAMERA_FISHEYE) return gspl::fail_arg("project_bwd: unknown camera model");
     if ((int64_t)C * N == 0) return GSPL_OK;
     if (!means || !scales || !quats || !viewmats || !Ks || !radii || !v_means2d || !v_conics ||
         !v_means || !v_scales || !v_quats)
@@ -240,14 +272,15 @@ extern "C" int gspl_project_bwd(int C, int N,
     const int64_t grid = (total + block - 1) / block;
     const int s2 = v_means2d_stride > 0 ? v_means2d_stride : 2, s3 = v_conics_stride > 0 ? v_conics_stride : 3;
     if ((s2 != 2 || s3 != 3) && C != 1) return gspl::fail_arg("project_bwd: strided gradients need C == 1");
-    if (C == 1) {
-        hipLaunchKernelGGL(gspl::project_bwd_kernel<false>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream,
-                           C, N, means, scales, quats, viewmats, Ks, width, height, scale_modifier, eps2d, radii,
-                           v_means2d, s2, v_depths, v_conics, s3, v_compensations, v_means, v_scales, v_quats);
-    } else {
-        hipLaunchKernelGGL(gspl::project_bwd_kernel<true>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream,
-                           C, N, means, scales, quats, viewmats, Ks, width, height, scale_modifier, eps2d, radii,
-                           v_means2d, s2, v_depths, v_conics, s3, v_compensations, v_means, v_scales, v_quats);
-    }
+#define GSPL_PROJECT_BWD(ATOMIC, CAM)                                                                                      \
+    hipLaunchKernelGGL((gspl::project_bwd_kernel<ATOMIC, CAM>), dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, C, N, \
+                       means, scales, quats, viewmats, Ks, width, height, scale_modifier, eps2d, radii, v_means2d, s2,        \
+                       v_depths, v_conics, s3, v_compensations, v_means, v_scales, v_quats)
+#define GSPL_PROJECT_BWD_CAM(CAM) do { if (C == 1) GSPL_PROJECT_BWD(false, CAM); else GSPL_PROJECT_BWD(true, CAM); } while (0)
+    if (camera_model == GSPL_CAMERA_ORTHO) GSPL_PROJECT_BWD_CAM(gspl::GSPL_CAM_ORTHO_);
+    else if (camera_model == GSPL_CAMERA_FISHEYE) GSPL_PROJECT_BWD_CAM(gspl::GSPL_CAM_FISHEYE_);
+    else GSPL_PROJECT_BWD_CAM(gspl::GSPL_CAM_PINHOLE_);
+#undef GSPL_PROJECT_BWD_CAM
+#undef GSPL_PROJECT_BWD
     return gspl::check_launch("project_bwd");
 }

@@ -97,7 +97,7 @@ class _ProjectFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)
     def forward(ctx, means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier,
-                eps2d, near_plane, far_plane, radius_clip, calc_compensations, want_tiles):
+                eps2d, near_plane, far_plane, radius_clip, calc_compensations, want_tiles, camera_model=0):
         lib = L.lib()
         means, scales, quats, viewmats, Ks = map(_f32c, (means, scales, quats, viewmats, Ks))
         C, N = viewmats.shape[0], means.shape[0]
@@ -111,10 +111,10 @@ class _ProjectFn(torch.autograd.Function):
         L.call("gspl_project_fwd", 
             C, N, L.ptr(means), L.ptr(scales), L.ptr(quats), L.ptr(viewmats), L.ptr(Ks),
             int(width), int(height), int(tile_size), float(scale_modifier), float(eps2d), float(near_plane),
-            float(far_plane), float(radius_clip),
+            float(far_plane), float(radius_clip), int(camera_model),
             L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(tiles), L.stream())
         ctx.save_for_backward(means, scales, quats, viewmats, Ks, radii)
-        ctx.cfg = (int(width), int(height), float(scale_modifier), float(eps2d), bool(calc_compensations))
+        ctx.cfg = (int(width), int(height), float(scale_modifier), float(eps2d), bool(calc_compensations), int(camera_model))
         ctx.set_materialize_grads(False)      # unused outputs (radii, tiles, often depths) arrive as None, not as zero tensors
         ctx.mark_non_differentiable(radii)
         outs = [radii, means2d, depths, conics]
@@ -129,7 +129,7 @@ class _ProjectFn(torch.autograd.Function):
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, _v_tiles):
         lib = L.lib()
         means, scales, quats, viewmats, Ks, radii = ctx.saved_tensors
-        width, height, scale_modifier, eps2d, calc_comp = ctx.cfg
+        width, height, scale_modifier, eps2d, calc_comp, camera_model = ctx.cfg
         C, N = radii.shape
         dev = means.device
         s2 = s3 = 0
@@ -148,10 +148,10 @@ class _ProjectFn(torch.autograd.Function):
         v_quats = alloc((N, 4), dtype=torch.float32, device=dev)
         L.call("gspl_project_bwd", 
             C, N, L.ptr(means), L.ptr(scales), L.ptr(quats), L.ptr(viewmats), L.ptr(Ks),
-            width, height, scale_modifier, eps2d, L.ptr(radii),
+            width, height, scale_modifier, eps2d, camera_model, L.ptr(radii),
             _raw_ptr(v_means2d), s2, L.ptr(v_depths), _raw_ptr(v_conics), s3, L.ptr(v_comps),
             L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.stream())
-        return (v_means, v_scales, v_quats) + (None,) * 12
+        return (v_means, v_scales, v_quats) + (None,) * 13
 
 
 def fully_fused_projection(
@@ -168,14 +168,14 @@ def fully_fused_projection(
         raise NotImplementedError("covars input is not part of the reference's call sites")
     if packed:
         raise NotImplementedError("packed=True is not used by the reference (always packed=False)")
-    if camera_model != "pinhole":
-        raise NotImplementedError(f"camera_model={camera_model!r}: only the pinhole model is built")
+    if camera_model not in L.CAMERA_MODELS:
+        raise ValueError(f"camera_model={camera_model!r}: one of {sorted(L.CAMERA_MODELS)}")
     assert means.dim() == 2 and means.shape[1] == 3, means.shape
     assert quats.shape == (means.shape[0], 4) and scales.shape == (means.shape[0], 3)
     assert viewmats.dim() == 3 and viewmats.shape[1:] == (4, 4) and Ks.shape == (viewmats.shape[0], 3, 3)
     radii, means2d, depths, conics, comps, _ = _ProjectFn.apply(
         means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier, eps2d, near_plane, far_plane,
-        radius_clip, calc_compensations, False)
+        radius_clip, calc_compensations, False, L.CAMERA_MODELS[camera_model])
     return radii, means2d, depths, conics, (comps if calc_compensations else None)
 
 
@@ -228,7 +228,7 @@ def project_gaussians(
         K = _cached_intrinsics(float(fx), float(fy), float(cx), float(cy), dev)
     radii, xys, depths, conics, comps, tiles = _ProjectFn.apply(
         means3d, scales, quats, vm[None], K[None], img_width, img_height, block_width, glob_scale,
-        filter_2d_kernel_size, clip_thresh, 1e10, 0.0, True, True)
+        filter_2d_kernel_size, clip_thresh, 1e10, 0.0, True, True, L.GSPL_CAMERA_PINHOLE)
     # views, not selects: their backward is a view of the incoming gradient (select_backward allocates zeros + copies)
     return xys.view(N, 2), depths.view(N), radii.view(N), conics.view(N, 3), comps.view(N), tiles.view(N), None
 

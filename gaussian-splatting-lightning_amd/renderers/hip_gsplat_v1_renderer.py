@@ -4,7 +4,7 @@ dataclass, `GSplatV1RendererModule`, and the static `GSplatV1` helper class that
 distributed renderer and several research renderers call (`preprocess_camera`, `project`, `isect_encode`,
 `rasterize`).  All native calls go to the HIP ops.
 
-Not built (raise NotImplementedError, §8f "next"): fisheye/ortho camera models.
+`runtime_options.camera_model` ("pinhole" | "ortho" | "fisheye") is forwarded to the projection (csrc/projection.hip).
 """
 from __future__ import annotations
 

@@ -46,6 +46,9 @@ enum {
 
 enum { GSPL_MODE_GSPLAT = 0, GSPL_MODE_INRIA = 1 };
 
+/* camera model of gspl_project_fwd/bwd (gsplat v1 `camera_model`, reference option internal/renderers/gsplat_v1_renderer.py:50) */
+enum { GSPL_CAMERA_PINHOLE = 0, GSPL_CAMERA_ORTHO = 1, GSPL_CAMERA_FISHEYE = 2 };
+
 /* image memory layout of composite outputs / incoming image gradients */
 enum { GSPL_LAYOUT_HWC = 0, GSPL_LAYOUT_CHW = 1 };
 
@@ -65,13 +68,18 @@ const char* gspl_last_error(void);
  *    Outputs (all [C,N,...]): radii i32 (0 = culled), means2d [.,2], depths, conics [.,3],
  *    compensations (nullable), tiles_hit i32 (nullable; v0 `num_tiles_hit`).
  *    Culled Gaussians get zeros in every output (gaussian_projection.py:127-136).
+ *    camera_model: GSPL_CAMERA_PINHOLE is the in-tree Python above (1.3 tan(fov) clamp of the Jacobian's x/z, y/z).
+ *    GSPL_CAMERA_ORTHO / GSPL_CAMERA_FISHEYE (the `camera_model` option the reference passes through,
+ *    gsplat_v1_renderer.py:50,154) restate the published gsplat models — ortho: mean2d = (fx x + cx, fy y + cy),
+ *    J = diag(fx, fy) | 0; fisheye (equidistant): mean2d = f * (x, y) * atan2(r, z) / r + c with the closed-form Jacobian —
+ *    without the clamp; everything after the 2D covariance (low-pass, radius, rect, culling) is shared.
  * ---------------------------------------------------------------------------------------- */
 int gspl_project_fwd(int C, int N,
                      const float* means, const float* scales, const float* quats,
                      const float* viewmats, const float* Ks,
                      int width, int height, int tile_size,
                      float scale_modifier, float eps2d, float near_plane, float far_plane,
-                     float radius_clip,
+                     float radius_clip, int camera_model,
                      int32_t* radii, float* means2d, float* depths, float* conics,
                      float* compensations /*nullable*/, int32_t* tiles_hit /*nullable*/,
                      void* stream);
@@ -85,7 +93,7 @@ int gspl_project_bwd(int C, int N,
                      const float* means, const float* scales, const float* quats,
                      const float* viewmats, const float* Ks,
                      int width, int height,
-                     float scale_modifier, float eps2d,
+                     float scale_modifier, float eps2d, int camera_model,
                      const int32_t* radii,
                      const float* v_means2d, int v_means2d_stride /* floats per row; 0 = dense [.,2] */,
                      const float* v_depths /*nullable = 0*/,

@@ -129,6 +129,40 @@ def test_hip_gsplat_renderers_contract_and_parity(which):
         assert not bool((acc & ~out["visibility_filter"]).any()) and 0 < int(acc.sum()) < int(out["visibility_filter"].sum())
 
 
+@pytest.mark.parametrize("model_name", ["fisheye", "ortho"])
+def test_v1_renderer_runtime_camera_model(model_name):
+    """The viewer's camera-model dropdown (gsplat_v1_renderer.py:653-661) sets `runtime_options.camera_model`; the projection
+    then runs the fisheye / ortho model.  Render and every parameter gradient against the oracle pipeline with the same model."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatV1Renderer
+    W, H = 272, 176
+    means, scales, quats, opac, shs = O.synthetic_scene(6000, seed=33)
+    if model_name == "fisheye":
+        scales = scales * 4
+        cam = O.synthetic_camera(W, H, 110.0, 108.0, distance=2.5)        # ~100 degrees across the image
+    else:
+        scales = scales * 4
+        cam = O.synthetic_camera(W, H, 70.0, 69.0, distance=4.0)          # 70 pixels per world unit
+    params = (means, scales, quats, opac, shs)
+    g = torch.Generator().manual_seed(3)
+    wimg = torch.randn(3, H, W, generator=g)
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    renderer = HipGSplatV1Renderer().instantiate()
+    renderer.runtime_options.camera_model = model_name
+    out = renderer(FakeCamera(cam, DEV), model, bg.to(DEV))
+    assert int(out["visibility_filter"].sum()) > 3000
+    (out["render"] * wimg.to(DEV)).sum().backward()
+    dl = [t.double().requires_grad_(True) for t in params]
+    r = O.render_gsplat(*dl, 3, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W, H, bg.double(),
+                        cam["camera_center"].double(), camera_model=model_name)
+    (r["render"] * wimg.double()).sum().backward()
+    _check(model, dl, out["render"], r)
+    # and it is not the pinhole image
+    pin = HipGSplatV1Renderer().instantiate()(FakeCamera(cam, DEV), FakeGaussianModel(*[p.to(DEV) for p in params]), bg.to(DEV))
+    assert float((pin["render"] - out["render"]).abs().max()) > 0.05
+
+
 def test_hip_gsplat_renderer_depth_types():
     import gspl_amd  # noqa: F401
     from gspl_amd.renderers import HipGSplatRenderer, HipGSplatV1Renderer
