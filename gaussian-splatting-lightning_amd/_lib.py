@@ -16,8 +16,9 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 25
+ABI_VERSION = 26
 
+GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
 CAMERA_MODELS = {"pinhole": 0, "ortho": 1, "fisheye": 2}
 GSPL_MODE_GSPLAT = 0
@@ -63,6 +64,11 @@ _SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int,
                                  _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "gspl_records_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gspl_records_pack_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gspl_records_pack_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_records_unpack_fwd": (c_int, [ctypes.c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_records_unpack_bwd": (c_int, [ctypes.c_int64, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
     "gspl_sh_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),
     "gspl_sh_fwd_batched": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),

@@ -16,7 +16,7 @@ All arithmetic happens in libgspl_hip.so; nothing here falls back to PyTorch mat
 from __future__ import annotations
 
 import os
-from typing import NamedTuple, Optional, Tuple
+from typing import NamedTuple, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -671,6 +671,168 @@ class _PendingBins:
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
     __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "spans", "offsets", "tile_w", "tile_h",
                  "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes", "big_list", "depths", "count")
+
+
+# =============================================================================================
+# visible-splat records of the Gaussian-sharded renderer (csrc/records.hip)
+# =============================================================================================
+def _batched(ts: Sequence[Tensor]) -> Tensor:
+    """[C, ...] tensor of C per-camera tensors: the base buffer itself when they are its consecutive slices (what
+    `batch_project` hands out), a stacked copy otherwise."""
+    t0 = ts[0]
+    base = t0._base
+    if base is not None and base.is_contiguous() and base.dim() == t0.dim() + 1 and base.shape[0] == len(ts) and base.shape[1:] == t0.shape:
+        step = t0.numel() * t0.element_size()
+        if all(t._base is base and t.is_contiguous() and t.data_ptr() == base.data_ptr() + i * step for i, t in enumerate(ts)):
+            return base
+    return torch.stack([t.contiguous() for t in ts])
+
+
+class _UnbindFn(torch.autograd.Function):
+    """`t.unbind(0)` whose backward hands the batched gradient through when the per-slice gradients already ARE consecutive
+    slices of one buffer (what `_PackRecordsFn.backward` returns) — `t[i]` costs a zero fill plus a copy per slice there."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.shape, ctx.like = t.shape, (t.dtype, t.device)
+        ctx.set_materialize_grads(False)
+        return t.unbind(0)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return None
+        if any(g is None for g in grads):
+            dt, dev = ctx.like
+            grads = [g if g is not None else torch.zeros(ctx.shape[1:], dtype=dt, device=dev) for g in grads]
+        return _batched(grads)
+
+
+def unbind_cameras(t: Tensor):
+    """Per-camera views of a [C, ...] tensor (see `_UnbindFn`)."""
+    return _UnbindFn.apply(t) if t.requires_grad else t.unbind(0)
+
+
+_PINNED_ENDS: dict = {}
+
+
+class _PackRecordsFn(torch.autograd.Function):
+    """(opacities [N], C x (radii, means2d, depths, conics, compensations, rgbs)) -> records [M, 12] grouped by camera,
+    ends [C] (CPU int64: one past each camera's last row)."""
+
+    @staticmethod
+    @_guarded(3)
+    def forward(ctx, C, has_comp, opacities, *flat):
+        lib = L.lib()
+        groups = [flat[k * C:(k + 1) * C] for k in range(6)]
+        radii = _batched(groups[0])
+        if radii.dtype != torch.int32:
+            radii = radii.to(torch.int32)
+        means2d, depths, conics = (_f32c(_batched(g)) for g in groups[1:4])
+        comps = _f32c(_batched(groups[4])) if has_comp else None
+        rgbs = _f32c(_batched(groups[5]))
+        opac = _f32c(opacities.detach()).reshape(-1)
+        N, dev = radii.shape[1], radii.device
+        assert opac.shape[0] == N and means2d.shape == (C, N, 2) and conics.shape == (C, N, 3) and rgbs.shape == (C, N, 3)
+        records = torch.empty((max(C * N, 1), L.GSPL_RECORD_FLOATS), dtype=torch.float32, device=dev)
+        slots = torch.empty((C, N), dtype=torch.int32, device=dev)
+        ends = torch.empty((C,), dtype=torch.int64, device=dev)
+        pool = _PINNED_ENDS.setdefault(C, [])
+        host_ends = pool.pop() if pool else torch.empty((C,), dtype=torch.int64).pin_memory()
+        ws_bytes = lib.gspl_records_workspace_bytes(C, N)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        L.call("gspl_records_pack_fwd", C, N, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(opac), L.ptr(rgbs),
+               L.ptr(records), L.ptr(slots), L.ptr(ends), host_ends.data_ptr(), L.ptr(ws), ws_bytes, L.stream())
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()                 # the split sizes of the all-to-all are needed on the host (as in the reference)
+        ends_cpu = host_ends.clone() if C * N > 0 else torch.zeros((C,), dtype=torch.int64)
+        pool.append(host_ends)
+        total = int(ends_cpu[-1]) if C > 0 else 0
+        ctx.save_for_backward(slots)
+        ctx.cfg = (C, N, has_comp, tuple(opacities.shape))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(ends_cpu)
+        return records[:total], ends_cpu
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, v_records, _v_ends):
+        (slots,) = ctx.saved_tensors
+        C, N, has_comp, opac_shape = ctx.cfg
+        dev = slots.device
+        if v_records is None:
+            return (None,) * (3 + 6 * C)
+        v_records = _f32c(v_records)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        v_means2d, v_depths, v_conics, v_rgbs, v_opac = e(C, N, 2), e(C, N), e(C, N, 3), e(C, N, 3), e(N)
+        v_comps = e(C, N) if has_comp else None
+        L.call("gspl_records_pack_bwd", C, N, L.ptr(slots), L.ptr(v_records), L.ptr(v_means2d), L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comps),
+               L.ptr(v_opac), L.ptr(v_rgbs), L.stream())
+        per_cam = lambda t: [t[c] for c in range(C)] if t is not None else [None] * C
+        return (None, None, v_opac.reshape(opac_shape), *([None] * C), *per_cam(v_means2d), *per_cam(v_depths), *per_cam(v_conics),
+                *per_cam(v_comps), *per_cam(v_rgbs))
+
+
+def pack_visible_records(projection_results_list, rgb_list, opacities: Tensor):
+    """Records of every (camera, local splat) with radius > 0, grouped by camera (csrc/records.hip): what the reference builds
+    with a concat + boolean-mask selection per camera (gsplat_distributed_renderer.py:313-360).
+    projection_results_list[c] = (radii, means2d, depths, conics, compensations | None, ...).  Returns (records [M,12],
+    counts per camera as a python list)."""
+    C = len(projection_results_list)
+    has_comp = projection_results_list[0][4] is not None
+    cols = [[r[k] for r in projection_results_list] for k in range(5)]
+    if not has_comp:
+        cols[4] = [r[2] for r in projection_results_list]      # placeholder tensors (ignored)
+    records, ends = _PackRecordsFn.apply(C, has_comp, opacities, *cols[0], *cols[1], *cols[2], *cols[3], *cols[4], *rgb_list)
+    e = [0] + [int(v) for v in ends.tolist()]
+    return records, [e[i + 1] - e[i] for i in range(C)]
+
+
+class _UnpackRecordsFn(torch.autograd.Function):
+    @staticmethod
+    @_guarded(1)
+    def forward(ctx, records, fold_compensation):
+        records = _f32c(records)
+        M, dev = records.shape[0], records.device
+        radii = torch.empty((M,), dtype=torch.int32, device=dev)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        means2d, depths, conics, opac, rgbs = e(M, 2), e(M), e(M, 3), e(M), e(M, 3)
+        L.call("gspl_records_unpack_fwd", M, int(bool(fold_compensation)), L.ptr(records), L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics),
+               L.ptr(opac), L.ptr(rgbs), L.stream())
+        ctx.save_for_backward(records)
+        ctx.fold = int(bool(fold_compensation))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, opac, rgbs
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_opac, v_rgbs):
+        (records,) = ctx.saved_tensors
+        M = records.shape[0]
+        v_means2d, s2 = _rows(v_means2d, 2)
+        v_conics, s3 = _rows(v_conics, 3)
+        v_rgbs, sc = _rows(v_rgbs, 3)
+        s1 = 0
+        if v_opac is not None:
+            v_opac = v_opac.float() if v_opac.dtype != torch.float32 else v_opac
+            flat = v_opac.reshape(-1) if v_opac.is_contiguous() else v_opac
+            if flat.dim() == 1:
+                v_opac, s1 = flat, (0 if flat.is_contiguous() else flat.stride(0))
+            else:
+                v_opac, s1 = v_opac.contiguous().reshape(-1), 0
+        v_depths = _f32c(v_depths)
+        v_records = torch.empty_like(records)
+        L.call("gspl_records_unpack_bwd", M, ctx.fold, L.ptr(records), _raw_ptr(v_means2d), s2, L.ptr(v_depths), _raw_ptr(v_conics), s3,
+               _raw_ptr(v_opac), s1, _raw_ptr(v_rgbs), sc, L.ptr(v_records), L.stream())
+        return v_records, None
+
+
+def unpack_visible_records(records: Tensor, fold_compensation: bool):
+    """records [M,12] -> radii [M] i32, means2d [M,2], depths [M], conics [M,3], opacities [M] (x compensation when
+    `fold_compensation`), rgbs [M,3] — the `torch.split` (+ the anti-aliasing product) of the reference's receiving side."""
+    return _UnpackRecordsFn.apply(records, fold_compensation)
 
 
 _PINNED_WORDS: list = []      # free list of pinned int64 words for the count read-back

@@ -128,19 +128,34 @@ class HipGSplatDistributedRendererImpl(Renderer):
     def batch_project(self, cameras, pc, scales, scaling_modifier):
         """ONE projection launch and ONE SH launch for all W cameras (reference :252-311 loops over the cameras for the SH
         colours; here the coefficient rows are read once)."""
-        viewmats = torch.stack([c.world_to_camera.T for c in cameras])
-        Ks = torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, scales.device) for c in cameras])
+        viewmats, Ks, centers = self._camera_batch(cameras, scales.device)
         W, H = camera_hw(cameras[0])
         if scaling_modifier != 1.:
             scales = scales * scaling_modifier
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(
             pc.get_means(), None, pc.get_rotations(), scales, viewmats=viewmats, Ks=Ks, width=W, height=H,
             eps2d=self.config.filter_2d_kernel_size, calc_compensations=True, packed=False)
-        centers = torch.stack([c.camera_center for c in cameras])
         rgbs = ops.sh_view_colors_batched(pc.active_sh_degree, pc.get_xyz, centers, pc.get_shs_dc(), pc.get_shs_rest(), radii)
         vis = radii > 0
-        results = [(radii[i], means2d[i], depths[i], conics[i], comps[i], vis[i]) for i in range(len(cameras))]
-        return results, [rgbs[i] for i in range(len(cameras))]
+        # per-camera views whose backward passes a batched gradient through (no zero fill + copy per slice)
+        m2, dep, con, cmp_, col = (ops.unbind_cameras(t) for t in (means2d, depths, conics, comps, rgbs))
+        results = [(radii[i], m2[i], dep[i], con[i], cmp_[i], vis[i]) for i in range(len(cameras))]
+        return results, list(col)
+
+    def _camera_batch(self, cameras, device):
+        """Stacked view matrices [W,4,4], intrinsics [W,3,3] and centres [W,3] of a camera set, built once per set: a training
+        run cycles through a fixed set of (camera, camera, ...) tuples, and the three stacks cost a dozen small launches."""
+        k = lambda v: (v.data_ptr(), v._version) if isinstance(v, torch.Tensor) else float(v)      # no device read-back for tensors
+        key = tuple((k(c.world_to_camera), k(c.camera_center), k(c.fx), k(c.fy), k(c.cx), k(c.cy)) for c in cameras) + (str(device),)
+        cache = self.__dict__.setdefault("_camera_batches", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 4096:
+                cache.clear()
+            hit = cache[key] = (torch.stack([c.world_to_camera.T for c in cameras]).contiguous(),
+                                torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, device) for c in cameras]).contiguous(),
+                                torch.stack([c.camera_center for c in cameras]).contiguous())
+        return hit
 
     def non_batch_project(self, cameras, pc, scales, scaling_modifier):
         """Cameras of different sizes: one projection and one SH launch per camera (reference :238-250)."""
@@ -175,16 +190,26 @@ class HipGSplatDistributedRendererImpl(Renderer):
                     r[1].retain_grad()              # per-camera xys: what the distributed density controller reads
 
             with self._span("rasterizer_required_data_all2all"):
-                records = [D.pack_visible(r[0], r[1], r[2], r[3], r[4], opacities, rgb, r[5])
-                           for r, rgb in zip(projection_results_list, rgb_list)]
-                if len(cameras) > 1:
-                    received, _ = D.exchange_visible_splats(records, self.group)
+                if opacities.is_cuda:
+                    # one pack kernel for all cameras, one all-to-all, one unpack kernel (csrc/records.hip)
+                    records, send_counts = ops.pack_visible_records(projection_results_list, rgb_list, opacities)
+                    if len(cameras) > 1:
+                        recv_counts = D.exchange_counts(send_counts, records.device, self.group)
+                        records = D.all_to_all_rows(records, send_counts, recv_counts, self.group)
+                    radii, means2d, depths, conics, opac, rgbs = ops.unpack_visible_records(records, self.config.anti_aliased)
+                    opac = opac.unsqueeze(0)
                 else:
-                    received = records[0]
-                radii, means2d, depths, conics, comps, opac, rgbs = D.unpack_records(received)
-            if self.config.anti_aliased:
-                opac = opac * comps.unsqueeze(-1)
-            opac = opac.squeeze(-1).unsqueeze(0)
+                    # host tensors (the CPU tests of the exchange logic): the same steps as torch ops
+                    records = [D.pack_visible(r[0], r[1], r[2], r[3], r[4], opacities, rgb, r[5])
+                               for r, rgb in zip(projection_results_list, rgb_list)]
+                    if len(cameras) > 1:
+                        received, _ = D.exchange_visible_splats(records, self.group)
+                    else:
+                        received = records[0]
+                    radii, means2d, depths, conics, comps, opac, rgbs = D.unpack_records(received)
+                    if self.config.anti_aliased:
+                        opac = opac * comps.unsqueeze(-1)
+                    opac = opac.squeeze(-1).unsqueeze(0)
 
             local = cameras[rank]
             W, H = camera_hw(local)

@@ -403,6 +403,35 @@ int gspl_profile_enable(int on);
 int gspl_profile_read(int which, int* count, float* total_ms);
 
 /* ------------------------------------------------------------------------------------------
+ * 6c. Visible-splat records of the Gaussian-sharded multi-GPU renderer: pack / unpack, forward and backward.
+ *    Replaces the per-camera `torch.concat` + boolean-mask selection before, and the `torch.split` after, the all-to-all of
+ *    internal/renderers/gsplat_distributed_renderer.py:313-414.  Record = 12 fp32 (48 B):
+ *        [x, y, depth, conic a, b, c, compensation, opacity, r, g, b, radius (int32 bits)]
+ *    pack: every (camera, local splat) with radius > 0 -> one record, grouped by camera (= destination rank), splat order kept.
+ *      records: room for C*N rows; slots [C,N] i32 = row of the pair's record or -1 (the backward's route); ends [C] i64 =
+ *      one past each camera's last row (device), host_ends (nullable) the same in pinned host memory, stored by the kernel.
+ *    pack_bwd: writes EVERY row of every gradient tensor (zeros where invisible); v_opacities [N] summed over the cameras.
+ *    unpack: received records -> per-quantity tensors; fold_compensation: opacities = opacity x compensation (anti-aliased
+ *      mode), with the product rule applied by unpack_bwd.  Strides (floats per row, 0 = dense) let unpack_bwd read the columns
+ *      of gspl_composite_bwd_packed's row buffer in place.
+ * ---------------------------------------------------------------------------------------- */
+#define GSPL_RECORD_FLOATS 12
+size_t gspl_records_workspace_bytes(int C, int N);
+int gspl_records_pack_fwd(int C, int N, const int32_t* radii, const float* means2d, const float* depths, const float* conics,
+                          const float* compensations /*nullable = 1*/, const float* opacities /*[N]*/, const float* colors /*[C,N,3]*/,
+                          float* records, int32_t* slots, int64_t* ends, int64_t* host_ends /*nullable*/,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int gspl_records_pack_bwd(int C, int N, const int32_t* slots, const float* v_records,
+                          float* v_means2d, float* v_depths, float* v_conics, float* v_compensations /*nullable*/, float* v_opacities,
+                          float* v_colors, void* stream);
+int gspl_records_unpack_fwd(int64_t M, int fold_compensation, const float* records, int32_t* radii, float* means2d, float* depths,
+                            float* conics, float* opacities, float* colors, void* stream);
+int gspl_records_unpack_bwd(int64_t M, int fold_compensation, const float* records,
+                            const float* v_means2d /*nullable = 0*/, int v_means2d_stride, const float* v_depths /*nullable*/,
+                            const float* v_conics /*nullable*/, int v_conics_stride, const float* v_opacities /*nullable*/, int v_opacities_stride,
+                            const float* v_colors /*nullable*/, int v_colors_stride, float* v_records, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 7. Mean squared distance to the 3 nearest neighbours ("next" row SURVEY.md §8f rank 1).
  *    Replaces `simple_knn._C.distCUDA2` at its one call site, the initial scales of
  *    `VanillaGaussianModel.setup_from_pcd` (internal/models/vanilla_gaussian.py:122-125):
