@@ -625,6 +625,39 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
 static constexpr int B2CHUNK = GSPL_BWD2_CHUNK;   // splats staged per round
 static constexpr int P2_SLOTS = 4;                // splats per phase-2 batch (16 lanes each)
 
+#ifdef GSPL_BWD_LPT
+// EXPERIMENT (A/B builds): workgroups take the tiles longest list first, so that the heavy tiles of the image centre do not start
+// in the middle of the launch and define its end.
+__device__ int g_tile_order[1 << 16];
+__global__ __launch_bounds__(1024) void tile_order_kernel(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects) {
+    __shared__ int s_max;
+    __shared__ int s_hist[256], s_cur[256];
+    const int t = threadIdx.x;
+    if (t == 0) s_max = 0;
+    if (t < 256) s_hist[t] = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int k = t; k < n_tiles; k += 1024) {
+        const int len = (int)((k + 1 < n_tiles ? (int64_t)offsets[k + 1] : n_isects) - offsets[k]);
+        mx = max(mx, len);
+    }
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = 256.f / (float)(s_max + 1);
+    for (int k = t; k < n_tiles; k += 1024) {
+        const int len = (int)((k + 1 < n_tiles ? (int64_t)offsets[k + 1] : n_isects) - offsets[k]);
+        atomicAdd(&s_hist[255 - min(255, (int)((float)len * scale))], 1);
+    }
+    __syncthreads();
+    if (t == 0) { int run = 0; for (int b = 0; b < 256; ++b) { s_cur[b] = run; run += s_hist[b]; } }
+    __syncthreads();
+    for (int k = t; k < n_tiles; k += 1024) {
+        const int len = (int)((k + 1 < n_tiles ? (int64_t)offsets[k + 1] : n_isects) - offsets[k]);
+        g_tile_order[atomicAdd(&s_cur[255 - min(255, (int)((float)len * scale))], 1)] = k;
+    }
+}
+#endif
+
 template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
 __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
@@ -651,7 +684,11 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column 0..15][channel][row]
     __shared__ int s_last;
 
+#ifdef GSPL_BWD_LPT
+    const int tile = g_tile_order[blockIdx.x];
+#else
     const int tile = xcd_remap(blockIdx.x, n_tiles);
+#endif
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int tx = (tile % tile_w) * TILE, ty = (tile / tile_w) * TILE;
     const int pxA = tx + (l & 7), pxB = pxA + 8;
@@ -1298,6 +1335,10 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
     return check_launch("composite_bwd");
 #endif
 #ifndef GSPL_BWD_V2      // default: the two-pixels-per-lane kernel; -DGSPL_BWD_V2 selects the one-pixel-per-lane kernel (A/B builds)
+#ifdef GSPL_BWD_LPT
+    if (n_tiles > (1 << 16)) return fail_arg("composite_bwd (LPT experiment): more than 65536 tiles");
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, offsets, n_tiles, n_isects);
+#endif
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
