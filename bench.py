@@ -35,6 +35,9 @@ Extra objects on the JSON line:
                 timed as well (`reference_projection_sh`, kind "reference").  `--cpu-baseline-only` runs just this leg
                 (no GPU needed).
 """
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL / tensor sharing need on this driver
+
 import argparse
 import json
 import os

@@ -11,8 +11,8 @@
 //
 // Roofline: HBM-bound.  Emit: 16 B read per visible Gaussian + 12 B written per intersection.
 // Sort: 12 B x I x 2 x ceil(bits/8) with bits = 32 + ceil(log2(tiles)).
-// Scans and sorts are the in-tree one-sweep kernels of sort.hip (gspl_sort.h) on every path and at every size; only the
-// significant key bits are sorted.
+// Scans and sorts are the in-tree kernels of sort.hip (gspl_sort.h: count -> scatter passes, block-sum scans; no workgroup
+// waits for another) on every path and at every size; only the significant key bits are sorted.
 #include <cstring>
 #include <cstdlib>
 #include "gspl_device.h"

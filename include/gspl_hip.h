@@ -162,7 +162,7 @@ int gspl_sh_bwd_batched(int C, int N, int degree, int n_coeffs,
  *    to internal/utils/gaussian_projection.py:159-208: key = (tile_id << 32) | bits(depth),
  *    tile_id row-major, value = Gaussian index.  Single camera per call.
  *
- *    Step a: per-Gaussian tile counts + inclusive prefix sum (i64, one chained-look-back launch).  Host reads cum[N-1].
+ *    Step a: per-Gaussian tile counts + inclusive prefix sum (i64; block sums, scan of the sums, per-block scan).  Host reads cum[N-1].
  *    Step b: emit keys, sort them (stable LSD radix, so equal-depth ties keep Gaussian order).
  *    Step c: offsets[t] = first sorted index whose tile id is >= t   (t in [0, tiles)).
  *    gspl_isect_workspace_bytes gives the scratch size for steps a and b.
@@ -497,9 +497,10 @@ int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host a
 
 /* ------------------------------------------------------------------------------------------
  * 10. Stable LSD radix sort of the binning stage, exported for the parity tests.
- *    The depth sort inside gspl_bin_count (depth keys + splat ids, u32 pairs, prepared by the key pass
- *    itself) runs on this one-sweep sort; the u64 keys-only entry point is the same kernel at the record
- *    width of the tile sort (gspl_bin_sort runs it with a last pass that writes ids + per-tile counts).  Both stand in for the
+ *    The depth sort inside gspl_bin_count (depth keys + splat ids, u32 pairs, first pass counted by the key pass
+ *    itself) runs on this sort (csrc/sort.hip: count -> scatter per pass, no inter-workgroup waiting); the u64 keys-only entry
+ *    point is the same kernels at the record width of the tile sort (gspl_bin_sort runs them with a last pass that writes
+ *    ids + per-tile counts).  Both stand in for the
  *    cub::DeviceRadixSort::SortPairs calls of the reference's native rasterizers (gsplat `isect_tiles`
  *    behind gsplat_v1_renderer.py:524-556, the Inria rasterizer behind vanilla_renderer.py:111): stable,
  *    ascending on key bits [begin_bit, end_bit); at most 32 selected bits (4 passes of <= 8 bits), at most

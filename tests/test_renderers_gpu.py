@@ -215,8 +215,8 @@ def test_distributed_renderer_world1_matches_v1():
 
 def test_concurrent_streams_are_reentrant():
     """The viewer situation (SURVEY §8b threads/streams): several host threads, each on its own stream, render concurrently
-    under no_grad.  Every frame must equal the single-thread frame bit for bit (scratch is per call; the look-back sort and
-    scan kernels of concurrent frames share the device)."""
+    under no_grad.  Every frame must equal the single-thread frame bit for bit (scratch is per call; the sort and scan kernels of
+    concurrent frames share the device and never wait for one another)."""
     import threading
     import gspl_amd  # noqa: F401
     from gspl_amd import ops, synthetic
