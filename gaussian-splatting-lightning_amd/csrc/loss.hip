@@ -52,8 +52,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
 // v_pk_fma_f32 and only E[xy] is a scalar chain: 33 instead of 55 instructions per output and pass.  Horizontal results
 // are stored transposed ([column][row]) so that the vertical pass reads its 14 rows the same way.
 typedef float lv2 __attribute__((ext_vector_type(2)));
-static constexpr int LPS = 44;           // padded patch row (pixels): segments of 4 outputs read 16 pixels
-static constexpr int LRS = 28;           // padded column of the transposed horizontal results (26 rows + 2)
+// LDS strides, chosen with a bank-conflict model of the access patterns below (64 banks for 8/16-byte accesses, the b128 lane
+// groups of MI355X_MICROARCH.md; horizontal threads mapped row-fastest): LDS cycles per workgroup 1040 -> 524 (forward),
+// 956 -> 512 (backward) against 384 / 352 conflict-free.  The previous strides (44 / 28, segment-fastest mapping) made 70 % of
+// the LDS-active cycles conflicts (rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+static constexpr int LPS = 46;           // padded patch row of (x, y) pairs: segments of 4 outputs read 16 pixels (<= column 43)
+static constexpr int LPSC = 44;          // padded patch row of the scalar plane of the backward (16-byte aligned rows)
+static constexpr int LRS = 30;           // padded column of the transposed horizontal pair results (26 rows used)
+static constexpr int LRSC = 28;          // ... of the transposed scalar results
 static constexpr int LHSEG = LTX / 4;    // horizontal pass: segments of 4 columns per patch row
 static constexpr int LVSEG = LTY / 4;    // vertical pass: segments of 4 rows per column
 
@@ -87,48 +93,78 @@ __device__ __forceinline__ void load16(const lv2* p, lv2 (&v)[16]) {       // 14
     for (int i = 0; i < 8; ++i) { const float4 t = q[i]; v[2 * i] = (lv2){t.x, t.y}; v[2 * i + 1] = (lv2){t.z, t.w}; }
 }
 
+// Workgroup -> tile.  The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md): each XCD gets ONE contiguous
+// eighth of the (plane, row, column) tile sequence and walks it in order, so that the tiles whose halos overlap (left / right
+// neighbours: the same 128-byte lines; up / down: 10 of 26 patch rows) are served by the same L2 shortly after one another.
+// With the plain 3-D grid neighbouring tiles sit on different XCDs and every XCD's L2 fetches the shared lines again.
+// Returns false for the padding workgroups of the last eighth.
+__device__ __forceinline__ bool loss_tile(int tiles_x, int tiles_y, int planes, int& tx, int& ty, int& plane, size_t& tile) {
+    const int n = tiles_x * tiles_y * planes, per = (n + 7) / 8;
+    const int b = blockIdx.x;
+    const int t = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || t >= n) return false;
+    plane = t / (tiles_x * tiles_y);
+    const int rem = t - plane * (tiles_x * tiles_y);
+    ty = rem / tiles_x;
+    tx = rem - ty * tiles_x;
+    tile = (size_t)t;
+    return true;
+}
+
 // partials[(plane * tiles + tile) * 2 + {0,1}] = tile sums of |x - y| and of the SSIM map
 template <bool TRAIN>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(
-    int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
+    int planes, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
     float* __restrict__ dm_dmu1, float* __restrict__ dm_ds1, float* __restrict__ dm_ds12, float* __restrict__ partials) {
     // LDS: the input patch, then (after every thread has its inputs in registers) the transposed horizontal results on
     // top of it — 18 KB per workgroup instead of 27, i.e. 8 instead of 5 workgroups per CU
     constexpr int PATCH_BYTES = LPY * LPS * (int)sizeof(lv2);
-    constexpr int HRES_BYTES = LTX * LRS * (2 * (int)sizeof(lv2) + (int)sizeof(float));
+    constexpr int HRES_BYTES = LTX * (LRS * 2 * (int)sizeof(lv2) + LRSC * (int)sizeof(float));
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES > HRES_BYTES ? PATCH_BYTES : HRES_BYTES];
     lv2 (*s_p)[LPS] = reinterpret_cast<lv2 (*)[LPS]>(s_raw);                                      // (x, y)
     lv2 (*s_hm)[LRS] = reinterpret_cast<lv2 (*)[LRS]>(s_raw);                                     // [column][row] (mu1, mu2)
     lv2 (*s_hq)[LRS] = reinterpret_cast<lv2 (*)[LRS]>(s_raw + LTX * LRS * sizeof(lv2));           // (E[x^2], E[y^2])
-    float (*s_hc)[LRS] = reinterpret_cast<float (*)[LRS]>(s_raw + 2 * LTX * LRS * sizeof(lv2));   // E[xy]
+    float (*s_hc)[LRSC] = reinterpret_cast<float (*)[LRSC]>(s_raw + 2 * LTX * LRS * sizeof(lv2)); // E[xy]
     __shared__ float s_red[4];
-    const int plane = blockIdx.z;
-    const int x0 = blockIdx.x * LTX, y0 = blockIdx.y * LTY;
+    int tile_x, tile_y, plane;
+    size_t tile_index;
+    if (!loss_tile((W + LTX - 1) / LTX, (H + LTY - 1) / LTY, planes, tile_x, tile_y, plane, tile_index)) return;
+    const int x0 = tile_x * LTX, y0 = tile_y * LTY;
     const int t = threadIdx.x;
     const float* p1 = img1 + (size_t)plane * H * W;
     const float* p2 = img2 + (size_t)plane * H * W;
     // patch load: all of a thread's global loads are issued before the first LDS store (the rolled loop was a chain of
     // five ~1.5 us round trips per workgroup, which at 5 workgroups per CU bounded the whole kernel)
-    constexpr int NLOAD = (LPY * LPS + 255) / 256;
+    // (thread = one patch column and every fourth patch row: the column's bounds test and address are computed once, a row step is
+    // one add — the linear-index version spent ~25 instructions per load on div/mod by the row stride and five range tests)
+    constexpr int NLOAD = (LPY + 3) / 4;
     lv2 pv[NLOAD];
+    const int pcol = t & 63, prow = t >> 6;
+    {
+        const int gx = x0 + pcol - LH;
+        const bool col_in = pcol < LPX && gx >= 0 && gx < W;
 #pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {
-        const int i = t + k * 256;
-        const int r = i / LPS, c = i - r * LPS;
-        const int gy = y0 + r - LH, gx = x0 + c - LH;
-        const bool in = i < LPY * LPS && c < LPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        pv[k] = in ? (lv2){p1[(size_t)gy * W + gx], p2[(size_t)gy * W + gx]} : (lv2){0.f, 0.f};
+        for (int k = 0; k < NLOAD; ++k) {
+            const int r = prow + 4 * k;
+            const int gy = y0 + r - LH;
+            const bool in = col_in && r < LPY && gy >= 0 && gy < H;
+            const size_t o = (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+            pv[k] = in ? (lv2){p1[o], p2[o]} : (lv2){0.f, 0.f};
+        }
     }
+    if (pcol < LPS) {
 #pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {
-        const int i = t + k * 256;
-        if (i < LPY * LPS) s_p[i / LPS][i % LPS] = pv[k];
+        for (int k = 0; k < NLOAD; ++k) {
+            const int r = prow + 4 * k;
+            if (r < LPY) s_p[r][pcol] = pv[k];
+        }
     }
     __syncthreads();
-    // horizontal pass: 26 rows x 8 segments of 4 columns (208 threads); the L1 term of the segment's own pixels rides along
+    // horizontal pass: 26 rows x 8 segments of 4 columns (208 threads, consecutive lanes = consecutive rows: the transposed
+    // stores below then go to consecutive addresses); the L1 term of the segment's own pixels rides along
     float l1_acc = 0.f, ssim_acc = 0.f;
     const bool hthread = t < LPY * LHSEG;
-    const int hr = t / LHSEG, hc0 = (t % LHSEG) * 4;
+    const int hr = t % LPY, hc0 = (t / LPY) * 4;
     lv2 hv[16];
     if (hthread) {
         load16(&s_p[hr][hc0], hv);
@@ -174,15 +210,17 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
                 const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
                 const float s1 = ee[j].x - mu1_sq, s2 = ee[j].y - mu2_sq, s12 = e12[j] - mu12;
                 const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cd = mu1_sq + mu2_sq + C1, Dd = s1 + s2 + C2;
-                const float m = (A * B) / (Cd * Dd);
+                // v_rcp_f32 (1 ulp) instead of four IEEE divisions (~10 instructions each) per pixel
+                const float inv_c = __builtin_amdgcn_rcpf(Cd), inv_d = __builtin_amdgcn_rcpf(Dd);
+                const float inv_cd = inv_c * inv_d;
+                const float m = (A * B) * inv_cd;
                 ssim_acc += m;
                 if (TRAIN) {
                     // partial derivatives of m w.r.t. (mu1, s1, s12), then the mu1 dependence of s1 = E[x^2] - mu1^2 and
                     // s12 = E[xy] - mu1 mu2 folded into the first, so that the backward only needs dE-type convolutions
-                    const float inv_cd = 1.f / (Cd * Dd);
-                    const float d_s1 = -m / Dd;                         // dm/ds1
+                    const float d_s1 = -m * inv_d;                      // dm/ds1
                     const float d_s12 = 2.f * A * inv_cd;               // dm/ds12
-                    const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * m / Cd - 2.f * mu1 * d_s1 - mu2 * d_s12;
+                    const float d_mu1 = 2.f * mu2 * B * inv_cd - 2.f * mu1 * m * inv_c - 2.f * mu1 * d_s1 - mu2 * d_s12;
                     const size_t o = (size_t)plane * H * W + (size_t)gy * W + gx;
                     dm_dmu1[o] = d_mu1; dm_ds1[o] = d_s1; dm_ds12[o] = d_s12;
                 }
@@ -192,9 +230,8 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(
     const float l1_sum = block_sum_256(l1_acc, s_red);
     const float ssim_sum = block_sum_256(ssim_acc, s_red);
     if (t == 0) {
-        const size_t tile = ((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partials[tile * 2 + 0] = l1_sum;
-        partials[tile * 2 + 1] = ssim_sum;
+        partials[tile_index * 2 + 0] = l1_sum;
+        partials[tile_index * 2 + 1] = ssim_sum;
     }
 }
 
@@ -233,19 +270,21 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(int n_tiles, const fl
 // v_img1 = g_ssim * (conv(dm_dmu1) + 2 x conv(dm_ds1) + y conv(dm_ds12)) + g_l1 * sign(x - y); g_* read from device
 // scalars (upstream gradients of the two means, already divided by the element count by the caller's scale factors)
 __global__ __launch_bounds__(256) void loss_bwd_kernel(
-    int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
+    int planes, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2, SsimWindow win,
     const float* __restrict__ dm_dmu1, const float* __restrict__ dm_ds1, const float* __restrict__ dm_ds12,
     const float* __restrict__ v_l1_mean, const float* __restrict__ v_ssim_mean, float scale_l1, float scale_ssim,
     float* __restrict__ v_img1) {
-    constexpr int PATCH_BYTES = LPY * LPS * ((int)sizeof(lv2) + (int)sizeof(float));
-    constexpr int HRES_BYTES = LTX * LRS * ((int)sizeof(lv2) + (int)sizeof(float));
+    constexpr int PATCH_BYTES = LPY * (LPS * (int)sizeof(lv2) + LPSC * (int)sizeof(float));
+    constexpr int HRES_BYTES = LTX * (LRS * (int)sizeof(lv2) + LRSC * (int)sizeof(float));
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[PATCH_BYTES > HRES_BYTES ? PATCH_BYTES : HRES_BYTES];
     lv2 (*s_da)[LPS] = reinterpret_cast<lv2 (*)[LPS]>(s_raw);                                     // (dm_dmu1, dm_ds1)
-    float (*s_dc)[LPS] = reinterpret_cast<float (*)[LPS]>(s_raw + LPY * LPS * sizeof(lv2));       // dm_ds12
+    float (*s_dc)[LPSC] = reinterpret_cast<float (*)[LPSC]>(s_raw + LPY * LPS * sizeof(lv2));     // dm_ds12
     lv2 (*s_ha)[LRS] = reinterpret_cast<lv2 (*)[LRS]>(s_raw);                                     // [column][row], over the patch
-    float (*s_hc)[LRS] = reinterpret_cast<float (*)[LRS]>(s_raw + LTX * LRS * sizeof(lv2));
-    const int plane = blockIdx.z;
-    const int x0 = blockIdx.x * LTX, y0 = blockIdx.y * LTY;
+    float (*s_hc)[LRSC] = reinterpret_cast<float (*)[LRSC]>(s_raw + LTX * LRS * sizeof(lv2));
+    int tile_x, tile_y, plane;
+    size_t tile_index;
+    if (!loss_tile((W + LTX - 1) / LTX, (H + LTY - 1) / LTY, planes, tile_x, tile_y, plane, tile_index)) return;
+    const int x0 = tile_x * LTX, y0 = tile_y * LTY;
     const int t = threadIdx.x;
     const size_t pbase = (size_t)plane * H * W;
     const bool want_ssim = dm_dmu1 != nullptr;
@@ -262,28 +301,37 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(
         return;
     }
     const float g_ssim = (v_ssim_mean ? v_ssim_mean[0] : 1.f) * scale_ssim;
-    constexpr int NLOAD = (LPY * LPS + 255) / 256;
+    constexpr int NLOAD = (LPY + 3) / 4;            // thread = one patch column, every fourth row (see the forward)
     lv2 pa[NLOAD];
     float pc[NLOAD];
+    const int pcol = t & 63, prow = t >> 6;
+    {
+        const int gx = x0 + pcol - LH;
+        const bool col_in = pcol < LPX && gx >= 0 && gx < W;
 #pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {       // all global loads in flight before the first LDS store
-        const int i = t + k * 256;
-        const int r = i / LPS, c = i - r * LPS;
-        const int gy = y0 + r - LH, gx = x0 + c - LH;
-        const bool in = i < LPY * LPS && c < LPX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = pbase + (size_t)gy * W + gx;
-        pa[k] = in ? (lv2){dm_dmu1[o], dm_ds1[o]} : (lv2){0.f, 0.f};
-        pc[k] = in ? dm_ds12[o] : 0.f;
+        for (int k = 0; k < NLOAD; ++k) {       // all global loads in flight before the first LDS store
+            const int r = prow + 4 * k;
+            const int gy = y0 + r - LH;
+            const bool in = col_in && r < LPY && gy >= 0 && gy < H;
+            const size_t o = pbase + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+            pa[k] = in ? (lv2){dm_dmu1[o], dm_ds1[o]} : (lv2){0.f, 0.f};
+            pc[k] = in ? dm_ds12[o] : 0.f;
+        }
     }
+    if (pcol < LPS) {
 #pragma unroll
-    for (int k = 0; k < NLOAD; ++k) {
-        const int i = t + k * 256;
-        if (i < LPY * LPS) { s_da[i / LPS][i % LPS] = pa[k]; s_dc[i / LPS][i % LPS] = pc[k]; }
+        for (int k = 0; k < NLOAD; ++k) {
+            const int r = prow + 4 * k;
+            if (r < LPY) {
+                s_da[r][pcol] = pa[k];
+                if (pcol < LPSC) s_dc[r][pcol] = pc[k];
+            }
+        }
     }
     __syncthreads();
     {
         const bool hthread = t < LPY * LHSEG;
-        const int r = t / LHSEG, c0 = (t % LHSEG) * 4;
+        const int r = t % LPY, c0 = (t / LPY) * 4;      // row-fastest: see the forward
         lv2 v[16], o[4];
         float vc[16], oc[4];
         if (hthread) { load16(&s_da[r][c0], v); load16(&s_dc[r][c0], vc); }
@@ -341,15 +389,16 @@ static int loss_fwd_common(int planes, int H, int W, const float* img1, const fl
     if (planes > 65535) return fail_arg(who);
     static const SsimWindow win = make_window();
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((W + LTX - 1) / LTX, (H + LTY - 1) / LTY, planes), block(256);
+    const int n_wg = ((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * planes;
+    const dim3 grid((unsigned)((n_wg + 7) / 8 * 8)), block(256);      // workgroup -> tile: loss_tile
     float* partials = (float*)workspace;
     if (train)
-        hipLaunchKernelGGL(loss_fwd_kernel<true>, grid, block, 0, s, H, W, img1, img2, win, dm_dmu1, dm_ds1, dm_ds12, partials);
+        hipLaunchKernelGGL(loss_fwd_kernel<true>, grid, block, 0, s, planes, H, W, img1, img2, win, dm_dmu1, dm_ds1, dm_ds12, partials);
     else
-        hipLaunchKernelGGL(loss_fwd_kernel<false>, grid, block, 0, s, H, W, img1, img2, win, dm_dmu1, dm_ds1, dm_ds12, partials);
+        hipLaunchKernelGGL(loss_fwd_kernel<false>, grid, block, 0, s, planes, H, W, img1, img2, win, dm_dmu1, dm_ds1, dm_ds12, partials);
     int rc = check_launch("loss_fwd");
     if (rc != GSPL_OK) return rc;
-    const int n_tiles = (int)(grid.x * grid.y * grid.z);
+    const int n_tiles = n_wg;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, n_tiles, (const float2*)partials,
                        1.0 / ((double)planes * H * W), out_means, w_l1, w_ssim, write_loss);
     return check_launch("loss_reduce");
@@ -382,9 +431,10 @@ extern "C" int gspl_loss_l1_ssim_bwd(int planes, int H, int W, const float* img1
     if (planes > 65535) return fail_arg("loss_l1_ssim_bwd: more than 65535 planes");
     static const SsimWindow win = make_window();
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((W + LTX - 1) / LTX, (H + LTY - 1) / LTY, planes), block(256);
+    const int n_wg = ((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * planes;
+    const dim3 grid((unsigned)((n_wg + 7) / 8 * 8)), block(256);      // workgroup -> tile: loss_tile
     const float inv_n = (float)(1.0 / ((double)planes * H * W));
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, block, 0, s, H, W, img1, img2, win, dm_dmu1, dm_ds1, dm_ds12,
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, block, 0, s, planes, H, W, img1, img2, win, dm_dmu1, dm_ds1, dm_ds12,
                        v_l1_mean, v_ssim_mean, weight_l1 * inv_n, (dm_dmu1 ? weight_ssim : 0.f) * inv_n, v_img1);
     return check_launch("loss_bwd");
 }

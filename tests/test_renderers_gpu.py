@@ -129,6 +129,27 @@ def test_hip_gsplat_renderers_contract_and_parity(which):
         assert not bool((acc & ~out["visibility_filter"]).any()) and 0 < int(acc.sum()) < int(out["visibility_filter"].sum())
 
 
+def test_hip_pypreprocess_renderer_contract_and_parity():
+    """Stand-in for `PythonPreprocessGSplatRenderer` (BASELINE.json configs[0], pypreprocess_gsplat_renderer.py:8-66): its output
+    dictionary (scalar grad scale, projection mask) and parity of render + gradients with the oracle's gsplat pipeline."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipPythonPreprocessGSplatRenderer
+    params, cam, wimg, bg = _scene(seed=34)
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    renderer = HipPythonPreprocessGSplatRenderer()
+    assert renderer.block_size == 16 and renderer.anti_aliased is True
+    out = renderer(FakeCamera(cam, DEV), model, bg.to(DEV))
+    assert set(out) == {"render", "viewspace_points", "viewspace_points_grad_scale", "visibility_filter", "radii"}
+    W, H = cam["width"], cam["height"]
+    assert out["viewspace_points_grad_scale"] == 0.5 * max(H, W) and out["render"].shape == (3, H, W)
+    out["viewspace_points"].retain_grad()
+    (out["render"] * wimg.to(DEV)).sum().backward()
+    r, dl = _oracle_grads("gsplat", params, cam, wimg, bg)
+    assert torch.equal(out["visibility_filter"].cpu(), r["mask"])
+    _check(model, dl, out["render"], r)
+    assert_close_scaled(out["viewspace_points"].grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", 0.995, rel_all=0.5)
+
+
 @pytest.mark.parametrize("model_name", ["fisheye", "ortho"])
 def test_v1_renderer_runtime_camera_model(model_name):
     """The viewer's camera-model dropdown (gsplat_v1_renderer.py:653-661) sets `runtime_options.camera_model`; the projection
