@@ -684,8 +684,20 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column 0..15][channel][row]
     __shared__ int s_last;
 
-#ifdef GSPL_BWD_LPT
+#if defined(GSPL_BWD_LPT)
     const int tile = g_tile_order[blockIdx.x];
+#elif defined(GSPL_BWD_BLOCKS)
+    // EXPERIMENT (A/B builds): the runs of 32 tiles an XCD works through are 8 x 4 BLOCKS of tiles instead of 32 tiles of one
+    // tile row, so that vertical neighbours (which share as many splats as horizontal ones) meet in the same L2 too.
+    int tile;
+    {
+        const int tile_h = n_tiles / tile_w, bx = (tile_w + 7) / 8, by = (tile_h + 3) / 4;
+        const int sidx = xcd_remap(blockIdx.x, bx * by * 32);
+        const int blk = sidx >> 5, pos = sidx & 31;
+        const int txx = (blk % bx) * 8 + (pos & 7), tyy = (blk / bx) * 4 + (pos >> 3);
+        if (txx >= tile_w || tyy >= tile_h) return;
+        tile = tyy * tile_w + txx;
+    }
 #else
     const int tile = xcd_remap(blockIdx.x, n_tiles);
 #endif
@@ -1339,13 +1351,18 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
     if (n_tiles > (1 << 16)) return fail_arg("composite_bwd (LPT experiment): more than 65536 tiles");
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, offsets, n_tiles, n_isects);
 #endif
+#ifdef GSPL_BWD_BLOCKS
+    const int grid_bwd2 = ((tile_w + 7) / 8) * ((n_tiles / tile_w + 3) / 4) * 32;
+#else
+    const int grid_bwd2 = n_tiles;
+#endif
     if (absgrad)
-        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(128), 0, s,
+        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(grid_bwd2), dim3(128), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     else
-        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(128), 0, s,
+        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(grid_bwd2), dim3(128), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
