@@ -216,6 +216,35 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         for i, r in enumerate(out["projection_results_list"]):
             assert torch.equal(out["visible_mask_list"][i], r[0] > 0)
             _close(r[1].grad, ref_xy[i].reshape(N, 2)[lo:hi], tol, f"xys grad of camera {i}")
+        # ---- the reference's own DistributedVanillaDensityControllerImpl consumes these outputs (lightning stubbed; only where the
+        # reference tree exists — not on the GPU box): its statistics buffers equal the sums computed by hand
+        ref_root = os.environ.get("GSPL_REFERENCE_ROOT", "/root/reference")
+        if os.path.exists(os.path.join(ref_root, "internal", "density_controllers", "distributed_vanilla_density_controller.py")):
+            import types
+            if "lightning" not in sys.modules:
+                Lm = types.ModuleType("lightning")
+                Lm.LightningModule = type("LightningModule", (), {})
+                sys.modules["lightning"] = Lm
+            if ref_root not in sys.path:
+                sys.path.insert(0, ref_root)
+            from internal.density_controllers.distributed_vanilla_density_controller import DistributedVanillaDensityController
+            ctrl = DistributedVanillaDensityController().instantiate()
+            n_local = hi - lo
+            ctrl._init_state(n_local, dev)
+            ctrl.max_radii2D, ctrl.xyz_gradient_accum, ctrl.denom = (b.to(dtype) for b in (ctrl.max_radii2D, ctrl.xyz_gradient_accum, ctrl.denom))
+            with torch.no_grad():
+                ctrl.update_states(out)
+            exp_accum = torch.zeros(n_local, 1, dtype=dtype, device=dev)
+            exp_denom = torch.zeros(n_local, 1, dtype=dtype, device=dev)
+            exp_radii = torch.zeros(n_local, dtype=dtype, device=dev)
+            scale = 0.5 * torch.tensor([[W_IMG, H_IMG]], dtype=dtype, device=dev)
+            for i, r in enumerate(out["projection_results_list"]):
+                vis = out["visible_mask_list"][i]
+                exp_accum[vis] += torch.norm(r[1].grad[vis, :2] * scale, dim=-1, keepdim=True)
+                exp_denom[vis] += 1
+                exp_radii[vis] = torch.max(exp_radii[vis], r[0][vis].to(dtype))
+            assert torch.equal(ctrl.denom, exp_denom) and torch.equal(ctrl.max_radii2D, exp_radii)
+            assert torch.allclose(ctrl.xyz_gradient_accum, exp_accum, rtol=1e-6, atol=0) and float(ctrl.denom.sum()) > 0
         # hard inverse depth render type is produced and finite
         with torch.no_grad():
             d = renderer(camset[rank], model, bg.to(dev), render_types=["rgb", "hard_inverse_depth"])

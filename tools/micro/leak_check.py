@@ -13,4 +13,6 @@ for api in ("vanilla", "gsplat"):
     torch.cuda.synchronize(); m0 = torch.cuda.memory_allocated(); r0 = torch.cuda.memory_reserved()
     for i in range(300): step()
     torch.cuda.synchronize(); m1 = torch.cuda.memory_allocated(); r1 = torch.cuda.memory_reserved()
-    print(api, "allocated", m0, "->", m1, "reserved", r0, "->", r1, "pinned words", len(ops._PINNED_WORDS))
+    for i in range(600): step()
+    torch.cuda.synchronize(); m2 = torch.cuda.memory_allocated(); r2 = torch.cuda.memory_reserved()
+    print(api, "allocated", m0, "->", m1, "->", m2, "reserved", r0, "->", r1, "->", r2, "pinned words", len(ops._PINNED_WORDS))
