@@ -564,8 +564,8 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     const RadixPlan& dp = w.depth;
     RadixProducer hdr;
     radix_producer_args(dp, ws + w.sort1_off, hdr);
-    hipError_t e = hipMemsetAsync(ws + w.sort1_off, 0, dp.header_bytes, s);
-    if (e != hipSuccess) return check_hip(e, "bin_count: sort tables clear");
+    rc = radix_zero(ws + w.sort1_off, dp.header_bytes, s);
+    if (rc != GSPL_OK) return rc;
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
     else
@@ -609,8 +609,8 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     // list is not longer, else the emission is repeated; gspl_bin_sort keeps the spans)
     RadixProducer hdr;
     radix_producer_args(w.tile, ws + w.sort2_off, hdr);
-    hipError_t e = hipMemsetAsync(ws + w.sort2_off, 0, w.tile.header_bytes, s);
-    if (e != hipSuccess) return check_hip(e, "bin_emit: sort tables clear");
+    rc = radix_zero(ws + w.sort2_off, w.tile.header_bytes, s);
+    if (rc != GSPL_OK) return rc;
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity, hdr);
     else

@@ -154,6 +154,22 @@ extern "C" int gspl_rasterize_inria_fwd(
     int rc = GSPL_OK;
     int64_t n_isects = 0;
     if (N > 0) {
+        // every block whose size is known up front is asked for BEFORE the first launch: an allocation call-back costs the host
+        // 5-10 us (it runs the caller's allocator), and between two launches that is a 6 us bubble on the device
+        const size_t ws1_bytes = gspl_bin_workspace_bytes(N, 0);
+        char* ws1 = (char*)alloc(alloc_ctx, GSPL_BUF_BINNING, ws1_bytes);
+        if (!ws1) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
+        int64_t capacity = 0;
+        char* ws2 = nullptr;
+        size_t ws2_bytes = 0;
+        if (capacity_hint > 0) {
+            capacity = capacity_hint;
+            ws2_bytes = gspl_bin_workspace_bytes(N, capacity);
+            ws2 = (char*)alloc(alloc_ctx, GSPL_BUF_LISTS_WORK, ws2_bytes);
+            if (!ws2) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
+        }
+        int64_t* host = pinned_words();
+        if (!host) return fail_arg("rasterize_inria_fwd: no pinned host word");
         // geometry; then two independent chains: the colour (SH) kernel on the side stream, the count / depth-sort half of the
         // binning on the caller's stream; the host meanwhile waits for the one number that sizes the tile sort
         rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
@@ -174,11 +190,6 @@ extern "C" int gspl_rasterize_inria_fwd(
                                        st->colors, st->clamped, st->cov3d, GSPL_INRIA_COLOURS, cs);
         if (rc == GSPL_OK && ev_col) (void)hipEventRecord(ev_col, cs);
         if (rc != GSPL_OK) return rc;
-        const size_t ws1_bytes = gspl_bin_workspace_bytes(N, 0);
-        char* ws1 = (char*)alloc(alloc_ctx, GSPL_BUF_BINNING, ws1_bytes);
-        if (!ws1) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
-        int64_t* host = pinned_words();
-        if (!host) return fail_arg("rasterize_inria_fwd: no pinned host word");
         {
             rc = gspl_bin_count(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
                                 spans, host, ws1, ws1_bytes, s);      // the scan kernel stores the two numbers into `host` itself
@@ -186,16 +197,10 @@ extern "C" int gspl_rasterize_inria_fwd(
             hipEvent_t ev_cnt = fe.cnt;
             (void)hipEventRecord(ev_cnt, s);
             // speculative emission with the caller's guess of the list length, while the host waits for the real one
-            int64_t capacity = 0;
-            char* ws2 = nullptr;
-            size_t ws2_bytes = 0;
-            if (capacity_hint > 0) {
-                capacity = capacity_hint;
-                ws2_bytes = gspl_bin_workspace_bytes(N, capacity);
-                ws2 = (char*)alloc(alloc_ctx, GSPL_BUF_LISTS_WORK, ws2_bytes);
-                if (ws2) rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
-                                            capacity, ws2, ws2_bytes, s);
-                if (!ws2 || rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return ws2 ? rc : fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+            if (ws2) {
+                rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
+                                   capacity, ws2, ws2_bytes, s);
+                if (rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return rc; }
             }
             (void)hipEventSynchronize(ev_cnt);
             n_isects = host[0];

@@ -57,6 +57,7 @@ void radix_replan_items(RadixPlan& plan, size_t n);      // the same plan (bit s
 // (plan.passes & 1).  vals may be nullptr (keys only).  `prepared`: the caller zeroed plan.header_bytes at workspace and its
 // key-producing kernel accumulated the pass-0 rows (struct RadixProducer of gspl_sort_device.h, filled on the host by
 // radix_producer_args).
+int radix_zero(void* p, size_t bytes, void* stream);      // clears sort tables (16-byte multiples) with a kernel, not a memset
 struct RadixProducer;
 void radix_producer_args(const RadixPlan& plan, void* workspace, RadixProducer& rp);
 
