@@ -39,6 +39,45 @@ __global__ __launch_bounds__(256) void selective_adam_kernel(AdamBatchDev batch,
     const int64_t total = (int64_t)N * T.row;
     const float step = T.lr * inv_bc1;
     const int64_t nvec = total >> 2;
+#ifndef GSPL_ADAM_V1
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    auto ntl = [](const float* base, int64_t i) { const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base) + i); return make_float4(t.x, t.y, t.z, t.w); };
+    auto nts = [](float* base, int64_t i, const float4& q) { v4f t = {q.x, q.y, q.z, q.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(base) + i); };
+    // two 16-byte chunks per thread and iteration (8 loads in flight) and streaming (nontemporal) accesses of everything that is
+    // not read again before the next step: 302 -> 257 us at 1 M Gaussians (1.65 GB: 6.4 TB/s); -DGSPL_ADAM_V1 = the one-chunk loop
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += 2 * stride) {
+        float4 p[2], g[2], m[2], v[2];
+        bool vis[2][4], any[2] = {false, false};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < nvec) {
+                const int64_t e = i << 2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { vis[u][k] = visible ? visible[(e + k) / T.row] != 0 : true; any[u] = any[u] || vis[u][k]; }
+            }
+            if (any[u]) {
+                p[u] = ntl(T.p, i);
+                g[u] = ntl(T.g, i);
+                m[u] = ntl(T.m, i);
+                v[u] = ntl(T.v, i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!any[u]) continue;
+            const int64_t i = i0 + u * stride;
+            if (vis[u][0]) adam_elem(p[u].x, g[u].x, m[u].x, v[u].x, step, b1, b2, inv_bc2, eps);
+            if (vis[u][1]) adam_elem(p[u].y, g[u].y, m[u].y, v[u].y, step, b1, b2, inv_bc2, eps);
+            if (vis[u][2]) adam_elem(p[u].z, g[u].z, m[u].z, v[u].z, step, b1, b2, inv_bc2, eps);
+            if (vis[u][3]) adam_elem(p[u].w, g[u].w, m[u].w, v[u].w, step, b1, b2, inv_bc2, eps);
+            reinterpret_cast<float4*>(T.p)[i] = p[u];
+            nts(T.m, i, m[u]);
+            nts(T.v, i, v[u]);
+        }
+    }
+#else
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = i << 2;
         bool vis[4];
@@ -58,6 +97,7 @@ __global__ __launch_bounds__(256) void selective_adam_kernel(AdamBatchDev batch,
         reinterpret_cast<float4*>(T.m)[i] = m;
         reinterpret_cast<float4*>(T.v)[i] = v;
     }
+#endif
     // tail (total not a multiple of 4)
     if (blockIdx.x == 0) {
         for (int64_t e = (nvec << 2) + threadIdx.x; e < total; e += blockDim.x) {

@@ -95,6 +95,25 @@ __device__ __forceinline__ void sh_basis_grad(int degree, float x, float y, floa
     { const float c = 0.6258357354491761f * w[24]; gx += c * (4.f * xx * x - 12.f * x * yy); gy += c * (-12.f * xx * y + 4.f * yy * y); }
 }
 
+// The coefficient rows and their gradients are streamed once per launch: nontemporal accesses (-DGSPL_SH_PLAIN: plain ones).
+typedef float sh_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 sh_load16(const float4* p) {
+#ifdef GSPL_SH_PLAIN
+    return *p;
+#else
+    const sh_v4f t = __builtin_nontemporal_load(reinterpret_cast<const sh_v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#endif
+}
+__device__ __forceinline__ void sh_store16(float4* p, const float4& q) {
+#ifdef GSPL_SH_PLAIN
+    *p = q;
+#else
+    const sh_v4f t = {q.x, q.y, q.z, q.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<sh_v4f*>(p));
+#endif
+}
+
 // Flat coalesced copy of `rows` rows x `rs` floats (contiguous in global) into LDS rows of stride ls.
 __device__ __forceinline__ void tile_load(const float* __restrict__ g, int rows, int rs, int ls, float inv_rs,
                                           float* lds, bool vec_ok) {
@@ -112,7 +131,7 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ g, int rows,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e4 = b4 + u * SH_BLOCK;
-                v[u] = (e4 < n4) ? g4[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = (e4 < n4) ? sh_load16(g4 + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -151,7 +170,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ g, int rows, int 
                 const int row = (int)(((float)e + 0.5f) * inv_rs);
                 vv[k] = lds[row * ls + (e - row * rs)];
             }
-            g4[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            sh_store16(g4 + e4, make_float4(vv[0], vv[1], vv[2], vv[3]));
         }
         done = n4 << 2;
     }
