@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -64,6 +64,7 @@ _SIGNATURES = {
                                  c_float, c_float, c_float, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int,
                                  _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "gspl_low_priority_stream": (c_void_p, []),
     "gspl_records_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gspl_records_pack_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_records_pack_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -168,15 +169,19 @@ def lib():
 # Optional per-call device timing (bench.py): a list that receives (name, start_event, end_event).
 # Events are recorded on torch's current stream, which is the stream every kernel is launched on.
 _PROFILE = None
+_PROFILE_PERIOD = 1
+_PROFILE_SEEN: dict = {}
 _PROFILE_NAMES = None
 
 
-def profile_start(names=None):
-    """Time C-ABI calls with events on the current stream; `names`: only these entry points (None: all)."""
-    global _PROFILE, _PROFILE_NAMES
+def profile_start(names=None, period: int = 1):
+    """Time C-ABI calls with events on the current stream; `names`: only these entry points (None: all); `period`: every
+    period-th call of a name is timed (an event pair costs the stream ~6 us of idle time on either side of the call)."""
+    global _PROFILE, _PROFILE_NAMES, _PROFILE_PERIOD, _PROFILE_SEEN
     _PROFILE = []
     _PROFILE_NAMES = None if names is None else frozenset(names)
-    lib().gspl_profile_enable(1)
+    _PROFILE_PERIOD, _PROFILE_SEEN = max(int(period), 1), {}
+    lib().gspl_profile_enable(_PROFILE_PERIOD)
 
 
 def profile_stop():
@@ -200,7 +205,12 @@ def profile_stop():
 def call(name: str, *args):
     """Invoke one C-ABI entry point and raise on a non-zero status."""
     fn = getattr(lib(), name)
-    if _PROFILE is not None and (_PROFILE_NAMES is None or name in _PROFILE_NAMES):
+    timed = _PROFILE is not None and (_PROFILE_NAMES is None or name in _PROFILE_NAMES)
+    if timed and _PROFILE_PERIOD > 1:
+        seen = _PROFILE_SEEN.get(name, 0)
+        _PROFILE_SEEN[name] = seen + 1
+        timed = seen % _PROFILE_PERIOD == 0
+    if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)

@@ -67,16 +67,35 @@ static FrameEvents& frame_events() {
     return ev;
 }
 
+// A LOW-priority stream per device for the colour kernel (created once, never destroyed).  The colour kernel is a 70-90 us
+// bandwidth stream that runs next to the latency-bound key pass and depth sort; at equal priority it takes half the machine
+// from kernels that are on the critical path.  (torch.cuda.Stream cannot ask for a priority below the default.)
+extern "C" void* gspl_low_priority_stream(void) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[dev]) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); streams[dev] = nullptr; }
+    }
+    return streams[dev];
+}
+
 // Optional timing of the two compositing launches INSIDE the fused calls (bench.py's roofline: the launches cannot be bracketed
 // from Python any more).  Events are recorded on the launch stream; durations are read after a synchronisation.
 struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
-static bool g_prof_on = false;
+static int g_prof_period = 0;   // 0: off; k: every k-th launch is timed (an event pair costs ~6 us of stream idle time per side)
+static unsigned g_prof_seen[2] = {0u, 0u};
 static std::mutex g_prof_mu;
 static ProfSlot g_prof[2];      // 0: composite forward, 1: composite backward
 struct ProfScope {
     int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(int w, hipStream_t st) : which(w), s(st) {
-        if (!g_prof_on) return;
+        if (g_prof_period <= 0) return;
+        if ((g_prof_seen[w]++ % (unsigned)g_prof_period) != 0u) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, s);
     }
@@ -90,9 +109,10 @@ struct ProfScope {
 
 }  // namespace gspl
 
-extern "C" int gspl_profile_enable(int on) {
+extern "C" int gspl_profile_enable(int period) {
     std::lock_guard<std::mutex> lk(gspl::g_prof_mu);
-    gspl::g_prof_on = on != 0;
+    gspl::g_prof_period = period > 0 ? period : 0;
+    gspl::g_prof_seen[0] = gspl::g_prof_seen[1] = 0u;
     for (auto& slot : gspl::g_prof) {
         for (auto& e : slot.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
         slot.ev.clear();

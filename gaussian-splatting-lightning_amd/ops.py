@@ -636,6 +636,7 @@ class _side_stream:
     keep everything on the caller's stream."""
     _streams: dict = {}
     _handles: dict = {}
+    _low: dict = {}
 
     def __init__(self, dev):
         import os
@@ -1081,6 +1082,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
 
 # ---- the same rasterizer through ONE C-ABI call per direction (gspl_rasterize_inria_fwd/bwd, csrc/fused.hip) -----------------
 FUSED_INRIA = os.environ.get("GSPL_FUSED_INRIA", "1") != "0"
+SIDE_LOW_PRIORITY = os.environ.get("GSPL_SIDE_LOW_PRIORITY", "1") != "0"
 _ALLOC_TLS = __import__("threading").local()
 
 
@@ -1133,11 +1135,20 @@ class _InriaFusedFn(torch.autograd.Function):
         side = _side_stream(dev)
         with torch.cuda.device(dev):
             side_handle = None
+            low = False
             if side.enabled:
                 hk = (dev.type, dev.index)
                 raw = _side_stream._handles.get(hk)
                 if raw is None:
-                    raw = _side_stream._handles[hk] = side.stream.cuda_stream      # (~10 us of Python per look-up: cached)
+                    # a stream of the device's LOWEST priority from the library (torch cannot create one below the default):
+                    # the colour kernel yields to the key pass and the depth sort it runs next to
+                    raw = (L.lib().gspl_low_priority_stream() or 0) if SIDE_LOW_PRIORITY else 0
+                    low = bool(raw)
+                    if not raw:
+                        raw = side.stream.cuda_stream      # (~10 us of Python per look-up: cached)
+                    _side_stream._handles[hk] = raw
+                    _side_stream._low[hk] = low
+                low = _side_stream._low.get(hk, False)
                 side_handle = ctypes.c_void_p(raw)
             try:
                 L.call("gspl_rasterize_inria_fwd", N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
@@ -1150,8 +1161,9 @@ class _InriaFusedFn(torch.autograd.Function):
                 raise
             finally:
                 _ALLOC_TLS.holder = None
-        if side.enabled:
+        if side.enabled and not low:
             # blocks the colour kernel used on the side stream are freed by the caller's stream: tell the allocator
+            # (the library's own low-priority stream is joined inside the call: stream order on the caller's stream covers it)
             for t in holder.get(L.GSPL_BUF_GEOMETRY, []):
                 t.record_stream(side.stream)
         _LAST_ISECTS[key] = int(state.n_isects)

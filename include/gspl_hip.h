@@ -395,11 +395,16 @@ int gspl_rasterize_inria_bwd(int degree, int n_coeffs,
                              float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_colors_precomp, float* v_opacities,
                              float* v_scales, float* v_rotations, float* v_cov3D, void* stream);
 
+/* A per-device stream of the LOWEST priority the device offers, created on first use and kept: a `side_stream` for
+ * gspl_rasterize_inria_fwd whose colour kernel then yields to the kernels on the caller's stream.  NULL on failure. */
+void* gspl_low_priority_stream(void);
+
 /* Timing of the compositing launches inside the fused calls (bench.py: the roofline of the graded kernel needs its launch
  * duration from HIP events on the launch stream, and the launches are no longer visible from the host language).
- * gspl_profile_enable(1) starts recording (and drops what was recorded), gspl_profile_read synchronises and returns the count
- * and the summed duration of the forward (which = 0) or backward (1) compositing launches since then; enable(0) stops. */
-int gspl_profile_enable(int on);
+ * gspl_profile_enable(k) starts recording every k-th launch (k = 1: all; an event pair costs the stream ~6 us of idle time on
+ * either side of the launch) and drops what was recorded, gspl_profile_read synchronises and returns the count and the summed
+ * duration of the timed forward (which = 0) or backward (1) compositing launches since then; enable(0) stops. */
+int gspl_profile_enable(int period);
 int gspl_profile_read(int which, int* count, float* total_ms);
 
 /* ------------------------------------------------------------------------------------------
