@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -49,7 +49,7 @@ ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctyp
 class InriaState(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int), ("width", ctypes.c_int), ("height", ctypes.c_int), ("n_isects", ctypes.c_int64),
                 ("means2d", ctypes.c_void_p), ("depths", ctypes.c_void_p), ("conics", ctypes.c_void_p), ("colors", ctypes.c_void_p),
-                ("clamped", ctypes.c_void_p), ("cov3d", ctypes.c_void_p),
+                ("clamped", ctypes.c_void_p), ("cov3d", ctypes.c_void_p), ("sh_jac", ctypes.c_void_p),
                 ("alphas", ctypes.c_void_p), ("final_Ts", ctypes.c_void_p), ("last_ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p),
                 ("flatten_ids", ctypes.c_void_p)]
 
@@ -105,7 +105,7 @@ _SIGNATURES = {
                                           c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_float, c_float, c_float,
-                                          _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+                                          _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "gspl_rasterize_inria_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float,
                                          ALLOC_FN, _P, c_int64, _P, _P, ctypes.POINTER(InriaState), _P, _P]),
     "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
@@ -116,7 +116,7 @@ _SIGNATURES = {
     "gspl_rasterize_inria_image_bytes": (c_size_t, [c_int, c_int]),
     "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_float, c_float, c_float,
-                                          _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                          _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _LIB = None

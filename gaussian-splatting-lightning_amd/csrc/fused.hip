@@ -23,14 +23,14 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // per-splat intermediates of one frame, carved out of ONE allocation (tag GSPL_BUF_GEOMETRY)
 struct GeomLayout {
-    size_t radii, means2d, depths, conics, colors, clamped, cov3d, order, cum, big_list, spans, total;
+    size_t radii, means2d, depths, conics, colors, clamped, cov3d, sh_jac, order, cum, big_list, spans, total;
 };
 static GeomLayout geom_layout(size_t n) {
     GeomLayout g;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
     g.means2d = take(8 * n); g.depths = take(4 * n); g.conics = take(12 * n); g.colors = take(12 * n);
-    g.clamped = take(3 * n); g.cov3d = take(24 * n);
+    g.clamped = take(3 * n); g.cov3d = take(24 * n); g.sh_jac = take(36 * n);
     g.order = take(4 * n); g.cum = take(8 * (n + 1)); g.big_list = take(4 * n); g.spans = take((size_t)GSPL_BIN_SPAN_BYTES * n);
     g.radii = 0;       // radii are an OUTPUT tensor of the call, not part of the block
     g.total = off;
@@ -165,6 +165,7 @@ extern "C" int gspl_rasterize_inria_fwd(
     if (!geom || !img) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
     st->means2d = (float*)(geom + g.means2d); st->depths = (float*)(geom + g.depths); st->conics = (float*)(geom + g.conics);
     st->colors = (float*)(geom + g.colors); st->clamped = (uint8_t*)(geom + g.clamped); st->cov3d = (float*)(geom + g.cov3d);
+    st->sh_jac = (float*)(geom + g.sh_jac);
     st->alphas = (float*)(img + im.alphas); st->final_Ts = (float*)(img + im.final_Ts); st->last_ids = (int32_t*)(img + im.last_ids);
     st->offsets = (int32_t*)(img + im.offsets);
     int32_t* order = (int32_t*)(geom + g.order);
@@ -194,7 +195,7 @@ extern "C" int gspl_rasterize_inria_fwd(
         // binning on the caller's stream; the host meanwhile waits for the one number that sizes the tile sort
         rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
                                        campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
-                                       st->colors, st->clamped, st->cov3d, GSPL_INRIA_GEOMETRY, s);
+                                       st->colors, st->clamped, st->cov3d, nullptr, GSPL_INRIA_GEOMETRY, s);
         if (rc != GSPL_OK) return rc;
         FrameEvents& fe = frame_events();
         if (!fe.ok) return check_hip(hipGetLastError(), "rasterize_inria_fwd: event");
@@ -207,7 +208,7 @@ extern "C" int gspl_rasterize_inria_fwd(
         hipStream_t cs = (ss && ss != s) ? ss : s;
         rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
                                        campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
-                                       st->colors, st->clamped, st->cov3d, GSPL_INRIA_COLOURS, cs);
+                                       st->colors, st->clamped, st->cov3d, st->sh_jac, GSPL_INRIA_COLOURS, cs);
         if (rc == GSPL_OK && ev_col) (void)hipEventRecord(ev_col, cs);
         if (rc != GSPL_OK) return rc;
         {
@@ -281,5 +282,5 @@ extern "C" int gspl_rasterize_inria_bwd(
     }
     return gspl_inria_preprocess_bwd(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, viewmatrix, projmatrix, campos, width, height,
                                      tanfovx, tanfovy, scale_modifier, radii, st->clamped, packed, packed + 2, packed + 6, 9, v_means3D, v_scales,
-                                     v_rotations, v_cov3D, v_shs, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, s);
+                                     v_rotations, v_cov3D, v_shs, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac, s);
 }

@@ -39,9 +39,10 @@ namespace gspl {
 int sh_fwd_launch(int N, int C, int degree, const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags,
-                  float* colors, uint8_t* clamped, void* stream);
+                  float* colors, uint8_t* clamped, void* stream, float* jac /* nullable [N,9]: d colour / d unit direction */);
 int sh_bwd_launch(int N, int C, int degree, int n_coeffs, const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
-                  const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream);
+                  const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream,
+                  const float* jac /* nullable: the forward's Jacobian; v_dirs then needs no coefficient read */);
 }  // namespace gspl

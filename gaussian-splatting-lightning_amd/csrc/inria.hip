@@ -217,7 +217,7 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                                          int width, int height, int tile_size,
                                          float tanfovx, float tanfovy, float scale_modifier,
                                          int32_t* radii, float* means2d, float* depths, float* conics,
-                                         float* colors, uint8_t* clamped, float* cov3d, int phases, void* stream) {
+                                         float* colors, uint8_t* clamped, float* cov3d, float* sh_jac, int phases, void* stream) {
     using namespace gspl;
     if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0) return fail_arg("inria_preprocess_fwd: bad sizes");
     if ((phases & ~GSPL_INRIA_ALL) || phases == 0) return fail_arg("inria_preprocess_fwd: bad phases");
@@ -244,7 +244,7 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
     }
     const int stride = 3 * n_coeffs;
     return sh_fwd_launch(N, 1, degree, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
-                         GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream);
+                         GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream, sh_jac);
 }
 
 extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
@@ -256,7 +256,7 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                                          const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
                                          float* v_means, float* v_scales, float* v_quats,
                                          float* v_cov3d_precomp, float* v_shs, float* v_colors_precomp,
-                                         float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, void* stream) {
+                                         float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac, void* stream) {
     using namespace gspl;
     if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
     if (v_opacities && (!v_opacities_packed || grad_stride <= 0)) return fail_arg("inria_preprocess_bwd: v_opacities needs the packed gradient buffer");
@@ -277,7 +277,7 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
         const int stride = 3 * n_coeffs;
         // dL/d(dir) lands in v_means; the geometry kernel accumulates on top
         int rc = sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
-                               GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream);
+                               GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream, sh_jac);
         if (rc != GSPL_OK) return rc;
         accum = true;
     }

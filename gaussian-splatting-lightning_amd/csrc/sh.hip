@@ -20,7 +20,10 @@ namespace gspl {
 #ifndef GSPL_SH_U
 #define GSPL_SH_U 6
 #endif
-static constexpr int SH_BLOCK = 256;
+#ifndef GSPL_SH_BLOCK
+#define GSPL_SH_BLOCK 256
+#endif
+static constexpr int SH_BLOCK = GSPL_SH_BLOCK;      // rows (= threads) per workgroup
 static constexpr int SH_MAX_K = 25;
 
 __device__ __constant__ const float kC0 = 0.28209479177387814f;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(
     const float* __restrict__ dirs, const float* __restrict__ origin,
     const float* __restrict__ dc, int dc_stride, const float* __restrict__ rest,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ mask32, int flags, ShTile tile, int vec_ok,
-    float* __restrict__ colors, uint8_t* __restrict__ clamped) {
+    float* __restrict__ colors, uint8_t* __restrict__ clamped, float* __restrict__ jac) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * SH_BLOCK;
     const int rows = min(SH_BLOCK, N - n0);
@@ -241,6 +244,20 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(
                     if (out[c] < 0.f) { out[c] = 0.f; cl[c] = 1; }
                 }
             }
+            // d colour_c / d (unit direction), 9 floats per splat: with it the backward gets the direction gradient without
+            // reading the 12 K bytes of coefficients again (single camera only)
+            if (jac && degree > 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float w[K];
+                    w[0] = 0.f;
+#pragma unroll
+                    for (int k = 1; k < K; ++k) w[k] = row[(k - 1) * 3 + c];
+                    float gx, gy, gz;
+                    sh_basis_grad(degree, dx, dy, dz, w, gx, gy, gz);
+                    jac[(int64_t)n * 9 + c * 3 + 0] = gx; jac[(int64_t)n * 9 + c * 3 + 1] = gy; jac[(int64_t)n * 9 + c * 3 + 2] = gz;
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) colors[cn * 3 + c] = out[c];
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
     const float* __restrict__ dc, int dc_stride, const float* __restrict__ rest,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ mask32, int flags, const uint8_t* __restrict__ clamped,
     const float* __restrict__ v_colors, int vc_stride, ShTile tile, int vec_ok_in, int vec_ok_out,
-    float* __restrict__ v_dc, float* __restrict__ v_rest, float* __restrict__ v_dirs) {
+    float* __restrict__ v_dc, float* __restrict__ v_rest, float* __restrict__ v_dirs, const float* __restrict__ jac) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * SH_BLOCK;
     const int rows = min(SH_BLOCK, N - n0);
@@ -296,7 +313,23 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
     };
     if (r < rows) load_camera(0);
 
-    if (WITH_DIRS) {      // one camera only (checked by the launcher)
+    if (WITH_DIRS && jac) {      // the forward left d colour / d direction: no coefficient read at all
+        if (r < rows) {
+            float g[3] = {0.f, 0.f, 0.f};
+            if (live && degree > 0) {
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gx += vc[c] * jac[(int64_t)n * 9 + c * 3 + 0];
+                    gy += vc[c] * jac[(int64_t)n * 9 + c * 3 + 1];
+                    gz += vc[c] * jac[(int64_t)n * 9 + c * 3 + 2];
+                }
+                const float dot = gx * dx + gy * dy + gz * dz;
+                g[0] = (gx - dx * dot) * inv; g[1] = (gy - dy * dot) * inv; g[2] = (gz - dz * dot) * inv;
+            }
+            v_dirs[n * 3 + 0] = g[0]; v_dirs[n * 3 + 1] = g[1]; v_dirs[n * 3 + 2] = g[2];
+        }
+    } else if (WITH_DIRS) {      // one camera only (checked by the launcher)
         if (degree > 0) {
             const float* base = tile.merged ? dc + (int64_t)n0 * tile.rs : rest + (int64_t)n0 * tile.rs;
             tile_load(base, rows, tile.rs, tile.ls, 1.f / (float)tile.rs, lds, vec_ok_in != 0);
@@ -375,8 +408,9 @@ int sh_fwd_launch(int N, int C, int degree,
                   const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags,
-                  float* colors, uint8_t* clamped, void* stream) {
+                  float* colors, uint8_t* clamped, void* stream, float* jac) {
     if (N < 0 || C < 1 || degree < 0 || degree > 4) return fail_arg("sh_fwd: bad N/C/degree");
+    if (jac && C != 1) return fail_arg("sh_fwd: the direction Jacobian is kept for one camera only");
     if (C > 1 && !origin) return fail_arg("sh_fwd: several cameras need their origins");
     if (N == 0) return GSPL_OK;
     if (!dirs || !dc || !colors || (degree > 0 && !rest)) return fail_arg("sh_fwd: NULL required pointer");
@@ -399,7 +433,7 @@ int sh_fwd_launch(int N, int C, int degree,
             if (e != hipSuccess) return check_hip(e, "sh_fwd: hipFuncSetAttribute");                                  \
         }                                                                                                             \
         hipLaunchKernelGGL(sh_fwd_kernel<DEG>, dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, C, dirs, \
-                           origin, dc, dc_stride, rest, mask, mask32, flags, tile, vec_ok, colors, clamped);          \
+                           origin, dc, dc_stride, rest, mask, mask32, flags, tile, vec_ok, colors, clamped, jac);     \
     } break;
     switch (degree) { GSPL_SH_FWD(0) GSPL_SH_FWD(1) GSPL_SH_FWD(2) GSPL_SH_FWD(3) GSPL_SH_FWD(4) }
 #undef GSPL_SH_FWD
@@ -412,7 +446,7 @@ extern "C" int gspl_sh_fwd(int N, int degree,
                            const float* dc, int dc_stride, const float* rest, int rest_stride,
                            const uint8_t* mask, int flags,
                            float* colors, uint8_t* clamped, void* stream) {
-    return gspl::sh_fwd_launch(N, 1, degree, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, colors, clamped, stream);
+    return gspl::sh_fwd_launch(N, 1, degree, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, colors, clamped, stream, nullptr);
 }
 
 // C cameras in one launch: origins [C,3], radii [C,N] (radius > 0 = evaluate; may be NULL), colors [C,N,3], clamped [C,N,3].
@@ -422,7 +456,7 @@ extern "C" int gspl_sh_fwd_batched(int C, int N, int degree,
                                    const float* dc, int dc_stride, const float* rest, int rest_stride,
                                    const int32_t* radii, int flags,
                                    float* colors, uint8_t* clamped, void* stream) {
-    return gspl::sh_fwd_launch(N, C, degree, means, origins, dc, dc_stride, rest, rest_stride, nullptr, radii, flags, colors, clamped, stream);
+    return gspl::sh_fwd_launch(N, C, degree, means, origins, dc, dc_stride, rest, rest_stride, nullptr, radii, flags, colors, clamped, stream, nullptr);
 }
 
 namespace gspl {
@@ -431,12 +465,13 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride,
-                  float* v_dc, float* v_rest, float* v_dirs, void* stream) {
+                  float* v_dc, float* v_rest, float* v_dirs, void* stream, const float* jac) {
     if (N < 0 || C < 1 || degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("sh_bwd: bad N/C/degree/n_coeffs");
+    if (jac && !v_dirs) jac = nullptr;
     if (C > 1 && (v_dirs || !origin)) return fail_arg("sh_bwd: several cameras need their origins and give no direction gradient");
     if (N == 0) return GSPL_OK;
     if (!dirs || !v_colors || !v_dc || (n_coeffs > 1 && !v_rest)) return fail_arg("sh_bwd: NULL required pointer");
-    if (v_dirs && (!dc || (degree > 0 && !rest))) return fail_arg("sh_bwd: v_dirs needs the coefficients");
+    if (v_dirs && !jac && (!dc || (degree > 0 && !rest))) return fail_arg("sh_bwd: v_dirs needs the coefficients (or the forward's Jacobian)");
     ShTile tile;
     // geometry is decided on the OUTPUT arrays (they have the same strides as the inputs)
     tile.merged = (n_coeffs > 1 && v_rest == v_dc + 3 && dc_stride == rest_stride) ? 1 : 0;
@@ -444,7 +479,7 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs,
     if (n_coeffs > 1 && tile.rs < 3 * (n_coeffs - 1) + (tile.merged ? 3 : 0)) return fail_arg("sh_bwd: row stride too small");
     if (n_coeffs <= 1) tile.rs = 1;
     tile.ls = tile.rs | 1;
-    if (v_dirs && degree > 0) {
+    if (v_dirs && !jac && degree > 0) {
         const int in_merged = (rest == dc + 3) ? 1 : 0;
         if (in_merged != tile.merged) return fail_arg("sh_bwd: input/output coefficient layouts differ");
     }
@@ -464,7 +499,7 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs,
         }                                                                                                             \
         hipLaunchKernelGGL((sh_bwd_kernel<DEG, WD>), dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, C, \
                            n_coeffs, dirs, origin, dc, dc_stride, rest, mask, mask32, flags, clamped, v_colors, vc_stride, tile, vec_in, \
-                           vec_out, v_dc, v_rest, v_dirs);                                                            \
+                           vec_out, v_dc, v_rest, v_dirs, jac);                                                       \
     }
 #define GSPL_SH_BWD_CASE(DEG) \
     case DEG:                 \
@@ -483,7 +518,7 @@ extern "C" int gspl_sh_bwd(int N, int degree, int n_coeffs,
                            const float* v_colors, int v_colors_stride,
                            float* v_dc, float* v_rest, float* v_dirs, void* stream) {
     return gspl::sh_bwd_launch(N, 1, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors,
-                               v_colors_stride > 0 ? v_colors_stride : 3, v_dc, v_rest, v_dirs, stream);
+                               v_colors_stride > 0 ? v_colors_stride : 3, v_dc, v_rest, v_dirs, stream, nullptr);
 }
 
 // Backward of gspl_sh_fwd_batched: v_colors [C,N,3] (dense) -> v_dc / v_rest summed over the cameras, written once.
@@ -493,5 +528,5 @@ extern "C" int gspl_sh_bwd_batched(int C, int N, int degree, int n_coeffs,
                                    const int32_t* radii, int flags, const uint8_t* clamped,
                                    const float* v_colors, float* v_dc, float* v_rest, void* stream) {
     return gspl::sh_bwd_launch(N, C, degree, n_coeffs, means, origins, nullptr, dc_stride, nullptr, rest_stride, nullptr, radii, flags, clamped,
-                               v_colors, 3, v_dc, v_rest, nullptr, stream);
+                               v_colors, 3, v_dc, v_rest, nullptr, stream, nullptr);
 }

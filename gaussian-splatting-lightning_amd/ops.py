@@ -998,6 +998,8 @@ class _InriaRasterizeFn(torch.autograd.Function):
         colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev)
         cov3d = torch.empty((N, 6), dtype=torch.float32, device=dev)
+        # d colour / d view direction, left by the colour kernel for the backward (which then reads no coefficients for v_means)
+        sh_jac = torch.empty((N, 9), dtype=torch.float32, device=dev) if (sh is not None and ctx.needs_input_grad[0]) else None
         tile = 16
         tile_w, tile_h = (W + tile - 1) // tile, (H + tile - 1) // tile
         def preprocess(phases):
@@ -1007,7 +1009,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                        L.ptr(sh), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
                        float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
                        L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
-                       phases, L.stream())
+                       L.ptr(sh_jac) if (phases & L.GSPL_INRIA_COLOURS) else None, phases, L.stream())
         # geometry, then two independent chains: the SH kernel (HBM-bound, one launch) on a side stream, and the count /
         # depth-sort half of the binning (a dozen small latency-bound launches) on the caller's stream; the host meanwhile
         # waits for the one number that sizes the tile sort.
@@ -1027,7 +1029,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
             L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat) if n_isects else None,
             L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), None, L.stream())
         ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
-                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids)
+                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac)
         if KEEP_LAST_RASTER:
             global LAST_RASTER
             LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=means2d, conics=conics, opacities=opac,
@@ -1044,7 +1046,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
     def backward(ctx, v_out, _v_radii):
         lib = L.lib()
         (means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
-         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids) = ctx.saved_tensors
+         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac) = ctx.saved_tensors
         H, W, tile, tile_w, tile_h, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, opac_shape = ctx.cfg
         N = means3D.shape[0]
         dev = means3D.device
@@ -1075,7 +1077,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                 L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tanfovx, tanfovy, scale_modifier,
                 L.ptr(radii), L.ptr(clamped), L.ptr(packed), L.ptr(packed, offset_bytes=8), L.ptr(packed, offset_bytes=24), RS,
                 L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_cp), L.ptr(v_ndc),
-                L.ptr(packed, offset_bytes=20), L.ptr(v_opac), L.stream())
+                L.ptr(packed, offset_bytes=20), L.ptr(v_opac), L.ptr(sh_jac), L.stream())
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings
         return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
 

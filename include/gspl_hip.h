@@ -327,6 +327,9 @@ int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                               float tanfovx, float tanfovy, float scale_modifier,
                               int32_t* radii, float* means2d, float* depths, float* conics,
                               float* colors, uint8_t* clamped, float* cov3d,
+                              float* sh_jac /* nullable [N,9]: the colour kernel leaves d colour / d (unit view direction) here, and
+                                               a backward that is handed it finds the view-direction part of v_means without
+                                               reading the 12 n_coeffs bytes of coefficients per splat again */,
                               int phases /* GSPL_INRIA_GEOMETRY | GSPL_INRIA_COLOURS */,
                               void* stream);
 /*    Backward.  v_means2d is the composite kernel's pixel-unit gradient [N,2]; the returned
@@ -349,6 +352,7 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               const float* v_opacities_packed /*nullable: the opacity column of the packed buffer */,
                               float* v_opacities /*nullable: [N], receives that column densely (the optimizer's
                                                    gradient is then a contiguous tensor, not a strided view) */,
+                              const float* sh_jac /*nullable: from the forward*/,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -369,7 +373,7 @@ typedef void* (*gspl_alloc_fn)(void* ctx, int tag, size_t bytes);      /* device
 typedef struct gspl_inria_state {
     int N, width, height;
     int64_t n_isects;
-    float* means2d; float* depths; float* conics; float* colors; uint8_t* clamped; float* cov3d;      /* GSPL_BUF_GEOMETRY */
+    float* means2d; float* depths; float* conics; float* colors; uint8_t* clamped; float* cov3d; float* sh_jac;      /* GSPL_BUF_GEOMETRY */
     float* alphas; float* final_Ts; int32_t* last_ids; int32_t* offsets;                               /* GSPL_BUF_IMAGE */
     int32_t* flatten_ids;                                                                              /* GSPL_BUF_LISTS */
 } gspl_inria_state;
