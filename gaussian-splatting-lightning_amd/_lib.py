@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -95,6 +95,7 @@ _SIGNATURES = {
     "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_emit": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, c_size_t, _P]),
     "gspl_bin_sort": (c_int, [c_int, c_int, c_int, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
+    "gspl_bin_sort_device_count": (c_int, [c_int, c_int, c_int, _P, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t, _P]),
     "gspl_composite_fwd": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                    c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

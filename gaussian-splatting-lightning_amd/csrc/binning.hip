@@ -648,6 +648,30 @@ extern "C" int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, in
     return tile_offsets_from_counts((uint32_t*)offsets, (uint32_t)n_tiles, s);
 }
 
+// gspl_bin_sort for a host that has NOT read the list length back yet: the records were emitted into room for `capacity` of them,
+// their real number sits in *n_isects_dev (the scan's cum_tiles[N - 1]).  flatten_ids has room for `capacity` ids; offsets has
+// tile_w * tile_h + 1 entries, the last one receives the list length (compositing calls take n_isects = -1 with such an array).
+// The caller checks *n_isects_dev <= capacity afterwards (it has the number in host memory by then) and repeats the frame's
+// emission and sort when the guess was too low.
+extern "C" int gspl_bin_sort_device_count(int N, int tile_w, int tile_h, const int64_t* n_isects_dev, int64_t capacity,
+                                          int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gspl;
+    if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_sort_device_count: bad sizes");
+    if (capacity > 0x7fffffffll) return fail_arg("bin_sort_device_count: more than 2^31-1 intersections");
+    if (!n_isects_dev || !flatten_ids || !offsets || !workspace) return fail_arg("bin_sort_device_count: NULL required pointer");
+    const int n_tiles = tile_w * tile_h;
+    BinWorkspace w;
+    int rc = plan_bin(N, capacity, n_tiles, w);       // the layout and the spans gspl_bin_emit used
+    if (rc != GSPL_OK) return rc;
+    if (workspace_bytes < w.total) return fail_ws("bin_sort_device_count");
+    char* ws = (char*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    uint64_t* const tk[2] = {(uint64_t*)(ws + w.tkeys_off), (uint64_t*)(ws + w.tkeys2_off)};
+    rc = radix_sort_tiles(w.tile, ws + w.sort2_off, tk, true, (uint32_t*)flatten_ids, (uint32_t*)offsets, (uint32_t)n_tiles + 1u, s, n_isects_dev);
+    if (rc != GSPL_OK) return rc;
+    return tile_offsets_from_counts((uint32_t*)offsets, (uint32_t)n_tiles + 1u, s);
+}
+
 extern "C" int gspl_bin_emit_sort(int N, int mode, const float* means2d, const int32_t* radii,
                                   const float* conics, const float* opacities,
                                   const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,

@@ -91,7 +91,8 @@ __device__ __forceinline__ bool box_reachable(float mx, float my, float a, float
 __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isects,
                                            const int32_t* __restrict__ offsets, int& start, int& end) {
     start = offsets[tile];
-    end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
+    // n_isects < 0: `offsets` has n_tiles + 1 entries, the last one is the list length (device-side count, gspl_bin_sort_device_count)
+    end = (tile + 1 < n_tiles || n_isects < 0) ? offsets[tile + 1] : (int)n_isects;
 }
 
 // Forward: ONE WAVE PER WORKGROUP.  A workgroup is a single wave64 that owns one 8x8 quadrant of a tile and walks
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(64) void composite_scores_kernel(
 
 static int check_common(int N, int64_t n_isects, int D, int mode, int layout, int width, int height,
                         int tile_size, int tile_w, int tile_h, const char* who) {
-    if (N < 0 || n_isects < 0 || width <= 0 || height <= 0) return fail_arg(who);
+    if (N < 0 || n_isects < -1 || width <= 0 || height <= 0) return fail_arg(who);
     if (tile_size != TILE) { set_error(who, "only tile_size 16 is built"); return GSPL_ERR_UNSUPPORTED; }
     if (tile_w != (width + TILE - 1) / TILE || tile_h != (height + TILE - 1) / TILE) return fail_arg(who);
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg(who);
@@ -1498,7 +1499,7 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
     int rc = check_common(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_fwd: bad argument");
     if (rc != GSPL_OK) return rc;
     if (!offsets || !out_colors || !out_alphas || !final_Ts || !last_ids) return fail_arg("composite_fwd: NULL required pointer");
-    if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return fail_arg("composite_fwd: NULL required pointer");
+    if (n_isects != 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return fail_arg("composite_fwd: NULL required pointer");
     const int n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream;
     rc = GSPL_ERR_UNSUPPORTED;

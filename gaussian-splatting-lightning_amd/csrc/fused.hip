@@ -41,7 +41,7 @@ static ImageLayout image_layout(size_t pixels, size_t tiles) {
     ImageLayout m;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off = up256(off + b); return o; };
-    m.alphas = take(4 * pixels); m.final_Ts = take(4 * pixels); m.last_ids = take(4 * pixels); m.offsets = take(4 * tiles);
+    m.alphas = take(4 * pixels); m.final_Ts = take(4 * pixels); m.last_ids = take(4 * pixels); m.offsets = take(4 * (tiles + 1));
     m.total = off;
     return m;
 }
@@ -223,8 +223,29 @@ extern "C" int gspl_rasterize_inria_fwd(
                                    capacity, ws2, ws2_bytes, s);
                 if (rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return rc; }
             }
-            (void)hipEventSynchronize(ev_cnt);
-            n_isects = host[0];
+            if (ws2) {
+                // The host does not wait for the list length: the sort reads it on the device (the grid is sized by `capacity`), the
+                // compositing kernel finds the end of the last list in offsets[n_tiles].  The number is looked at AFTER everything is
+                // enqueued — by then the scan has long finished — and only a guess that turns out too low costs a second round.
+                st->flatten_ids = (int32_t*)alloc(alloc_ctx, GSPL_BUF_LISTS, 4 * (size_t)capacity);
+                if (!st->flatten_ids) { (void)hipEventSynchronize(ev_cnt); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+                rc = gspl_bin_sort_device_count(N, tile_w, tile_h, cum + (N - 1), capacity, st->flatten_ids, st->offsets, ws2, ws2_bytes, s);
+                if (rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return rc; }
+                if (ev_col) (void)hipStreamWaitEvent(s, ev_col, 0);      // colours are ready before compositing reads them
+                {
+                    ProfScope prof(0, s);
+                    rc = gspl_composite_fwd(N, -1, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height,
+                                            tile, tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
+                }
+                (void)hipEventSynchronize(ev_cnt);
+                n_isects = host[0];
+                if (rc != GSPL_OK) return rc;
+                if (n_isects <= capacity) { st->n_isects = n_isects; return GSPL_OK; }
+                ws2 = nullptr;                                  // too low a guess: the frame is redone below with the real length
+            } else {
+                (void)hipEventSynchronize(ev_cnt);
+                n_isects = host[0];
+            }
             if (n_isects > 0 && (!ws2 || capacity < n_isects)) {
                 capacity = n_isects;
                 ws2_bytes = gspl_bin_workspace_bytes(N, capacity);

@@ -67,8 +67,9 @@ int radix_sort_u32(const RadixPlan& plan, void* workspace, uint32_t* const keys[
 int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], uint32_t* const vals[2], bool prepared, void* stream);
 // Tile sort of the binning: records (tile id << 32 | splat id) sorted on plan's bits (inside the high word); the sorted low
 // words land in ids_out, tile_counts[0, n_tile_counts) receives the number of records per tile id (plan.passes >= 2).
+// n_dev (nullable): the number of records lives on the device (<= plan.n, which sizes the grid): the host need not know it.
 int radix_sort_tiles(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], bool prepared, uint32_t* ids_out,
-                     uint32_t* tile_counts, uint32_t n_tile_counts, void* stream);
+                     uint32_t* tile_counts, uint32_t n_tile_counts, void* stream, const int64_t* n_dev = nullptr);
 int tile_offsets_from_counts(uint32_t* counts, uint32_t n, void* stream);      // exclusive prefix, in place, one workgroup
 // Exclusive scan of n u32 (n < 2^32; three launches; workspace: exclusive_scan_u32_workspace_bytes(n), 4-byte aligned).
 size_t exclusive_scan_u32_workspace_bytes(size_t n);

@@ -59,8 +59,14 @@ __device__ __forceinline__ void scan256_excl(const uint32_t* src, uint32_t* dst)
 // ---- count: counts[g][digit] = items of workgroup g's tile range whose digit of this pass is `digit`; groups[g / 32][digit] += ----
 template <typename KeyT, int IPT>
 __global__ __launch_bounds__(RS_THREADS) void radix_count_kernel(const KeyT* __restrict__ keys, uint32_t n, uint32_t ntiles, uint32_t tiles_per_wg,
-                                                                 int shift, int nbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ groups) {
+                                                                 int shift, int nbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ groups,
+                                                                 const int64_t* __restrict__ n_dev) {
     constexpr uint32_t TILE = RS_THREADS * IPT;
+    if (n_dev) {      // the item count lives on the device (<= the n the grid was sized for): workgroups past it find empty ranges
+        const int64_t m = *n_dev;
+        n = (uint32_t)(m < 0 ? 0 : (m < (int64_t)n ? m : (int64_t)n));
+        ntiles = (n + TILE - 1u) / TILE;
+    }
     __shared__ uint32_t cnt[RS_WAVES][RADIX_BINS];      // per-wave counters: no inter-wave contention on hot digits
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const uint32_t mask = (1u << nbits) - 1u;
@@ -141,8 +147,13 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
                                                                    uint32_t ntiles, uint32_t tiles_per_wg, int shift, int nbits,
                                                                    const uint32_t* __restrict__ groups, const uint32_t* __restrict__ counts,
                                                                    uint32_t* __restrict__ aux, uint32_t aux_zero,
-                                                                   const uint32_t* __restrict__ gather) {
+                                                                   const uint32_t* __restrict__ gather, const int64_t* __restrict__ n_dev) {
     constexpr uint32_t TILE = RS_THREADS * IPT;
+    if (n_dev) {      // see radix_count_kernel
+        const int64_t m = *n_dev;
+        n = (uint32_t)(m < 0 ? 0 : (m < (int64_t)n ? m : (int64_t)n));
+        ntiles = (n + TILE - 1u) / TILE;
+    }
     __shared__ RadixShared<KeyT, VALUES, IPT> sh;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const uint32_t mask = (1u << nbits) - 1u;
@@ -404,7 +415,7 @@ void radix_producer_args(const RadixPlan& plan, void* workspace, RadixProducer& 
 template <typename KeyT, int IPT>
 static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const keys[2], uint32_t* const vals[2], bool prepared, void* stream,
                            uint32_t* final_ids = nullptr, uint32_t* tile_counts = nullptr, uint32_t n_tile_counts = 0,
-                           const uint32_t* gather = nullptr) {
+                           const uint32_t* gather = nullptr, const int64_t* n_dev = nullptr) {
     if (plan.n == 0) return GSPL_OK;
     if (plan.tile_items != (uint32_t)(RS_THREADS * IPT)) return fail_arg("radix_sort: plan made for another tile size");
     if (plan.nwg > plan.wg_cap) return fail_arg("radix_sort: plan replanned for more items than its tables hold");
@@ -423,13 +434,13 @@ static int radix_sort_impl(const RadixPlan& plan, void* workspace, KeyT* const k
         uint32_t* counts = (uint32_t*)(ws + ((p == 0 && prepared) ? plan.counts0_off : plan.counts_off));
         if (!(p == 0 && prepared))
             hipLaunchKernelGGL((radix_count_kernel<KeyT, IPT>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, plan.n, plan.ntiles, plan.tiles_per_wg,
-                               plan.shift[p], plan.bits[p], counts, groups);
+                               plan.shift[p], plan.bits[p], counts, groups, n_dev);
         const bool last = p == plan.passes - 1;
         uint32_t* aux = final_ids ? tile_counts : nullptr;
         const uint32_t aux_zero = (final_ids && p == plan.passes - 2) ? n_tile_counts : 0u;
 #define GSPL_SCATTER(VALUES, FINAL, VIN, VOUT)                                                                                              \
         hipLaunchKernelGGL((radix_scatter_kernel<KeyT, VALUES, IPT, FINAL>), dim3(plan.nwg), dim3(RS_THREADS), 0, s, kin, VIN, kout, VOUT, plan.n, \
-                           plan.ntiles, plan.tiles_per_wg, plan.shift[p], plan.bits[p], groups, counts, aux, aux_zero, gather)
+                           plan.ntiles, plan.tiles_per_wg, plan.shift[p], plan.bits[p], groups, counts, aux, aux_zero, gather, n_dev)
         if (final_ids && last) {
             if constexpr (sizeof(KeyT) == 8) GSPL_SCATTER(false, FINAL_TILES, nullptr, final_ids);
         } else if (gather && last) {
@@ -458,9 +469,10 @@ int radix_sort_u64(const RadixPlan& plan, void* workspace, uint64_t* const keys[
 // to `ids_out`, `tile_counts[0, n_tile_counts)` receives the number of records of every tile id.  plan.passes >= 2 (the pass
 // before the last clears the counters).
 int radix_sort_tiles(const RadixPlan& plan, void* workspace, uint64_t* const keys[2], bool prepared, uint32_t* ids_out,
-                     uint32_t* tile_counts, uint32_t n_tile_counts, void* stream) {
+                     uint32_t* tile_counts, uint32_t n_tile_counts, void* stream, const int64_t* n_dev) {
     if (plan.passes < 2) return fail_arg("radix_sort_tiles: at least two passes");
-    return radix_sort_impl<uint64_t, RADIX_TILE_U64 / RS_THREADS>(plan, workspace, keys, nullptr, prepared, stream, ids_out, tile_counts, n_tile_counts);
+    return radix_sort_impl<uint64_t, RADIX_TILE_U64 / RS_THREADS>(plan, workspace, keys, nullptr, prepared, stream, ids_out, tile_counts, n_tile_counts,
+                                                                  nullptr, n_dev);
 }
 
 // counts[0, n) (u32) -> exclusive prefix in place.  One workgroup: n is the number of image tiles (8160 at 1080p) or of scan blocks.

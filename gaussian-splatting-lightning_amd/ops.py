@@ -1180,7 +1180,7 @@ class _InriaFusedFn(torch.autograd.Function):
         ctx.means2D_ref = means2D
         if KEEP_LAST_RASTER:
             global LAST_RASTER
-            geom, lists = holder[L.GSPL_BUF_GEOMETRY][0], holder.get(L.GSPL_BUF_LISTS, [None])[0]
+            geom, lists = holder[L.GSPL_BUF_GEOMETRY][0], holder.get(L.GSPL_BUF_LISTS, [None])[-1]
             img = holder[L.GSPL_BUF_IMAGE][0]
             nI = int(state.n_isects)
             LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=_view(geom, state.means2d, (N, 2), torch.float32),

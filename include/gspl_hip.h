@@ -234,6 +234,12 @@ int gspl_bin_emit(int N, int mode, const float* means2d, const int32_t* radii,
                   void* workspace, size_t workspace_bytes, void* stream);
 int gspl_bin_sort(int N, int tile_w, int tile_h, int64_t n_isects, int64_t capacity,
                   int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for a host that has not read the list length back yet: it stays on the device (n_isects_dev = &cum_tiles[N - 1]), the
+ * sort's grid is sized by `capacity`.  flatten_ids: room for `capacity` ids; offsets: tile_w * tile_h + 1 entries, the last one
+ * receives the list length — the compositing entry points take n_isects = -1 with such an array.  The caller compares the
+ * length with `capacity` once it has it (gspl_bin_count's host_counts) and repeats emission and sort when the guess was too low. */
+int gspl_bin_sort_device_count(int N, int tile_w, int tile_h, const int64_t* n_isects_dev, int64_t capacity,
+                               int32_t* flatten_ids, int32_t* offsets, void* workspace, size_t workspace_bytes, void* stream);
 /* Sorts and scans of this library are in-tree kernels (csrc/sort.hip): every radix pass is count -> digit-row scan -> scatter
  * over contiguous tile ranges, the scans are block sums -> scan of the sums -> per-block scan.  No workgroup waits for another,
  * so they make progress under any dispatch order and contention, and their output is bit-reproducible. */

@@ -649,6 +649,40 @@ def test_inria_api_precomputed_cov3d_and_colors_and_scale_modifier(hip):
                                                                     scales=s3, rotations=q3)
 
 
+def test_fused_inria_device_side_list_length_and_guesses(hip):
+    """The fused Inria call (gspl_rasterize_inria_fwd) launches emission, sort and compositing BEFORE the host has the list length:
+    the sort reads it on the device, sized by a guess from the last frame.  Frames whose guess is far too low (the frame is
+    redone), about right, and far too high must all equal the staged path (which waits for the length) bit for bit — image, radii
+    and every gradient (the backward is atomics-ordered: compared to the spread the staged path shows against itself)."""
+    if not hip.FUSED_INRIA:
+        pytest.skip("GSPL_FUSED_INRIA=0")
+    small = _e2e_scene(n=500, seed=41)
+    big = _e2e_scene(n=9000, seed=42)
+
+    def render(scene, fused):
+        means, scales, quats, opac, shs, cam, wimg, bg = scene
+        W, H = cam["width"], cam["height"]
+        saved = hip.FUSED_INRIA
+        hip.FUSED_INRIA = fused
+        try:
+            leaves = [t.requires_grad_(True) for t in _cuda(means, scales * (6.0 if scene is big else 1.0), quats, opac, shs)]
+            m, sc, q, o, c = leaves
+            img, radii = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, W, H))(
+                means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, shs=c, scales=sc, rotations=q)
+            (img * wimg.to(_dev())).sum().backward()
+            return img.detach(), radii, [t.grad for t in leaves]
+        finally:
+            hip.FUSED_INRIA = saved
+
+    ref = {id(sc): render(sc, False) for sc in (small, big)}
+    for sc in (small, big, big, small, small):          # guesses: none, far too low, right, far too high, right
+        img, radii, grads = render(sc, True)
+        r_img, r_radii, r_grads = ref[id(sc)]
+        assert torch.equal(img, r_img) and torch.equal(radii, r_radii)
+        for g, rg in zip(grads, r_grads):
+            assert float((g - rg).abs().max()) <= 2e-5 * max(1.0, float(rg.abs().max()))
+
+
 def test_degenerate_inputs(hip):
     """Everything behind the camera, a single huge splat covering the whole image, image smaller than a tile."""
     d = _dev()
