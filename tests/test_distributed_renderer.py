@@ -25,10 +25,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 N_SPLATS, W_IMG, H_IMG = 3000, 208, 144
 
 
-def _cameras():
+def _cameras(world=2):
     from oracle import gsplat_oracle as O
     cams = []
-    for i, (t, f) in enumerate((((0.0, 0.0, 4.0), 190.0), ((0.35, -0.2, 3.4), 205.0))):
+    poses = (((0.0, 0.0, 4.0), 190.0), ((0.35, -0.2, 3.4), 205.0), ((-0.3, 0.25, 4.6), 180.0), ((0.1, 0.3, 3.8), 198.0))
+    for i, (t, f) in enumerate(poses[:world]):
         cam = O.synthetic_camera(W_IMG, H_IMG, f, f + 3.0)
         w2c = cam["world_to_camera"].clone()
         w2c[3, :3] = torch.tensor(t)
@@ -46,9 +47,9 @@ def _scene(dtype):
     return [t.to(dtype) for t in (means, scales, quats, opac, shs)]
 
 
-def _weights(dtype):
+def _weights(dtype, world=2):
     g = torch.Generator().manual_seed(3)
-    return [torch.randn(3, H_IMG, W_IMG, generator=g).to(dtype) for _ in range(2)]
+    return [torch.randn(3, H_IMG, W_IMG, generator=g).to(dtype) for _ in range(world)]
 
 
 def _install_oracle_ops():
@@ -169,7 +170,7 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         if not on_gpu:
             _install_oracle_ops()
         params = _scene(dtype)
-        cams, weights = _cameras(), _weights(dtype)
+        cams, weights = _cameras(world), _weights(dtype, world)
         bg = torch.tensor([0.2, 0.1, 0.4], dtype=dtype)
         N = params[0].shape[0]
         lo, hi = D.shard_bounds(N, world, rank)
@@ -200,7 +201,7 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         out = renderer(camset[rank], model, bg.to(dev))
         assert set(out) == {"render", "hard_inverse_depth", "cameras", "projection_results_list", "visible_mask_list", "xys_grad_scale_required"}
         assert out["render"].shape == (3, H_IMG, W_IMG) and len(out["cameras"]) == world and out["xys_grad_scale_required"] is True
-        assert [int(c.idx) for c in out["cameras"]] == [0, 1]
+        assert [int(c.idx) for c in out["cameras"]] == list(range(world))
         for r in out["projection_results_list"]:          # what DistributedVanillaDensityControllerImpl.before_backward does
             r[1].retain_grad()
         (out["render"] * weights[rank].to(dev)).sum().backward()
@@ -285,7 +286,9 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         # the rebalanced shards still render the same image
         with torch.no_grad():
             again = renderer(camset[rank], model, bg.to(dev))["render"]
-        assert float((again.cpu() - ref_renders[rank]).abs().max()) <= (2e-5 if on_gpu else 1e-9)
+        # (the rows are permuted now: splats whose depths agree to the 32 bits of the sort key change their order — ties are broken
+        # by row index, as in the reference — which moves single pixels by ~1e-7 even in the fp64 CPU variant)
+        assert float((again.cpu() - ref_renders[rank]).abs().max()) <= (2e-5 if on_gpu else 2e-6), float((again.cpu() - ref_renders[rank]).abs().max())
 
         # ---- after_training_step honours interval / until / threshold
         renderer.config.redistribute_interval, renderer.config.redistribute_until = 10, 100
@@ -304,14 +307,20 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         dist.destroy_process_group()
 
 
-def _run(tmp_path, on_gpu):
-    port = 29900 + (os.getpid() % 300) + (50 if on_gpu else 0)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), on_gpu), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+def _run(tmp_path, on_gpu, world=2):
+    port = 29900 + (os.getpid() % 300) + (50 if on_gpu else 0) + 7 * world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), on_gpu), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
 def test_world2_sharded_renderer_cpu_oracle_ops(tmp_path):
     _run(tmp_path, False)
+
+
+def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
+    """Three ranks: uneven shards (3000 = 1000 + 1000 + 1000 here, but the random redistribution leaves uneven ones), three
+    cameras per projection batch, three-way all-to-all."""
+    _run(tmp_path, False, world=3)
 
 
 @pytest.mark.gpu
