@@ -399,8 +399,15 @@ def main():
             with torch.no_grad():
                 stats(st, accum, denom, max_radii)
                 if optimizer is not None:
+                    if mode == "replicated" and opt_kind == "fused-adam":
+                        # replicas stay identical: the parameter gradients are averaged over the ranks (DDP of configs/ddp.yaml) in
+                        # chunks, and every chunk is updated by the fused Adam while the next ones are still being reduced
+                        gdist.all_reduce_and_step(optimizer, tensors)
+                        counter["n"] += 1
+                        if force_reduce or counter["n"] % DENSIFY_INTERVAL == 0:
+                            gdist.reduce_densification_stats(accum, denom, max_radii)
+                        return st
                     if mode == "replicated":
-                        # replicas stay identical: average the parameter gradients over the ranks (DDP of configs/ddp.yaml)
                         gdist.all_reduce_gradients(tensors)
                     if opt_kind == "selective-adam" and "radii" in st:
                         optimizer.step(st["radii"] > 0)
@@ -530,7 +537,7 @@ def main():
                      + (" + gradient all-reduce" if mode == "replicated" and args.optimizer != "none" else "")
                      + ("" if args.optimizer == "none" else " + " + args.optimizer + " step") + " + densification stats")
         par = {"single": "single GPU",
-               "replicated": f"replicated Gaussians, {world} camera(s)/step, all-reduce of parameter gradients every step and of the densification stats every {DENSIFY_INTERVAL} steps",
+               "replicated": f"replicated Gaussians, {world} camera(s)/step, chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step, all-reduce of the densification stats every {DENSIFY_INTERVAL} steps",
                "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of visible-splat records (configs/distributed.yaml)"}[mode]
         line = {
             "metric": "training images/sec + fwd/bwd ms @1080p, 1M Gaussians, 1/2/4/8 MI355X",

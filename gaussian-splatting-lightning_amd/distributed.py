@@ -149,6 +149,42 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
         torch._foreach_mul_(grads, 1.0 / world)
 
 
+def all_reduce_and_step(optimizer, params: Iterable[torch.Tensor], group=None, chunk_bytes: int = 48 << 20) -> None:
+    """Replicated-Gaussian mode, gradient exchange OVERLAPPED with the optimizer: the gradient rows of every parameter go out as
+    all-reduces of at most `chunk_bytes` each (all enqueued at once, smallest tensors first, so RCCL keeps the xGMI links busy
+    back to back), and as soon as one chunk is reduced the fused Adam updates exactly those rows — while the collectives of the
+    following chunks are still on the wire.  Same result as `all_reduce_gradients` + `optimizer.step()` (averaged gradients,
+    one step count per parameter); needs an optimizer with `begin_chunked_step` / `step_rows` (gspl_amd.optimizers.FusedAdam)."""
+    params = [p for p in params if p.grad is not None]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        optimizer.step()
+        return
+    world = dist.get_world_size(group)
+    ready = optimizer.begin_chunked_step()
+    rccl = is_rccl(group)
+    chunks = []
+    for p in sorted(params, key=lambda t: t.numel()):
+        n = p.shape[0]
+        row_bytes = max(p.numel() // max(n, 1), 1) * p.element_size()
+        rows = max(4, (chunk_bytes // row_bytes) // 4 * 4)      # multiples of four rows: every chunk starts 16-byte aligned
+        rows = min(n, rows)
+        for lo in range(0, n, rows):
+            hi = min(n, lo + rows)
+            g = p.grad[lo:hi]                                   # a contiguous view: reduced in place
+            if rccl:
+                work = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=group, async_op=True)
+                chunks.append((work, None, p, lo, hi))
+            else:                                               # gloo (tests on one shared GPU): host staged, summed then scaled
+                wire = g.cpu()
+                work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True)
+                chunks.append((work, wire, p, lo, hi))
+    for work, wire, p, lo, hi in chunks:
+        work.wait()                                             # RCCL: the current stream waits, the host does not
+        if wire is not None:
+            p.grad[lo:hi].copy_(wire.to(p.device, non_blocking=False)).mul_(1.0 / world)
+        optimizer.step_rows(ready, p, lo, hi)
+
+
 def redistribute_rows(local: torch.Tensor, destination: torch.Tensor, group=None, recv_counts: Optional[List[int]] = None) -> torch.Tensor:
     """Move row i of `local` to rank destination[i] (random rebalancing, gsplat_distributed_renderer.py:440-510):
     one all-to-all per tensor with rows grouped by destination (rows keep their relative order per source)."""

@@ -35,31 +35,23 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 raise NotImplementedError(f"fused Adam: {k}=True is not implemented")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
-    def _launch(self, visibility: Optional[torch.Tensor]):
-        L.lib()
-        # tensors are batched per (N, betas, eps, step count): the reference has one parameter per group, all [N, ...]
-        batches = {}
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("fused Adam: parameters must be contiguous fp32 tensors on the GPU")
-                if p.grad.is_sparse:
-                    raise RuntimeError("fused Adam: sparse gradients are not supported")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                # a state loaded from a `torch.optim.Adam` checkpoint keeps `step` as a tensor: a python int from here on
-                st["step"] = int(st["step"]) + 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                N = p.shape[0] if p.dim() > 0 else 1
-                row = p.numel() // max(N, 1)
-                key = (p.device, N, b1, b2, group["eps"], st["step"] if self._bias_correction else 0)
-                batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), row))
+    def _prepare(self, p, group):
+        """State of one parameter with its step counter advanced (once per optimizer step)."""
+        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+            raise RuntimeError("fused Adam: parameters must be contiguous fp32 tensors on the GPU")
+        if p.grad.is_sparse:
+            raise RuntimeError("fused Adam: sparse gradients are not supported")
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        # a state loaded from a `torch.optim.Adam` checkpoint keeps `step` as a tensor: a python int from here on
+        st["step"] = int(st["step"]) + 1
+        return st
+
+    def _run(self, batches, visibility: Optional[torch.Tensor]):
+        """batches: {(device, rows, b1, b2, eps, step): [(param, grad, exp_avg, exp_avg_sq, lr, row_elems), ...]} -> launches."""
         for (dev, N, b1, b2, eps, step), items in batches.items():
             vis = None
             if visibility is not None:
@@ -78,6 +70,51 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 with torch.cuda.device(dev):
                     L.call("gspl_selective_adam", len(chunk), ctypes.cast(table, ctypes.c_void_p), N, L.ptr(vis),
                            float(b1), float(b2), float(eps), float(bc1), float(bc2s), L.stream())
+
+    def _launch(self, visibility: Optional[torch.Tensor]):
+        L.lib()
+        # tensors are batched per (N, betas, eps, step count): the reference has one parameter per group, all [N, ...]
+        batches = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self._prepare(p, group)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                N = p.shape[0] if p.dim() > 0 else 1
+                row = p.numel() // max(N, 1)
+                key = (p.device, N, b1, b2, group["eps"], st["step"] if self._bias_correction else 0)
+                batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), row))
+        self._run(batches, visibility)
+
+    # ---- the same update in ROW CHUNKS (multi-GPU: a chunk is updated as soon as the all-reduce of its gradient rows has
+    #      finished, while the collectives of the following chunks are still on the wire; distributed.all_reduce_and_step) ----
+    @torch.no_grad()
+    def begin_chunked_step(self):
+        """Advances the step counters of every parameter that has a gradient; returns {parameter: (group, state)}."""
+        L.lib()
+        ready = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.grad.is_contiguous():
+                    raise RuntimeError("fused Adam (chunked): gradients must be contiguous")
+                ready[p] = (group, self._prepare(p, group))
+        return ready
+
+    @torch.no_grad()
+    def step_rows(self, ready, p, lo: int, hi: int):
+        """Adam update of rows [lo, hi) of parameter `p` (after `begin_chunked_step`)."""
+        if hi <= lo:
+            return
+        group, st = ready[p]
+        b1, b2 = group["betas"]
+        row = p.numel() // max(p.shape[0], 1)
+        key = (p.device, hi - lo, b1, b2, group["eps"], st["step"] if self._bias_correction else 0)
+        item = (p[lo:hi], p.grad[lo:hi], st["exp_avg"][lo:hi], st["exp_avg_sq"][lo:hi], float(group["lr"]), row)
+        self._run({key: [item]}, None)
 
 
 class SelectiveAdam(_FusedAdamBase):
