@@ -99,8 +99,8 @@ class _FusedAdamBase(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                if not p.grad.is_contiguous():
-                    raise RuntimeError("fused Adam (chunked): gradients must be contiguous")
+                if not p.grad.is_contiguous():          # (row chunks are reduced and consumed in place)
+                    p.grad = p.grad.contiguous()
                 ready[p] = (group, self._prepare(p, group))
         return ready
 
