@@ -212,6 +212,27 @@ class HipGSplatV1RendererModule(Renderer):
             outputs["hard_inverse_depth"] = outputs["inv_depth_alt"] = im
         return outputs
 
+    def setup_web_viewer_tabs(self, viewer, server, tabs):
+        """The two run-time options of the reference's viewer tab (gsplat_v1_renderer.py:350-352, 615-661): a "Radius Clip" number
+        and a "Camera Model" drop-down that write `runtime_options` and ask the viewer to render again.  `server` is the viewer's
+        viser server (only its `gui.add_number` / `gui.add_dropdown` are used; viser itself is not imported here)."""
+        options = self.runtime_options
+        with tabs.add_tab("gsplat"):
+            clip = server.gui.add_number(label="Radius Clip", initial_value=options.radius_clip, step=0.1, min=0., max=65535.)
+            model = server.gui.add_dropdown(label="Camera Model", options=["pinhole", "ortho", "fisheye"], initial_value=options.camera_model)
+
+        @clip.on_update
+        def _(_):
+            options.radius_clip = clip.value
+            viewer.rerender_for_all_client()
+
+        @model.on_update
+        def _(_):
+            options.camera_model = model.value
+            viewer.rerender_for_all_client()
+
+        self._viewer_options = (clip, model)
+
     def get_available_outputs(self):
         g = RendererOutputTypes.GRAY
         return {

@@ -70,3 +70,59 @@ def test_renderer_plugins_importable_and_picklable():
     from gspl_amd.renderers import GSplatV1
     culling = HipGSplatV1Renderer(tile_based_culling=True).instantiate()
     assert culling.isect_encode == GSplatV1.isect_encode_tile_based_culling and mod.isect_encode == GSplatV1.isect_encode_lists_only
+
+
+def test_v1_renderer_viewer_tab_writes_the_runtime_options():
+    """`setup_web_viewer_tabs` (Renderer plugin API, reference gsplat_v1_renderer.py:350-352,615-661) against a stand-in for the
+    viser server: the two controls exist with the reference's labels and ranges, and their callbacks update `runtime_options`
+    and ask for a re-render."""
+    import contextlib
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatV1Renderer
+
+    class Control:
+        def __init__(self, **kw):
+            self.kw, self.value, self.cb = kw, kw["initial_value"], None
+
+        def on_update(self, fn):
+            self.cb = fn
+            return fn
+
+    class Gui:
+        def __init__(self):
+            self.controls = {}
+
+        def add_number(self, **kw):
+            self.controls[kw["label"]] = Control(**kw)
+            return self.controls[kw["label"]]
+
+        def add_dropdown(self, **kw):
+            self.controls[kw["label"]] = Control(**kw)
+            return self.controls[kw["label"]]
+
+    class Server:
+        gui = Gui()
+
+    class Tabs:
+        names = []
+
+        def add_tab(self, name):
+            self.names.append(name)
+            return contextlib.nullcontext()
+
+    class Viewer:
+        rerenders = 0
+
+        def rerender_for_all_client(self):
+            Viewer.rerenders += 1
+
+    renderer = HipGSplatV1Renderer().instantiate()
+    renderer.setup_web_viewer_tabs(Viewer(), Server(), Tabs())
+    assert Tabs.names == ["gsplat"]
+    clip, model = Server.gui.controls["Radius Clip"], Server.gui.controls["Camera Model"]
+    assert clip.kw["min"] == 0. and clip.kw["max"] == 65535. and model.kw["options"] == ["pinhole", "ortho", "fisheye"]
+    clip.value = 2.5
+    clip.cb(None)
+    model.value = "fisheye"
+    model.cb(None)
+    assert renderer.runtime_options.radius_clip == 2.5 and renderer.runtime_options.camera_model == "fisheye" and Viewer.rerenders == 2
