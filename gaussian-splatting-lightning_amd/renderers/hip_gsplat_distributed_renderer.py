@@ -135,12 +135,16 @@ class HipGSplatDistributedRendererImpl(Renderer):
         radii, means2d, depths, conics, comps = ops.fully_fused_projection(
             pc.get_means(), None, pc.get_rotations(), scales, viewmats=viewmats, Ks=Ks, width=W, height=H,
             eps2d=self.config.filter_2d_kernel_size, calc_compensations=True, packed=False)
-        rgbs = ops.sh_view_colors_batched(pc.active_sh_degree, pc.get_xyz, centers, pc.get_shs_dc(), pc.get_shs_rest(), radii)
         vis = radii > 0
         # per-camera views whose backward passes a batched gradient through (no zero fill + copy per slice)
-        m2, dep, con, cmp_, col = (ops.unbind_cameras(t) for t in (means2d, depths, conics, comps, rgbs))
+        m2, dep, con, cmp_ = (ops.unbind_cameras(t) for t in (means2d, depths, conics, comps))
         results = [(radii[i], m2[i], dep[i], con[i], cmp_[i], vis[i]) for i in range(len(cameras))]
-        return results, list(col)
+        if type(self).get_rgbs is HipGSplatDistributedRendererImpl.get_rgbs:
+            rgbs = ops.sh_view_colors_batched(pc.active_sh_degree, pc.get_xyz, centers, pc.get_shs_dc(), pc.get_shs_rest(), radii)
+            return results, list(ops.unbind_cameras(rgbs))
+        # a subclass supplies its own colours (the reference's appearance-embedding renderer overrides `get_rgbs`,
+        # gsplat_distributed_appearance_embedding_renderer.py:67-84): per camera, as the reference calls it (:308)
+        return results, [self.get_rgbs(pc, cam, r) for cam, r in zip(cameras, results)]
 
     def _camera_batch(self, cameras, device):
         """Stacked view matrices [W,4,4], intrinsics [W,3,3] and centres [W,3] of a camera set, built once per set: a training
@@ -168,11 +172,13 @@ class HipGSplatDistributedRendererImpl(Renderer):
                 eps2d=self.config.filter_2d_kernel_size, anti_aliased=True)
             r = (radii[0], means2d[0], depths[0], conics[0], comps[0], radii[0] > 0)
             results.append(r)
-            rgbs.append(self.get_rgbs(pc, cam, r[-1]))
+            rgbs.append(self.get_rgbs(pc, cam, r))
         return results, rgbs
 
-    def get_rgbs(self, pc, camera, visibility):
-        return ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, camera.camera_center, pc.get_shs_dc(), pc.get_shs_rest(), visibility)
+    def get_rgbs(self, pc, camera, projection_results):
+        """Colours of the local splats for one camera (reference :416-421); `projection_results[-1]` is the visibility mask."""
+        return ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, camera.camera_center, pc.get_shs_dc(), pc.get_shs_rest(),
+                                  projection_results[-1])
 
     def forward(self, viewpoint_camera, pc, bg_color: torch.Tensor, scaling_modifier=1.0, render_types: list = None, **kwargs):
         if render_types is None:

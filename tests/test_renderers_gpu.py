@@ -234,6 +234,30 @@ def test_distributed_renderer_world1_matches_v1():
     assert xys.grad is not None and xys.grad.shape == (params[0].shape[0], 2)
 
 
+def test_distributed_renderer_subclass_colours_are_used():
+    """A subclass that overrides `get_rgbs(pc, camera, projection_results)` — the reference's appearance-embedding variant does
+    (gsplat_distributed_appearance_embedding_renderer.py:67-84) — supplies the colours in batched mode too, and its colours take
+    part in autograd."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatDistributedRenderer, HipGSplatDistributedRendererImpl
+    params, cam, wimg, bg = _scene(seed=35, n=3000)
+    model = FakeGaussianModel(*[p.to(DEV) for p in params])
+    tint = torch.tensor([0.9, 0.2, 0.1], device=DEV, requires_grad=True)
+    calls = []
+
+    class Tinted(HipGSplatDistributedRendererImpl):
+        def get_rgbs(self, pc, camera, projection_results):
+            calls.append(projection_results[-1].shape)
+            base = HipGSplatDistributedRendererImpl.get_rgbs(self, pc, camera, projection_results)
+            return base * tint
+
+    plain = HipGSplatDistributedRenderer().instantiate()(FakeCamera(cam, DEV), model, bg.to(DEV))["render"].detach()
+    out = Tinted(HipGSplatDistributedRenderer())(FakeCamera(cam, DEV), model, bg.to(DEV))["render"]
+    assert calls == [(3000,)] and float((out[1] - plain[1]).abs().max()) > 0.05      # green channel scaled by 0.2
+    out.sum().backward()
+    assert tint.grad is not None and float(tint.grad.abs().sum()) > 0
+
+
 def test_concurrent_streams_are_reentrant():
     """The viewer situation (SURVEY §8b threads/streams): several host threads, each on its own stream, render concurrently
     under no_grad.  Every frame must equal the single-thread frame bit for bit (scratch is per call; the sort and scan kernels of
