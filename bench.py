@@ -77,6 +77,9 @@ def parse():
     p.add_argument("--cpu-sample", default="auto", help="workload name for the CPU baseline leg, or 'auto'")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (code-path test on one GPU)")
     p.add_argument("--share-device", action="store_true", help="testing only: every rank uses cuda:0")
+    p.add_argument("--init-dist", action="store_true",
+                   help="testing only: with --gpus 1, create a process group of ONE rank and issue every collective of the chosen "
+                        "--parallelism anyway (the RCCL code paths on a one-GPU machine)")
     return p.parse_args()
 
 
@@ -294,9 +297,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.init_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -312,6 +316,8 @@ def main():
     from gspl_amd import distributed as gdist
     from gspl_amd.density import update_densification_stats
     _lib.lib()
+    if args.init_dist:
+        gdist.SINGLE_RANK_SHORTCUT = False
     wl = synthetic.WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
     means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
@@ -435,6 +441,10 @@ def main():
         gc.freeze()
         if dist is not None:
             dist.barrier()
+            # RCCL writes its version banner through C stdio, which on a pipe would come out at exit, AFTER the JSON line:
+            # push it out now, so that the line rank 0 prints stays the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         torch.cuda.synchronize()
         step.state["marks"] = []
         # the roofline needs the launch duration of the graded kernel from HIP events on its stream; an event pair idles the stream
@@ -546,7 +556,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "api": api, "n_gaussians": wl["n"], "width": W, "height": H,
                        "sh_degree": 3, "loss": args.loss, "optimizer": args.optimizer, "step": step_desc,
-                       "parallelism": par, "parallelism_mode": mode},
+                       "parallelism": par, "parallelism_mode": mode,
+                       **({"init_dist": f"process group of one rank on {args.dist_backend}: every collective of this mode is issued (code-path run, not a scaling point)"}
+                          if args.init_dist else {})},
             "images_per_s_with_optimizer": round(world * args.steps / elapsed, 3) if args.optimizer != "none" else None,
             "images_per_s_renderer_only": (renderer_only["images_per_s"] if renderer_only else
                                            (round(world * args.steps / elapsed, 3) if args.optimizer == "none" else None)),

@@ -26,6 +26,15 @@ import torch
 import torch.distributed as dist
 
 RECORD_FLOATS = 12     # 48 B per visible splat
+# A group of one rank needs no exchange and the reductions below return at once.  False makes them issue their collectives
+# anyway: how tests/test_rccl_single_rank.py and `bench.py --init-dist` drive the RCCL code paths on a one-GPU machine.
+SINGLE_RANK_SHORTCUT = True
+
+
+def _nothing_to_exchange(group) -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return SINGLE_RANK_SHORTCUT and dist.get_world_size(group) == 1
 
 
 def shard_bounds(n_gaussians: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -125,7 +134,7 @@ def exchange_visible_splats(records_per_camera: Sequence[torch.Tensor], group=No
 def reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor, group=None):
     """Replicated-Gaussian mode: make the densification statistics identical on every rank
     (buffers of VanillaDensityControllerImpl, internal/density_controllers/vanilla_density_controller.py:60-67)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _nothing_to_exchange(group):
         return
     dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group)
@@ -136,11 +145,9 @@ def all_reduce_gradients(params: Iterable[torch.Tensor], group=None, average: bo
     """Replicated-Gaussian mode: sum (or average) `p.grad` of every parameter over the ranks, in place — what DDP does for
     the reference's `configs/ddp.yaml`.  One collective per parameter tensor (five or six large tensors: each is its own
     bucket), all in flight before the first wait, so RCCL pipelines them over the xGMI links."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if _nothing_to_exchange(group):
         return
     world = dist.get_world_size(group)
-    if world == 1:
-        return
     grads = [p.grad for p in params if p.grad is not None]
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in grads]
     for w in works:
@@ -156,7 +163,7 @@ def all_reduce_and_step(optimizer, params: Iterable[torch.Tensor], group=None, c
     following chunks are still on the wire.  Same result as `all_reduce_gradients` + `optimizer.step()` (averaged gradients,
     one step count per parameter); needs an optimizer with `begin_chunked_step` / `step_rows` (gspl_amd.optimizers.FusedAdam)."""
     params = [p for p in params if p.grad is not None]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _nothing_to_exchange(group):
         optimizer.step()
         return
     world = dist.get_world_size(group)

@@ -115,7 +115,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def gather_cameras(self, viewpoint_camera):
-        if self._world() == 1:
+        if self._world() == 1 and (D.SINGLE_RANK_SHORTCUT or not dist.is_initialized()):
             return [viewpoint_camera]
         cams = []
         for i in D.gather_ints(int(viewpoint_camera.idx), viewpoint_camera.device, self.group):
@@ -199,7 +199,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
                 if opacities.is_cuda:
                     # one pack kernel for all cameras, one all-to-all, one unpack kernel (csrc/records.hip)
                     records, send_counts = ops.pack_visible_records(projection_results_list, rgb_list, opacities)
-                    if len(cameras) > 1:
+                    if len(cameras) > 1 or (dist.is_initialized() and not D.SINGLE_RANK_SHORTCUT):
                         recv_counts = D.exchange_counts(send_counts, records.device, self.group)
                         records = D.all_to_all_rows(records, send_counts, recv_counts, self.group)
                     radii, means2d, depths, conics, opac, rgbs = ops.unpack_visible_records(records, self.config.anti_aliased)
