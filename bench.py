@@ -15,12 +15,14 @@ statistics, no parameter update — what round 1 reported as `value`), measured 
 
 Multi-GPU (driver launches `torch.distributed.run ... bench.py --gpus N`), one process per GPU over RCCL, one camera per
 rank per step (weak scaling):
-  replicated  (default for N > 1; BASELINE.json north_star, the reference's configs/ddp.yaml): every rank holds all
-              Gaussians; parameter gradients are all-reduced (averaged) before the optimizer step, the densification
-              statistics (12 B/Gaussian) every 100 steps (the reference's cadence) and at the end of the timed region.
-  sharded     (the reference's configs/distributed.yaml): Gaussians sharded over the ranks, every rank projects its
-              shard for all N cameras, one packed all-to-all of visible-splat records, compositing local
-              (gspl_amd.renderers.HipGSplatDistributedRenderer), optimizer and statistics on the shard.
+  sharded     (default for N > 1; the reference's configs/distributed.yaml, SURVEY.md §8e "primary"): Gaussians sharded over
+              the ranks, every rank projects its shard for all N cameras, one packed all-to-all of visible-splat records
+              (48 B per visible splat), compositing local (gspl_amd.renderers.HipGSplatDistributedRenderer), optimizer and
+              statistics on the shard: no gradient all-reduce.
+  replicated  (BASELINE.json north_star's wording, the reference's configs/ddp.yaml): every rank holds all Gaussians;
+              parameter gradients are all-reduced (averaged; 236 B per Gaussian per step: bound by the xGMI links at 1 M
+              Gaussians) before the optimizer step, the densification statistics (12 B/Gaussian) every 100 steps (the
+              reference's cadence) and at the end of the timed region.
 
 Extra objects on the JSON line:
   roofline      dominant kernel = composite backward; achieved = algorithmic bytes (76*I + 20*P, SURVEY.md §8d, I = every
@@ -67,8 +69,8 @@ def parse():
     p.add_argument("--optimizer", default="fused-adam", choices=["none", "fused-adam", "selective-adam", "torch-adam"],
                    help="optimizer step inside the timed step (default: the package's fused Adam; none = renderer fwd+bwd rate only)")
     p.add_argument("--parallelism", default="auto", choices=["auto", "single", "replicated", "sharded"],
-                   help="auto: single for one GPU, replicated (gradient all-reduce + optimizer on every rank) for several; "
-                        "sharded: Gaussian-sharded renderer with the packed all-to-all (configs/distributed.yaml)")
+                   help="auto: single for one GPU, sharded for several (Gaussian-sharded renderer with the packed all-to-all, "
+                        "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
     p.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg and print it (no GPU needed)")
     p.add_argument("--stage-times", action="store_true",
@@ -307,7 +309,7 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     mode = args.parallelism
     if mode == "auto":
-        mode = "single" if world == 1 else "replicated"
+        mode = "single" if world == 1 else "sharded"
     if mode == "single" and world > 1:
         sys.exit("--parallelism single needs --gpus 1")
 

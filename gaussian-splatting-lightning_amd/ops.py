@@ -448,6 +448,9 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 # `has_hit_any_pixels` to the caller's screen-space tensor (the fork-only side channel gsplat's SelectiveAdam adapter
 # reads, internal/optimizers.py:39).  Off by default: it is one more byte store per (tile, splat) in the hot kernel.
 TRACK_HIT_PIXELS = False
+# Staged binning (`bin_gaussians`): with a speculative emission in flight the tile sort is enqueued before the host has read the
+# list length (False: wait for the count first, then sort — the round-1 order; kept for A/B runs and the tests of both orders).
+DEVICE_SIDE_LIST_LENGTH = True
 # Introspection for bench.py / tools: with KEEP_LAST_RASTER set, the last compositing forward leaves its per-splat inputs and
 # tile lists in LAST_RASTER (a dict of tensors; nothing is copied).
 KEEP_LAST_RASTER = False
@@ -671,7 +674,7 @@ class _PendingBins:
     """Binning in flight: the count/depth-sort half has been launched and the number of intersections is on its
     way to a pinned host word; `bin_gaussians_end` waits for it and launches the emit/sort half."""
     __slots__ = ("N", "mode", "means2d", "radii", "cull_c", "cull_o", "order", "cum", "spans", "offsets", "tile_w", "tile_h",
-                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes", "big_list", "depths", "count")
+                 "block_width", "host_count", "event", "dev", "capacity", "ws2", "ws2_bytes", "big_list", "depths", "count", "offsets_buf")
 
 
 # =============================================================================================
@@ -862,7 +865,9 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     p.cull_c = p.cull_o = None
     if conics is not None and opacities is not None:
         p.cull_c, p.cull_o = _f32c(conics.detach()).reshape(-1, 3), _f32c(opacities.detach()).reshape(-1)
-    p.offsets = torch.empty((p.tile_w * p.tile_h,), dtype=torch.int32, device=dev)
+    # tiles + 1 entries: the device-side-length sort stores the list length behind the per-tile starts; callers get the first tiles
+    p.offsets_buf = torch.empty((p.tile_w * p.tile_h + 1,), dtype=torch.int32, device=dev)
+    p.offsets = p.offsets_buf[:p.tile_w * p.tile_h]
     p.order = p.cum = p.spans = p.host_count = p.event = p.ws2 = p.big_list = p.depths = None
     p.capacity = p.ws2_bytes = 0
     if N > 0:
@@ -913,12 +918,23 @@ def bin_gaussians_end(p: _PendingBins):
 def _bin_gaussians_end(p: _PendingBins):
     lib = L.lib()
     n_isects = 0
-    if p.N > 0:
+    N, dev = p.N, p.dev
+    flat_cap = None
+    if N > 0 and p.ws2 is not None and DEVICE_SIDE_LIST_LENGTH:
+        # The records were emitted speculatively: sort them BEFORE the host knows how many there are (the sort reads the length on
+        # the device, its grid is sized by the capacity), so that the device has the whole sort queued while the host waits for the
+        # count — and check the guess afterwards.
+        flat_cap = torch.empty((p.capacity,), dtype=torch.int32, device=dev)
+        L.call("gspl_bin_sort_device_count", N, p.tile_w, p.tile_h, L.ptr(p.cum, offset_bytes=8 * (N - 1)), p.capacity, L.ptr(flat_cap),
+               L.ptr(p.offsets_buf), L.ptr(p.ws2), p.ws2_bytes, L.stream())
+    if N > 0:
         p.event.synchronize()
         n_isects = int(p.host_count[0])
         _PINNED_WORDS.append(p.host_count)
         _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
-    N, dev = p.N, p.dev
+    if flat_cap is not None and 0 < n_isects <= p.capacity:
+        p.ws2 = None
+        return flat_cap[:n_isects], p.offsets
     flat = torch.empty((n_isects,), dtype=torch.int32, device=dev)
     if n_isects > 0 and (p.ws2 is None or p.capacity < n_isects):
         p.capacity = n_isects

@@ -1,0 +1,55 @@
+"""bench.py's launch contract as the driver uses it: `python bench.py` on one GPU, and `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` for several ranks — ONE JSON line from rank 0, last on stdout, with the fields the
+driver reads.  The two-rank launch shares the one GPU of the test box and stages its collectives through gloo
+(`--share-device --dist-backend gloo`): slow, but the same code path as the RCCL launch apart from the backend."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def _run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    line = json.loads(lines[-1])                     # the JSON line is the LAST line of stdout
+    for k in REQUIRED:
+        assert k in line, k
+    return line
+
+
+@pytest.mark.gpu
+def test_single_gpu_line():
+    line = _run([sys.executable, "bench.py", "--workload", "S-800-100k", "--steps", "5", "--warmup", "2"])
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["unit"] == "images/s"
+    assert line["config"]["workload"] == "S-800-100k" and line["config"]["parallelism_mode"] == "single"
+    assert abs(line["value"] - 1e3 / line["ms_per_step"]) <= 1e-3 * line["value"]
+    assert line["images_per_s_with_optimizer"] == line["value"] and line["images_per_s_renderer_only"] >= line["value"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0.0 < roof["frac"] and roof["unit"] == "GB/s" and roof["valu_frac"] > 0.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) <= 2e-3
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "replicated"])
+def test_two_rank_launch_line(mode):
+    port = 29700 + (os.getpid() + (7 if mode == "default" else 0)) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "S-800-100k",
+           "--share-device", "--dist-backend", "gloo"]
+    if mode != "default":
+        cmd += ["--parallelism", mode]
+    line = _run(cmd)
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["parallelism_mode"] == ("sharded" if mode == "default" else mode)      # sharded unless told otherwise
+    assert abs(line["value"] - 2e3 / line["ms_per_step"]) <= 1e-3 * line["value"]               # whole-job images/s
+    assert "cpu_baseline" not in line or line["cpu_baseline"] is None                           # rank 0, N = 1 only

@@ -229,12 +229,24 @@ def test_speculative_emission_recovers_from_a_low_guess(hip):
     tw, th = (W + 15) // 16, (H + 15) // 16
     res_small, _, _, _ = _projected_scene(300, W, H, 300.0, seed=11, scale_mul=1.0)
     res_big, _, _, _ = _projected_scene(6000, W, H, 300.0, seed=12, scale_mul=6.0)
-    for res in (res_small, res_big, res_small, res_big):
-        xys, depths, radii = res[0], res[1], res[2]
-        _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, xys, radii, depths, W, H)
-        flat, offs = hip.bin_gaussians(xys.to(d), depths.to(d), radii.to(d), H, W, 16)
-        assert np.array_equal(flat.cpu().numpy(), flat_ref) and np.array_equal(offs.cpu().numpy(), offs_ref)
-    assert hip._LAST_ISECTS[(torch.device(d).index, tw, th)] == flat_ref.shape[0]
+    # both orders of the second half: the sort enqueued before the host has the list length (read on the device, checked
+    # afterwards) and the round-1 order (wait for the count, then sort)
+    for device_side in (True, False):
+        hip.DEVICE_SIDE_LIST_LENGTH = device_side
+        low_guesses, last = 0, None
+        try:
+            for res in (res_small, res_big, res_small, res_big, res_big):
+                xys, depths, radii = res[0], res[1], res[2]
+                _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, xys, radii, depths, W, H)
+                flat, offs = hip.bin_gaussians(xys.to(d), depths.to(d), radii.to(d), H, W, 16)
+                assert np.array_equal(flat.cpu().numpy(), flat_ref) and np.array_equal(offs.cpu().numpy(), offs_ref)
+                assert offs.shape == (tw * th,) and offs.is_contiguous() and flat.is_contiguous()
+                low_guesses += last is not None and flat_ref.shape[0] > int(last * 1.25) + 65536
+                last = flat_ref.shape[0]
+        finally:
+            hip.DEVICE_SIDE_LIST_LENGTH = True
+        assert low_guesses >= 2, "the scenes must really overflow the speculative capacity"
+        assert hip._LAST_ISECTS[(torch.device(d).index, tw, th)] == flat_ref.shape[0]
 
 
 @pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
