@@ -26,7 +26,7 @@ from .. import distributed as D
 from .. import ops
 from ..optim_utils import replace_tensors_to_properties
 from .hip_gsplat_v1_renderer import GSplatV1
-from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw
+from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars
 
 
 @dataclass
@@ -118,7 +118,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
         if self._world() == 1 and (D.SINGLE_RANK_SHORTCUT or not dist.is_initialized()):
             return [viewpoint_camera]
         cams = []
-        for i in D.gather_ints(int(viewpoint_camera.idx), viewpoint_camera.device, self.group):
+        for i in D.gather_ints(int(camera_scalars(viewpoint_camera, ("idx",))[0]), viewpoint_camera.device, self.group):
             cam = self.camera_lookup(i, self.training)
             if cam.device != viewpoint_camera.device:
                 cam.to_device(viewpoint_camera.device)

@@ -7,6 +7,7 @@ import torch
 from .. import ops
 from .renderer import Renderer
 from .hip_gsplat_renderer import HipGSplatRenderer
+from .renderer import camera_hw
 
 
 class HipGSplatHitPixelCountRenderer(Renderer):
@@ -29,6 +30,6 @@ class HipGSplatHitPixelCountRenderer(Renderer):
                 scaling_modifier=scaling_modifier, block_size=block_size, extra_projection_kwargs=extra_projection_kwargs)
             if anti_aliased is True:
                 opacities = opacities * comp[:, None]
-            return ops.hit_pixel_count(xys, depths, radii, conics, num_tiles_hit, opacities,
-                                       img_height=int(viewpoint_camera.height.item()), img_width=int(viewpoint_camera.width.item()),
+            W, H = camera_hw(viewpoint_camera)
+            return ops.hit_pixel_count(xys, depths, radii, conics, num_tiles_hit, opacities, img_height=H, img_width=W,
                                        block_width=block_size)

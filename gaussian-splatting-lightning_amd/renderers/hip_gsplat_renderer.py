@@ -5,7 +5,7 @@ helpers (`render`, `project`, `rasterize`, `rasterize_simplified`) that ~8 other
 
 Differences that are deliberate:
   * view directions, SH evaluation, `+0.5` and the clamp run in ONE kernel (`ops.sh_view_colors`);
-  * width/height cost one device read-back per call instead of six `.item()`s;
+  * width/height are read back once per camera object instead of with six `.item()`s per call (`renderer.camera_scalars`);
   * `absgrad=True` asks the compositing backward for `viewspace_points.absgrad`
     (what `configs/gsplat-absgrad.yaml` needs from the density controller's point of view).
 """

@@ -253,11 +253,27 @@ class GSplatV1:
 
     @classmethod
     def preprocess_camera(cls, viewpoint_camera):
+        """(viewmats [1,4,4], Ks [1,3,3], (W, H)) — built on the device (no host sync) and kept on the camera object: dataset
+        cameras persist across steps and the six small launches that assemble K cost more host time than the projection
+        call.  The cache is keyed on identity and version counter of every source tensor (pose refinement, viewer edits)."""
+        src = (viewpoint_camera.world_to_camera, viewpoint_camera.fx, viewpoint_camera.fy, viewpoint_camera.cx, viewpoint_camera.cy)
+        tensors = all(isinstance(v, torch.Tensor) for v in src)
+        if tensors and not any(v.requires_grad for v in src):
+            key = tuple((id(v), v._version) for v in src)
+            hit = getattr(viewpoint_camera, "_gspl_v1_camera", None)
+            if hit is not None and hit[0] == key and all(a is b for a, b in zip(hit[1], src)):
+                return hit[2], hit[3], camera_hw(viewpoint_camera)
         viewmats = viewpoint_camera.world_to_camera.T.unsqueeze(0)
         dev = viewmats.device
-        Ks = torch.zeros((1, 3, 3), dtype=torch.float, device=dev)      # built on device: no host sync
+        Ks = torch.zeros((1, 3, 3), dtype=torch.float, device=dev)
         Ks[0, 0, 0], Ks[0, 1, 1], Ks[0, 0, 2], Ks[0, 1, 2], Ks[0, 2, 2] = \
             viewpoint_camera.fx, viewpoint_camera.fy, viewpoint_camera.cx, viewpoint_camera.cy, 1.0
+        if tensors and not any(v.requires_grad for v in src):
+            viewmats = viewmats.contiguous()
+            try:
+                viewpoint_camera._gspl_v1_camera = (key, src, viewmats, Ks)
+            except AttributeError:
+                pass
         return viewmats, Ks, camera_hw(viewpoint_camera)
 
     @classmethod

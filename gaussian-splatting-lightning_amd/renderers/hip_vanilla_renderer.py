@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars
 
 
 def _tan_half(fov):
@@ -30,9 +30,10 @@ class HipVanillaRenderer(Renderer):
     @staticmethod
     def _settings(viewpoint_camera, bg_color, scaling_modifier, sh_degree):
         W, H = camera_hw(viewpoint_camera)
+        fov_x, fov_y = camera_scalars(viewpoint_camera, ("fov_x", "fov_y"))
         return ops.GaussianRasterizationSettings(
             image_height=H, image_width=W,
-            tanfovx=_tan_half(viewpoint_camera.fov_x), tanfovy=_tan_half(viewpoint_camera.fov_y),
+            tanfovx=_tan_half(fov_x), tanfovy=_tan_half(fov_y),
             bg=bg_color, scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_to_camera, projmatrix=viewpoint_camera.full_projection,
             sh_degree=int(sh_degree), campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)

@@ -72,15 +72,47 @@ except Exception:  # ImportError, or lightning missing
             raise NotImplementedError()
 
 
-def camera_hw(viewpoint_camera):
-    """(width, height) as python ints with ONE device read-back (the reference does `.item()` per field:
-    gsplat_renderer.py:61-62,71-74)."""
-    w, h = viewpoint_camera.width, viewpoint_camera.height
-    if isinstance(w, torch.Tensor):
-        if w.is_cuda:
-            w, h = torch.stack([w.reshape(()), h.reshape(())]).tolist()
+def camera_scalars(viewpoint_camera, names):
+    """Python numbers of the camera's 0-d tensor fields `names` (width, height, fov_x, idx, ...).  The reference reads each of
+    them with `.item()` on every call (gsplat_renderer.py:61-62,71-74, vanilla_renderer.py:59-60): a device read-back drains
+    the queue — the whole previous step — before the new step's first kernel can be enqueued.  Here a field is read ONCE per
+    camera object (all missing fields in one transfer) and kept on the object, keyed on the tensor's identity and version
+    counter, so that a field replaced or modified in place is read again."""
+    cache = getattr(viewpoint_camera, "_gspl_scalars", None)
+    if cache is None:
+        cache = {}
+        try:
+            viewpoint_camera._gspl_scalars = cache
+        except AttributeError:          # an object that takes no attributes: read every time
+            pass
+    out, missing = {}, []
+    for n in names:
+        v = getattr(viewpoint_camera, n)
+        hit = cache.get(n)
+        if isinstance(v, torch.Tensor):
+            if hit is not None and hit[0] is v and hit[1] == v._version:
+                out[n] = hit[2]
+            else:
+                missing.append((n, v))
         else:
-            w, h = w.item(), h.item()
+            out[n] = v
+    if missing:
+        on_dev = [m for m in missing if m[1].is_cuda]
+        if len(on_dev) > 1:
+            vals = torch.stack([v.detach().reshape(()).double() for _, v in on_dev]).tolist()      # one read-back for all of them
+        else:
+            vals = [v.item() for _, v in on_dev]
+        got = {n: (int(round(x)) if not v.is_floating_point() else float(x)) for (n, v), x in zip(on_dev, vals)}
+        for n, v in missing:
+            val = got[n] if n in got else v.item()
+            cache[n] = (v, v._version, val)
+            out[n] = val
+    return tuple(out[n] for n in names)
+
+
+def camera_hw(viewpoint_camera):
+    """(width, height) as python ints (read back once per camera object: `camera_scalars`)."""
+    w, h = camera_scalars(viewpoint_camera, ("width", "height"))
     return int(w), int(h)
 
 

@@ -13,6 +13,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def free_port() -> int:
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests): asked from the kernel per test, so that
+    two tests of one session never meet on a port that is still in TIME_WAIT."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / by the driver)")
 

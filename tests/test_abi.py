@@ -126,3 +126,39 @@ def test_v1_renderer_viewer_tab_writes_the_runtime_options():
     model.value = "fisheye"
     model.cb(None)
     assert renderer.runtime_options.radius_clip == 2.5 and renderer.runtime_options.camera_model == "fisheye" and Viewer.rerenders == 2
+
+
+def test_camera_scalars_are_read_once_per_camera_object_and_follow_changes():
+    """`camera_scalars` keeps the python values of a camera's 0-d tensor fields on the camera object (the reference reads them
+    with `.item()` on every call); a field replaced or modified in place is read again."""
+    import types
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers.renderer import camera_hw, camera_scalars
+    cam = types.SimpleNamespace(width=torch.tensor(640, dtype=torch.int32), height=torch.tensor(480, dtype=torch.int32),
+                                fov_x=torch.tensor(0.75), idx=torch.tensor(7, dtype=torch.int32), plain=3)
+    assert camera_hw(cam) == (640, 480) and all(isinstance(v, int) for v in camera_hw(cam))
+    fov, idx, plain = camera_scalars(cam, ("fov_x", "idx", "plain"))
+    assert fov == float(torch.tensor(0.75)) and idx == 7 and isinstance(idx, int) and plain == 3
+    reads = {"n": 0}
+    real_item = torch.Tensor.item
+
+    def counting_item(self):
+        reads["n"] += 1
+        return real_item(self)
+    torch.Tensor.item = counting_item
+    try:
+        assert camera_hw(cam) == (640, 480) and camera_scalars(cam, ("fov_x", "idx")) == (fov, 7)
+        assert reads["n"] == 0                              # served from the object
+        cam.width.fill_(800)                                # modified in place: version counter moves
+        assert camera_hw(cam) == (800, 480) and reads["n"] == 1
+        cam.height = torch.tensor(600, dtype=torch.int32)   # replaced
+        assert camera_hw(cam) == (800, 600) and reads["n"] == 2
+        assert camera_hw(cam) == (800, 600) and reads["n"] == 2
+    finally:
+        torch.Tensor.item = real_item
+
+    class Slotted:                                          # an object that takes no new attributes: read every time, still right
+        __slots__ = ("width", "height")
+    s = Slotted()
+    s.width, s.height = torch.tensor(32), torch.tensor(16)
+    assert camera_hw(s) == (32, 16) and camera_hw(s) == (32, 16)

@@ -63,6 +63,7 @@ def _worker(rank, world, port, tmpdir):
 
 @pytest.mark.gpu
 def test_chunked_all_reduce_with_chunkwise_adam_matches_the_plain_sequence(tmp_path):
-    port = 29650 + (os.getpid() % 250)
+    from conftest import free_port
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

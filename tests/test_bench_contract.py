@@ -42,7 +42,8 @@ def test_single_gpu_line():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["default", "replicated"])
 def test_two_rank_launch_line(mode):
-    port = 29700 + (os.getpid() + (7 if mode == "default" else 0)) % 200
+    from conftest import free_port
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "S-800-100k",
            "--share-device", "--dist-backend", "gloo"]

@@ -87,6 +87,7 @@ def _worker(rank, world, port, tmpdir):
 
 
 def test_world2_gloo(tmp_path):
-    port = 29600 + (os.getpid() % 300)
+    from conftest import free_port
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()

@@ -308,7 +308,8 @@ def _worker(rank, world, port, tmpdir, on_gpu):
 
 
 def _run(tmp_path, on_gpu, world=2):
-    port = 29900 + (os.getpid() % 300) + (50 if on_gpu else 0) + 7 * world
+    from conftest import free_port
+    port = free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), on_gpu), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 

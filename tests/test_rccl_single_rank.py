@@ -110,9 +110,10 @@ WORKER = textwrap.dedent("""
 
 @pytest.mark.gpu
 def test_collectives_of_both_modes_run_on_rccl_with_one_rank(tmp_path):
+    from conftest import free_port
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, GSPL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
+    env = dict(os.environ, GSPL_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-SINGLE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

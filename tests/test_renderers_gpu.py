@@ -319,6 +319,26 @@ def test_gsplat_renderer_sees_pose_updates_and_other_devices_current():
         camera.world_to_camera = camera.world_to_camera.clone()    # replaced: same values
         d = r(camera, model, bg.to(DEV))["render"]
         assert torch.equal(c, d)
+    # the same for the v1 renderer's per-camera (view matrix, K) cache and for the cached image size / field of view
+    from gspl_amd.renderers import HipGSplatV1Renderer, HipVanillaRenderer
+    for make in (lambda: HipGSplatV1Renderer().instantiate(), lambda: HipVanillaRenderer()):
+        camera = FakeCamera(cam, DEV)
+        r = make()
+        with torch.no_grad():
+            a = r(camera, model, bg.to(DEV))["render"].clone()
+            assert torch.equal(a, r(camera, model, bg.to(DEV))["render"])
+            camera.world_to_camera[3, 0] += 0.25
+            if hasattr(camera, "full_projection"):
+                camera.full_projection = camera.world_to_camera @ (torch.linalg.inv(FakeCamera(cam, DEV).world_to_camera) @ FakeCamera(cam, DEV).full_projection)
+            c = r(camera, model, bg.to(DEV))["render"].clone()
+            assert float((a - c).abs().max()) > 1e-3
+            camera.fx.mul_(1.1), camera.fy.mul_(1.1)                   # intrinsics in place (the vanilla path reads the fov instead)
+            camera.fov_x.mul_(0.9), camera.fov_y.mul_(0.9)
+            e = r(camera, model, bg.to(DEV))["render"]
+            assert float((c - e).abs().max()) > 1e-3
+            H0 = int(camera.height)
+            camera.height = torch.tensor(H0 - 16, dtype=camera.height.dtype, device=DEV)      # replaced size field
+            assert r(camera, model, bg.to(DEV))["render"].shape[1] == H0 - 16
     g = L.device_guard(params[0].to(DEV))
     with g:
         assert g.prev == -1 and torch.cuda.current_device() == 0      # already current: nothing switched, nothing to restore
