@@ -888,7 +888,49 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                 // candidate: staged, in front of some pixel's last contributor, and able to reach alpha >= 1/255 in this half tile
                 const bool cand = (slot < cnt) && (hi - 1 - slot < wave_last) && ((qm >> (2 * w)) & 3u);
                 unsigned long long mask = __ballot(cand);
+#ifdef GSPL_BWD2_PREFETCH
+                // EXPERIMENT (A/B builds): the record of the NEXT candidate is read while the current one is processed
+                float4 n_r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float2 n_r1 = make_float2(0.f, 0.f);
+                float n_col[D];
+                int n_j = 0;
+                if (mask) {
+                    n_j = kk * 64 + (int)__builtin_ctzll(mask);
+                    const float* nrec = s_rec + n_j * RS;
+                    n_r0 = *reinterpret_cast<const float4*>(nrec);
+                    n_r1 = *reinterpret_cast<const float2*>(nrec + 4);
+#if GSPL_BWD2_PREFETCH >= 2
+#pragma unroll
+                    for (int c = 0; c < D; ++c) n_col[c] = nrec[8 + c];
+#endif
+                }
+#endif
                 while (mask) {
+#ifdef GSPL_BWD2_PREFETCH
+                    const int j = n_j;
+                    const float4 r0 = n_r0;
+                    const float2 r1 = n_r1;
+                    float col[D];
+#if GSPL_BWD2_PREFETCH >= 2
+#pragma unroll
+                    for (int c = 0; c < D; ++c) col[c] = n_col[c];
+#else
+#pragma unroll
+                    for (int c = 0; c < D; ++c) col[c] = s_rec[j * RS + 8 + c];
+#endif
+                    mask &= mask - 1;
+                    if (mask) {
+                        n_j = kk * 64 + (int)__builtin_ctzll(mask);
+                        const float* nrec = s_rec + n_j * RS;
+                        n_r0 = *reinterpret_cast<const float4*>(nrec);
+                        n_r1 = *reinterpret_cast<const float2*>(nrec + 4);
+#if GSPL_BWD2_PREFETCH >= 2
+#pragma unroll
+                        for (int c = 0; c < D; ++c) n_col[c] = nrec[8 + c];
+#endif
+                    }
+                    const int idx = hi - 1 - j;
+#else
                     const int j = kk * 64 + (int)__builtin_ctzll(mask);
                     mask &= mask - 1;
                     const int idx = hi - 1 - j;
@@ -898,6 +940,7 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     float col[D];                                                    // fetched with the record: one LDS round trip per candidate
 #pragma unroll
                     for (int c = 0; c < D; ++c) col[c] = rec[8 + c];
+#endif
                     // sigma, bit-identical per element to eval_sigma: fma(ha dx, dx, fma(hc dy, dy, (b dx) dy))
                     const v2f dx2 = (v2f){r0.x, r0.x} - pxf2;
                     const float dy = r0.y - pyf;
