@@ -107,7 +107,7 @@ __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isec
 //      (x[], y[], ha[], b[], hc[], opacity[], colour[][D]);
 //   3. the wave walks the list TWO candidates at a time: one ds_read_b64 per array yields the pair as a
 //      64-bit register pair, so sigma / exp argument / alpha are evaluated with packed fp32 math
-//      (v_pk_add/mul/fma_f32 — the only way CDNA reaches its fp32 rate; plain wave64 VALU ops issue at half of it),
+//      (v_pk_add/mul/fma_f32: half the instructions — and issue slots, scalar bookkeeping — for the same arithmetic),
 //      and the short sequential transmittance update is branch-free (predicated) to keep scalar-unit work low:
 //      the first version of this loop was bound by SALU mask bookkeeping (136 M scalar vs 118 M vector instructions).
 typedef float v2f __attribute__((ext_vector_type(2)));
