@@ -625,6 +625,16 @@ __global__ __launch_bounds__(256, GSPL_BWD_WAVES) void composite_bwd_kernel(
 #endif
 static constexpr int B2CHUNK = GSPL_BWD2_CHUNK;   // splats staged per round
 static constexpr int P2_SLOTS = 4;                // splats per phase-2 batch (16 lanes each)
+#ifdef GSPL_BWD2_SOLO
+// EXPERIMENT (A/B builds): one wave per WORKGROUP = one 16x8 half tile that stages, walks and flushes the tile's list on its own:
+// no partner wave to wait for at the two barriers of a round (the halves of a tile saturate at different depths and pass
+// different numbers of candidates), at the price of staging and flushing every list entry twice.  Needs GSPL_BWD2_CHUNK <= 64.
+static constexpr int B2_NW = 1;
+#else
+static constexpr int B2_NW = 2;                   // waves per workgroup: the two half tiles of a tile share the staged records
+#endif
+static constexpr int B2_NT = 64 * B2_NW;
+static_assert(B2CHUNK <= B2_NT || B2_NW == 2, "a round is staged by one pass of the workgroup's threads");
 
 #ifdef GSPL_BWD_LPT
 // EXPERIMENT (A/B builds): workgroups take the tiles longest list first, so that the heavy tiles of the image centre do not start
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const int32_t* __restr
 #endif
 
 template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
-__global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
+__global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
@@ -679,9 +689,9 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     __shared__ int s_id[B2CHUNK];
     __shared__ __attribute__((aligned(16))) float s_rec[B2CHUNK * RS];
     __shared__ float s_acc[B2CHUNK * NV];
-    __shared__ __attribute__((aligned(16))) float s_slab[2 * SLAB];
-    __shared__ __attribute__((aligned(16))) float s_vo_keep[VO_REGS ? 4 : 2 * 128 * D];
-    static_assert(!VO_REGS || 2 * 128 * D <= 2 * SLAB, "s_vo alias too small");
+    __shared__ __attribute__((aligned(16))) float s_slab[B2_NW * SLAB];
+    __shared__ __attribute__((aligned(16))) float s_vo_keep[VO_REGS ? 4 : B2_NW * 128 * D];
+    static_assert(!VO_REGS || B2_NW * 128 * D <= B2_NW * SLAB, "s_vo alias too small");
     float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column 0..15][channel][row]
     __shared__ int s_last;
 
@@ -699,10 +709,20 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         if (txx >= tile_w || tyy >= tile_h) return;
         tile = tyy * tile_w + txx;
     }
+#elif defined(GSPL_BWD2_SOLO)
+    const int unit = xcd_remap(blockIdx.x, 2 * n_tiles, 2 * GSPL_XCD_RUN);      // (tile, half): both halves of a tile on one XCD
+    const int tile = unit >> 1;
 #else
     const int tile = xcd_remap(blockIdx.x, n_tiles);
 #endif
+#ifdef GSPL_BWD2_SOLO
+    const int t = threadIdx.x, l = t;
+    const int w = unit & 1;           // half tile (rows [8w, 8w+8))
+    constexpr int ws = 0;             // this wave's slab / dL/dout slot in LDS
+#else
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int ws = w;
+#endif
     const int tx = (tile % tile_w) * TILE, ty = (tile / tile_w) * TILE;
     const int pxA = tx + (l & 7), pxB = pxA + 8;
     const int py = ty + w * 8 + (l >> 3);
@@ -722,7 +742,7 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     constexpr int TLB = 64;
 #endif
     const int ps = l >> 4, pc = l & 15;                // phase-2 role: splat slot, column of the half tile
-    float* slab = s_slab + w * SLAB;
+    float* slab = s_slab + ws * SLAB;
 
     int start, end;
     tile_range(tile, n_tiles, n_isects, offsets, start, end);
@@ -737,21 +757,21 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         if (insideA) vo[c].x = CHW ? v_out_colors[(int64_t)c * width * height + pixA] : v_out_colors[pixA * D + c];
         if (insideB) vo[c].y = CHW ? v_out_colors[(int64_t)c * width * height + pixB] : v_out_colors[pixB * D + c];
         if (backgrounds) bgdot += backgrounds[c] * vo[c];
-        s_vo[((w * 16 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].x;
-        s_vo[((w * 16 + 8 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].y;
+        s_vo[((ws * 16 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].x;
+        s_vo[((ws * 16 + 8 + (l & 7)) * D + c) * 8 + (l >> 3)] = vo[c].y;
     }
     const v2f v_out_a = {(insideA && v_out_alphas) ? v_out_alphas[pixA] : 0.f, (insideB && v_out_alphas) ? v_out_alphas[pixB] : 0.f};
     // R: see composite_bwd_kernel
     v2f R2 = T2 * (v_out_a - bgdot);
 
     if (t == 0) s_last = start;
-    for (int k = t; k < B2CHUNK * NV; k += 128) s_acc[k] = 0.f;
+    for (int k = t; k < B2CHUNK * NV; k += B2_NT) s_acc[k] = 0.f;
     __syncthreads();
     v2f vo2[VO_REGS ? 4 : 1][VO_REGS ? D : 1];         // phase-2 view of dL/dout: column pc, rows in pairs
     if constexpr (VO_REGS) {
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const float4* vp = reinterpret_cast<const float4*>(s_vo + ((w * 16 + pc) * D + c) * 8);
+            const float4* vp = reinterpret_cast<const float4*>(s_vo + ((ws * 16 + pc) * D + c) * 8);
             const float4 v0 = vp[0], v1 = vp[1];
             vo2[0][c] = (v2f){v0.x, v0.y}; vo2[1][c] = (v2f){v0.z, v0.w};
             vo2[2][c] = (v2f){v1.x, v1.y}; vo2[3][c] = (v2f){v1.z, v1.w};
@@ -807,7 +827,7 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                 for (int c = 0; c < D; ++c) {
                     v2f vv;
                     if constexpr (VO_REGS) vv = vo2[k][c];
-                    else vv = *reinterpret_cast<const v2f*>(s_vo + ((w * 16 + pc) * D + c) * 8 + 2 * k);
+                    else vv = *reinterpret_cast<const v2f*>(s_vo + ((ws * 16 + pc) * D + c) * 8 + 2 * k);
                     rgb2[c] = __builtin_elementwise_fma(F2[k], vv, rgb2[c]);
                 }
                 s02 += S2[k];
@@ -1001,7 +1021,7 @@ __global__ __launch_bounds__(128, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         __syncthreads();
         if constexpr (PACKED) {
             float* __restrict__ v_packed = v_means2d;
-            for (int e = t; e < cnt * NV; e += 128) {
+            for (int e = t; e < cnt * NV; e += B2_NT) {
                 const float v = s_acc[e];
                 s_acc[e] = 0.f;
                 const int row = e / NV;
@@ -1398,15 +1418,15 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
 #ifdef GSPL_BWD_BLOCKS
     const int grid_bwd2 = ((tile_w + 7) / 8) * ((n_tiles / tile_w + 3) / 4) * 32;
 #else
-    const int grid_bwd2 = n_tiles;
+    const int grid_bwd2 = n_tiles * (2 / B2_NW);
 #endif
     if (absgrad)
-        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(grid_bwd2), dim3(128), 0, s,
+        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(grid_bwd2), dim3(B2_NT), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     else
-        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(grid_bwd2), dim3(128), 0, s,
+        hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(grid_bwd2), dim3(B2_NT), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
