@@ -1431,7 +1431,7 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     return check_launch("composite_bwd");
-#endif
+#else                    // one-pixel-per-lane kernel: instantiated in -DGSPL_BWD_V2 builds only
     if (absgrad)
         hipLaunchKernelGGL((composite_bwd_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(256), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
@@ -1443,6 +1443,7 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                            offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas,
                            v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, packed_stride, hit_flags);
     return check_launch("composite_bwd");
+#endif
 }
 
 // ---- per-splat statistics of a compositing pass (no image) -----------------------------------------------------------------------

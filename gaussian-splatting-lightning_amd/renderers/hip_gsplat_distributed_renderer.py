@@ -118,7 +118,20 @@ class HipGSplatDistributedRendererImpl(Renderer):
         if self._world() == 1 and (D.SINGLE_RANK_SHORTCUT or not dist.is_initialized()):
             return [viewpoint_camera]
         cams = []
-        for i in D.gather_ints(int(camera_scalars(viewpoint_camera, ("idx",))[0]), viewpoint_camera.device, self.group):
+        idx = int(camera_scalars(viewpoint_camera, ("idx",))[0])
+        dev = torch.device(viewpoint_camera.device)
+        if dev.type == "cuda" and D.is_rccl(self.group):
+            # The ids travel on a stream of their own: the collective and the read-back of its result then wait for nothing but
+            # each other — on the current stream they would sit behind the previous step's backward and optimizer, and the host
+            # could not start enqueueing this step before the device had drained.
+            ctl = self.__dict__.get("_ctl_stream")
+            if ctl is None or ctl.device != dev:
+                ctl = self.__dict__["_ctl_stream"] = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(ctl):
+                ids = D.gather_ints(idx, dev, self.group)
+        else:
+            ids = D.gather_ints(idx, dev, self.group)
+        for i in ids:
             cam = self.camera_lookup(i, self.training)
             if cam.device != viewpoint_camera.device:
                 cam.to_device(viewpoint_camera.device)
