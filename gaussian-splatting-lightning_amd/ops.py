@@ -747,9 +747,10 @@ class _PackRecordsFn(torch.autograd.Function):
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         L.call("gspl_records_pack_fwd", C, N, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(opac), L.ptr(rgbs),
                L.ptr(records), L.ptr(slots), L.ptr(ends), host_ends.data_ptr(), L.ptr(ws), ws_bytes, L.stream())
-        ev = torch.cuda.Event()
+        ev = _take_event(dev)
         ev.record()
         ev.synchronize()                 # the split sizes of the all-to-all are needed on the host (as in the reference)
+        _EVENTS[dev.index].append(ev)
         ends_cpu = host_ends.clone() if C * N > 0 else torch.zeros((C,), dtype=torch.int64)
         pool.append(host_ends)
         total = int(ends_cpu[-1]) if C > 0 else 0
@@ -840,6 +841,14 @@ def unpack_visible_records(records: Tensor, fold_compensation: bool):
 
 
 _PINNED_WORDS: list = []      # free list of pinned int64 words for the count read-back
+_EVENTS: dict = {}            # device index -> free list of events (constructing one costs ~15 us of host time per frame)
+
+
+def _take_event(dev):
+    pool = _EVENTS.setdefault(dev.index, [])
+    return pool.pop() if pool else torch.cuda.Event()
+
+
 _LAST_ISECTS: dict = {}       # (device, tile grid) -> list length of the last frame: the guess of the speculative emission
 SPECULATIVE_EMIT = os.environ.get("GSPL_SPECULATIVE_EMIT", "1") != "0"
 
@@ -887,7 +896,7 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
         L.call("gspl_bin_count", N, mode, L.ptr(p.means2d), L.ptr(p.radii), L.ptr(depths), L.ptr(p.cull_c), L.ptr(p.cull_o),
                block_width, p.tile_w, p.tile_h, L.ptr(p.order), L.ptr(p.cum), L.ptr(p.big_list), L.ptr(p.spans), p.host_count.data_ptr(),
                L.ptr(ws), ws_bytes, L.stream())
-        p.event = torch.cuda.Event()
+        p.event = _take_event(dev)
         p.event.record()
         # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of
         # the list length (the last frame's, plus a margin) and runs while the host waits for the real number; a guess
@@ -929,6 +938,7 @@ def _bin_gaussians_end(p: _PendingBins):
                L.ptr(p.offsets_buf), L.ptr(p.ws2), p.ws2_bytes, L.stream())
     if N > 0:
         p.event.synchronize()
+        _EVENTS[dev.index].append(p.event)
         n_isects = int(p.host_count[0])
         _PINNED_WORDS.append(p.host_count)
         _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
