@@ -491,6 +491,19 @@ def main():
                          "fwd_ms": round(sum(m2[i].elapsed_time(m2[i + 1]) for i in range(0, len(m2), 3)) / args.steps, 4),
                          "bwd_ms": round(sum(m2[i + 1].elapsed_time(m2[i + 2]) for i in range(0, len(m2), 3)) / args.steps, 4)}
 
+    I_sharded = None
+    if mode == "sharded":
+        # every tile-rect intersection of rank 0's camera (the I of the byte model): each rank counts the rects of ITS shard for
+        # that camera, the counts are summed over the ranks (after the timed region; all ranks take part)
+        with torch.no_grad():
+            m, s, q = tensors[0], tensors[1], tensors[2]
+            c0 = cam_dicts[0]
+            vm = c0["world_to_camera"].T.contiguous().to(dev)
+            n_rects = ops.project_gaussians(m, s, 1.0, q, vm[:3], c0["fx"], c0["fy"], c0["cx"], c0["cy"], H, W, 16)[5].sum(dtype=torch.int64)
+            if dist is not None:
+                dist.all_reduce(n_rects, op=dist.ReduceOp.SUM)
+            I_sharded = int(n_rects.item())
+
     if rank == 0:
         mean = lambda name: (sum(prof[name]) / len(prof[name])) if prof.get(name) else None
         # per-STEP totals (an entry point called twice per step, e.g. the two phases of the Inria preprocess, counts twice)
@@ -517,6 +530,8 @@ def main():
                         vm = cam["world_to_camera"].T.contiguous().to(dev)
                         tiles = ops.project_gaussians(m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)[5]
                         I = int(tiles.sum().item())
+                else:
+                    I = I_sharded
         roofline = None
         if bwd_ms:
             kernel = _lib.lib().gspl_composite_bwd_kernel_name().decode()

@@ -54,3 +54,6 @@ def test_two_rank_launch_line(mode):
     assert line["config"]["parallelism_mode"] == ("sharded" if mode == "default" else mode)      # sharded unless told otherwise
     assert abs(line["value"] - 2e3 / line["ms_per_step"]) <= 1e-3 * line["value"]               # whole-job images/s
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None                           # rank 0, N = 1 only
+    roof = line["roofline"]                          # the byte model counts every tile-rect intersection, in every mode
+    assert roof["intersections"] >= roof["list_entries"] > 0
+    assert abs(roof["algorithmic_bytes"] - (76.0 * roof["intersections"] + 20.0 * line["config"]["width"] * line["config"]["height"])) < 1.0
