@@ -261,7 +261,8 @@ class GSplatV1:
         if tensors and not any(v.requires_grad for v in src):
             key = tuple((id(v), v._version) for v in src)
             hit = getattr(viewpoint_camera, "_gspl_v1_camera", None)
-            if hit is not None and hit[0] == key and all(a is b for a, b in zip(hit[1], src)):
+            if (hit is not None and hit[0] == key and all(a is b for a, b in zip(hit[1], src))
+                    and hit[2]._version == hit[4] and hit[3]._version == hit[5]):      # (a caller may have edited them in place)
                 return hit[2], hit[3], camera_hw(viewpoint_camera)
         viewmats = viewpoint_camera.world_to_camera.T.unsqueeze(0)
         dev = viewmats.device
@@ -271,7 +272,7 @@ class GSplatV1:
         if tensors and not any(v.requires_grad for v in src):
             viewmats = viewmats.contiguous()
             try:
-                viewpoint_camera._gspl_v1_camera = (key, src, viewmats, Ks)
+                viewpoint_camera._gspl_v1_camera = (key, src, viewmats, Ks, viewmats._version, Ks._version)
             except AttributeError:
                 pass
         return viewmats, Ks, camera_hw(viewpoint_camera)

@@ -162,3 +162,28 @@ def test_camera_scalars_are_read_once_per_camera_object_and_follow_changes():
     s = Slotted()
     s.width, s.height = torch.tensor(32), torch.tensor(16)
     assert camera_hw(s) == (32, 16) and camera_hw(s) == (32, 16)
+
+
+def test_v1_camera_constants_are_cached_per_camera_and_follow_edits():
+    """`GSplatV1.preprocess_camera` keeps (view matrix, K) on the camera object; an in-place change of a source field, a replaced
+    field, or a caller that edits the returned tensors in place all lead to a rebuild."""
+    import types
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import GSplatV1
+    cam = types.SimpleNamespace(world_to_camera=torch.eye(4), fx=torch.tensor(100.), fy=torch.tensor(101.), cx=torch.tensor(50.),
+                                cy=torch.tensor(40.), width=torch.tensor(100), height=torch.tensor(80))
+    a = GSplatV1.preprocess_camera(cam)
+    b = GSplatV1.preprocess_camera(cam)
+    assert a[0] is b[0] and a[1] is b[1] and a[2] == (100, 80)
+    assert torch.equal(a[0][0], cam.world_to_camera.T) and float(a[1][0, 1, 1]) == 101.0 and float(a[1][0, 2, 2]) == 1.0
+    b[1][0, 0, 2] -= 5.0                                     # a caller edits K in place
+    c = GSplatV1.preprocess_camera(cam)
+    assert c[1] is not b[1] and float(c[1][0, 0, 2]) == 50.0
+    cam.fx.mul_(2)                                           # source modified in place
+    assert float(GSplatV1.preprocess_camera(cam)[1][0, 0, 0]) == 200.0
+    cam.world_to_camera = torch.eye(4) * 2                   # source replaced
+    assert float(GSplatV1.preprocess_camera(cam)[0][0, 0, 0]) == 2.0
+    pose = torch.eye(4, requires_grad=True)                  # a pose being optimised is never cached
+    cam.world_to_camera = pose
+    v = GSplatV1.preprocess_camera(cam)[0]
+    assert v.requires_grad and GSplatV1.preprocess_camera(cam)[0] is not v
