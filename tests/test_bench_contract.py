@@ -57,3 +57,17 @@ def test_two_rank_launch_line(mode):
     roof = line["roofline"]                          # the byte model counts every tile-rect intersection, in every mode
     assert roof["intersections"] >= roof["list_entries"] > 0
     assert abs(roof["algorithmic_bytes"] - (76.0 * roof["intersections"] + 20.0 * line["config"]["width"] * line["config"]["height"])) < 1.0
+
+
+def test_cpu_baseline_leg_runs_without_a_gpu():
+    """`bench.py --cpu-baseline-only`: the oracle port of one forward + backward pass (and, where the reference tree is present,
+    its own projection + SH) timed on the host cores — the `cpu_baseline` object of the bench line, runnable on its own."""
+    r = subprocess.run([sys.executable, "bench.py", "--cpu-baseline-only", "--workload", "S-smoke"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cpu = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert cpu["kind"] == "port" and cpu["unit"] == "images/s" and cpu["value"] > 0 and cpu["cores"] >= 1
+    assert "S-smoke" in cpu["sample"] and all(v > 0 for v in cpu["ms"].values())
+    ref = cpu.get("reference_projection_sh")
+    if ref is not None:                   # only where GSPL_REFERENCE_ROOT (default /root/reference) exists
+        assert ref["kind"] == "reference" and ref["fwd_ms"] > 0 and ref["bwd_ms"] > 0
