@@ -565,7 +565,8 @@ def main():
                      + ("" if args.optimizer == "none" else " + " + args.optimizer + " step") + " + densification stats")
         par = {"single": "single GPU",
                "replicated": f"replicated Gaussians, {world} camera(s)/step, chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step, all-reduce of the densification stats every {DENSIFY_INTERVAL} steps",
-               "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of visible-splat records (configs/distributed.yaml)"}[mode]
+               "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of splat records (configs/distributed.yaml); "
+                          + (f"exchange format of the last step: {renderer.last_exchange}" if mode == "sharded" else "")}[mode]
         line = {
             "metric": "training images/sec + fwd/bwd ms @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(world * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,

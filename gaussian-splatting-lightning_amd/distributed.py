@@ -68,6 +68,17 @@ def gather_ints(value: int, device, group=None) -> List[int]:
     return [int(v) for v in out.tolist()]
 
 
+def gather_int_rows(values: Sequence[int], device, group=None) -> List[List[int]]:
+    """A short row of integers per rank, in rank order: ONE all-gather for everything a step has to agree on before it starts
+    (camera id, local Gaussian count, the rank's vote on the exchange format)."""
+    world = dist.get_world_size(group)
+    wire_dev = device if (is_rccl(group) or torch.device(device).type == "cpu") else "cpu"
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=wire_dev)
+    out = torch.empty((world * mine.numel(),), dtype=torch.int64, device=wire_dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return [[int(v) for v in row] for row in out.reshape(world, -1).tolist()]
+
+
 def exchange_counts(send_counts: Sequence[int], device, group=None) -> List[int]:
     """send_counts[j] = rows this rank sends to rank j -> rows it receives from each rank."""
     wire_dev = device if (is_rccl(group) or torch.device(device).type == "cpu") else "cpu"
@@ -110,6 +121,15 @@ def pack_visible(radii, means2d, depths, conics, compensations, opacities, rgbs,
     rec = torch.cat([means2d, depths.unsqueeze(-1), conics, compensations.unsqueeze(-1), opacities.reshape(-1, 1), rgbs,
                      rbits.unsqueeze(-1)], dim=-1)
     return rec[visibility]
+
+
+def pack_all(radii, means2d, depths, conics, compensations, opacities, rgbs) -> torch.Tensor:
+    """[N, 12] records of EVERY local splat for one camera, rows of invisible splats (radius <= 0) zeroed — radius 0 keeps them
+    out of the receiver's lists.  The fixed-size counterpart of `pack_visible` (no count to exchange)."""
+    rbits = radii.to(torch.int32).view(torch.float32)
+    rec = torch.cat([means2d, depths.unsqueeze(-1), conics, compensations.unsqueeze(-1), opacities.reshape(-1, 1), rgbs,
+                     rbits.unsqueeze(-1)], dim=-1)
+    return torch.where((radii > 0).unsqueeze(-1), rec, torch.zeros((), dtype=rec.dtype, device=rec.device))
 
 
 def unpack_records(rec: torch.Tensor):

@@ -794,6 +794,67 @@ def pack_visible_records(projection_results_list, rgb_list, opacities: Tensor):
     return records, [e[i + 1] - e[i] for i in range(C)]
 
 
+class _PackAllRecordsFn(torch.autograd.Function):
+    """(opacities [N], C x (radii, means2d, depths, conics, compensations, rgbs)) -> records [C*N, 12]: one row per (camera, local
+    splat), camera-major, rows of invisible splats zero.  The fixed-size exchange format: nothing about it depends on a number
+    the host would have to wait for.  Backward: `gspl_records_pack_bwd` with identity slots for the visible rows."""
+
+    @staticmethod
+    @_guarded(3)
+    def forward(ctx, C, has_comp, opacities, *flat):
+        groups = [flat[k * C:(k + 1) * C] for k in range(6)]
+        radii = _batched(groups[0])
+        if radii.dtype != torch.int32:
+            radii = radii.to(torch.int32)
+        means2d, depths, conics = (_f32c(_batched(g)) for g in groups[1:4])
+        comps = _f32c(_batched(groups[4])) if has_comp else torch.ones_like(depths)
+        rgbs = _f32c(_batched(groups[5]))
+        opac = _f32c(opacities.detach()).reshape(-1)
+        N, dev = radii.shape[1], radii.device
+        assert opac.shape[0] == N and means2d.shape == (C, N, 2) and conics.shape == (C, N, 3) and rgbs.shape == (C, N, 3)
+        vis = radii > 0
+        rec = torch.cat([means2d, depths.unsqueeze(-1), conics, comps.unsqueeze(-1), opac.reshape(1, N, 1).expand(C, N, 1), rgbs,
+                         radii.view(torch.float32).unsqueeze(-1)], dim=-1)
+        rec = torch.where(vis.unsqueeze(-1), rec, _zero_scalar(dev))
+        ident = _IDENTITY_SLOTS.get((C, N, dev))
+        if ident is None:
+            if len(_IDENTITY_SLOTS) > 8:
+                _IDENTITY_SLOTS.clear()
+            ident = _IDENTITY_SLOTS[(C, N, dev)] = torch.arange(C * N, dtype=torch.int32, device=dev).reshape(C, N)
+        slots = torch.where(vis, ident, -1)
+        ctx.save_for_backward(slots)
+        ctx.cfg = (C, N, has_comp, tuple(opacities.shape))
+        ctx.set_materialize_grads(False)
+        return rec.reshape(C * N, L.GSPL_RECORD_FLOATS)
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, v_records):
+        return _PackRecordsFn.backward(ctx, v_records, None)
+
+
+_IDENTITY_SLOTS: dict = {}
+_ZERO_SCALARS: dict = {}
+
+
+def _zero_scalar(dev):
+    z = _ZERO_SCALARS.get(dev)
+    if z is None:
+        z = _ZERO_SCALARS[dev] = torch.zeros((), dtype=torch.float32, device=dev)
+    return z
+
+
+def pack_all_records(projection_results_list, rgb_list, opacities: Tensor) -> Tensor:
+    """Records of EVERY (camera, local splat), camera-major, invisible rows zeroed (radius 0 keeps them out of the receiver's
+    lists): [C*N, 12].  Same arguments as `pack_visible_records`; no device read-back."""
+    C = len(projection_results_list)
+    has_comp = projection_results_list[0][4] is not None
+    cols = [[r[k] for r in projection_results_list] for k in range(5)]
+    if not has_comp:
+        cols[4] = [r[2] for r in projection_results_list]      # placeholder tensors (ignored)
+    return _PackAllRecordsFn.apply(C, has_comp, opacities, *cols[0], *cols[1], *cols[2], *cols[3], *cols[4], *rgb_list)
+
+
 class _UnpackRecordsFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)

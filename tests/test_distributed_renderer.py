@@ -153,7 +153,7 @@ def _close(got, ref, rel, name):
     assert_close_scaled(got.detach().cpu().double().numpy(), ref.detach().cpu().double().numpy(), rel, name, frac_ok=1.0)
 
 
-def _worker(rank, world, port, tmpdir, on_gpu):
+def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (HERE, os.path.dirname(HERE)):
@@ -183,7 +183,7 @@ def _worker(rank, world, port, tmpdir, on_gpu):
             p = g["params"][0]
             opt.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.ones_like(p), "exp_avg_sq": torch.ones_like(p)}
         module = _Module(model, [opt], world, rank, dev)
-        renderer = HipGSplatDistributedRenderer().instantiate()
+        renderer = HipGSplatDistributedRenderer(exchange=exchange).instantiate()
         assert renderer.training_setup(module) == (None, None)
         assert module.density_changes == 1 and renderer.world_size == world and renderer.global_rank == rank
         assert model.n_gaussians == hi - lo and torch.equal(model.get_property("ids").cpu(), ids[lo:hi])
@@ -202,6 +202,10 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         assert set(out) == {"render", "hard_inverse_depth", "cameras", "projection_results_list", "visible_mask_list", "xys_grad_scale_required"}
         assert out["render"].shape == (3, H_IMG, W_IMG) and len(out["cameras"]) == world and out["xys_grad_scale_required"] is True
         assert [int(c.idx) for c in out["cameras"]] == list(range(world))
+        # "auto" starts with the counted exchange (no rank has a visible share to vote with yet) and moves to the padded one when
+        # every rank saw at least half of its (camera, splat) pairs; the other two settings are fixed
+        assert renderer.last_exchange == ("counted" if exchange == "auto" else exchange)      # (auto: nobody has voted yet)
+        assert [r[1] for r in renderer._peer_rows] == [D.shard_bounds(N, world, r)[1] - D.shard_bounds(N, world, r)[0] for r in range(world)]
         for r in out["projection_results_list"]:          # what DistributedVanillaDensityControllerImpl.before_backward does
             r[1].retain_grad()
         (out["render"] * weights[rank].to(dev)).sum().backward()
@@ -250,6 +254,13 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         with torch.no_grad():
             d = renderer(camset[rank], model, bg.to(dev), render_types=["rgb", "hard_inverse_depth"])
         assert d["hard_inverse_depth"].shape == (1, H_IMG, W_IMG) and bool(torch.isfinite(d["hard_inverse_depth"]).all())
+        if exchange == "auto":                # every rank has voted by now: > 50 % of the pairs are visible in this scene
+            for _ in range(3):                # (on the GPU the visible count arrives through pinned memory, a step or two later)
+                with torch.no_grad():
+                    again = renderer(camset[rank], model, bg.to(dev))["render"]
+                torch.cuda.synchronize() if on_gpu else None
+            assert renderer.last_exchange == "padded" and min(r[2] for r in renderer._peer_rows) >= 500
+            assert float((again.cpu() - ref_renders[rank]).abs().max()) <= (2e-5 if on_gpu else 1e-9)
 
         # ---- random_redistribute: every row (parameter AND Adam moments AND non-optimised property) follows its id
         with torch.no_grad():
@@ -307,23 +318,27 @@ def _worker(rank, world, port, tmpdir, on_gpu):
         dist.destroy_process_group()
 
 
-def _run(tmp_path, on_gpu, world=2):
+def _run(tmp_path, on_gpu, world=2, exchange="counted"):
     from conftest import free_port
     port = free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), on_gpu), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), on_gpu, exchange), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-def test_world2_sharded_renderer_cpu_oracle_ops(tmp_path):
-    _run(tmp_path, False)
+@pytest.mark.parametrize("exchange", ["auto", "padded"])
+def test_world2_sharded_renderer_cpu_oracle_ops(tmp_path, exchange):
+    """auto: the graded step uses the counted exchange (the reference's scheme), later steps the padded one; padded: the graded
+    step itself sends one record per (camera, local splat) — same render, same gradients."""
+    _run(tmp_path, False, exchange=exchange)
 
 
 def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
     """Three ranks: uneven shards (3000 = 1000 + 1000 + 1000 here, but the random redistribution leaves uneven ones), three
     cameras per projection batch, three-way all-to-all."""
-    _run(tmp_path, False, world=3)
+    _run(tmp_path, False, world=3, exchange="padded")
 
 
 @pytest.mark.gpu
-def test_world2_sharded_renderer_shared_gpu(tmp_path):
-    _run(tmp_path, True)
+@pytest.mark.parametrize("exchange", ["auto", "padded"])
+def test_world2_sharded_renderer_shared_gpu(tmp_path, exchange):
+    _run(tmp_path, True, exchange=exchange)
