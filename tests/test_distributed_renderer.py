@@ -342,3 +342,25 @@ def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
 @pytest.mark.parametrize("exchange", ["auto", "padded"])
 def test_world2_sharded_renderer_shared_gpu(tmp_path, exchange):
     _run(tmp_path, True, exchange=exchange)
+
+
+def test_exchange_format_is_a_function_of_the_gathered_rows_only():
+    """Every rank must pick the same format from the same gathered rows (a mismatch would pair a padded send with a counted
+    receive): fixed settings ignore the votes; "auto" is padded only when EVERY rank has voted at least the threshold, and a
+    rank that has not seen a step yet (-1) keeps everybody on the counted format."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatDistributedRenderer
+    rows = lambda *votes: [[i, 1000, v] for i, v in enumerate(votes)]
+    r = HipGSplatDistributedRenderer(exchange="auto", padded_min_visible=0.5).instantiate()
+    for votes, expect in (((-1, -1), "counted"), ((900, -1), "counted"), ((900, 499), "counted"), ((500, 500), "padded"),
+                          ((1000, 730, 651), "padded"), ((1000, 730, 0), "counted")):
+        r._peer_rows = rows(*votes)
+        assert r._exchange_format() == expect, votes
+    for fixed in ("counted", "padded"):
+        r = HipGSplatDistributedRenderer(exchange=fixed).instantiate()
+        for votes in ((-1, -1), (1000, 1000), (0, 0)):
+            r._peer_rows = rows(*votes)
+            assert r._exchange_format() == fixed
+    with pytest.raises(ValueError):
+        HipGSplatDistributedRenderer(exchange="compressed").instantiate()
+    assert HipGSplatDistributedRenderer().exchange == "counted"          # the reference's scheme unless asked otherwise
