@@ -1,0 +1,117 @@
+// gspl_composite.h — device helpers shared by the compositing kernels (composite.hip: forward + per-splat statistics;
+// composite_bwd.hip: backward).  gfx950, wave64.
+//
+// The compositing rule restated here is the published 3DGS rule with the per-API constants of SURVEY.md Appendix B (ModeTraits
+// in gspl_device.h); call sites replaced: internal/renderers/gsplat_v1_renderer.py:588-601 (`rasterize_to_pixels`),
+// gsplat_renderer.py:86-99 (`rasterize_gaussians`), vanilla_renderer.py:111-120 (Inria `GaussianRasterizer`).
+#pragma once
+#include "gspl_device.h"
+#include "gspl_host.h"
+
+namespace gspl {
+
+static constexpr int TILE = 16;
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// sigma = 0.5 (a dx^2 + c dy^2) + b dx dy, written with explicit fma so that forward and backward
+// evaluate bit-identical values (the skip / stop decisions of the two passes must agree).
+__device__ __forceinline__ float eval_sigma(float half_a, float b, float half_c, float dx, float dy) {
+    return fmaf(half_a * dx, dx, fmaf(half_c * dy, dy, (b * dx) * dy));
+}
+
+// Two splats (or two pixels) at once with packed fp32 math; each component is bit-identical to eval_sigma.
+__device__ __forceinline__ v2f eval_sigma2(v2f half_a, v2f b, v2f half_c, v2f dx, v2f dy) {
+    return __builtin_elementwise_fma(half_a * dx, dx, __builtin_elementwise_fma(half_c * dy, dy, (b * dx) * dy));
+}
+
+// Exact test "can this splat reach alpha >= 1/255 at some pixel centre of the box [x0,x1] x [y0,y1]" (continuous box,
+// conservative margins).  alpha >= 1/255  <=>  sigma <= tau = ln(255 o); the x-span of (ellipse 1/2 d^T Q d <= tau) intersected
+// with the band dy in [y0-my, y1-my] is [left, right] with right = hx if the ellipse's rightmost point lies in the band, else
+// the larger chord end at the band edges (see binning.hip, row_span); the box is reachable iff that span meets [x0, x1].
+// The margins absorb the 1-ulp hardware rcp / sqrt and the fp32 rounding of exp / log: a pair the exact per-pixel test would keep
+// is never culled; candidates still go through the exact per-pixel test.
+__device__ __forceinline__ bool box_reachable(float mx, float my, float a, float b, float c, float opacity,
+                                              float x0, float x1, float y0, float y1) {
+    const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
+    if (!(tau > 0.f)) return false;
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return true;     // not an ellipse: never cull
+    const float two_tau = 2.f * tau;
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    const float hy = __builtin_amdgcn_sqrtf(two_tau * a * rdet) * 1.0004f + 1e-3f;
+    float lo = y0 - my, hi = y1 - my;
+    if (hi < -hy || lo > hy) return false;
+    lo = fmaxf(lo, -hy); hi = fminf(hi, hy);
+    const float tta = two_tau * a;
+    const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * lo * lo));
+    const float rhi = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * hi * hi));
+    const float hx = __builtin_amdgcn_sqrtf(two_tau * c * rdet);
+    const float dys = b * __builtin_amdgcn_sqrtf(two_tau * rdet * __builtin_amdgcn_rcpf(c));
+    const float inv_a = __builtin_amdgcn_rcpf(a);
+    const float right = (-dys >= lo && -dys <= hi) ? hx : fmaxf((-b * lo + rlo) * inv_a, (-b * hi + rhi) * inv_a);
+    const float left = (dys >= lo && dys <= hi) ? -hx : fminf((-b * lo - rlo) * inv_a, (-b * hi - rhi) * inv_a);
+    const float eps = 2e-3f + 5e-4f * hx;
+    return (mx + right + eps >= x0) && (mx + left - eps <= x1);
+}
+
+// box_reachable for a GRID of boxes of one tile at once: BANDS horizontal bands of 16 / BANDS pixel rows, each cut into a left and
+// a right half of 8 pixel columns.  Bit (2 * band + half) of the result = that 8 x (16 / BANDS) box is reachable.  The per-splat
+// terms (tau, extents, the tangent offset) are shared, the chord ends are per band.  (tx0, ty0) is the centre of the tile's first
+// pixel.  BANDS = 2: the four 8x8 quadrants; BANDS = 4: eight 8x4 units.
+template <int BANDS>
+__device__ __forceinline__ unsigned band_half_mask(float mx, float my, float a, float b, float c, float opacity, float tx0, float ty0) {
+    constexpr float BH = (float)(TILE / BANDS);
+    const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
+    if (!(tau > 0.f)) return 0u;
+    const float det = a * c - b * b;
+    if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return (1u << (2 * BANDS)) - 1u;      // not an ellipse: never cull
+    const float two_tau = 2.f * tau;
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    const float hy = __builtin_amdgcn_sqrtf(two_tau * a * rdet) * 1.0004f + 1e-3f;
+    const float tta = two_tau * a;
+    const float hx = __builtin_amdgcn_sqrtf(two_tau * c * rdet);
+    const float dys = b * __builtin_amdgcn_sqrtf(two_tau * rdet * __builtin_amdgcn_rcpf(c));
+    const float inv_a = __builtin_amdgcn_rcpf(a);
+    const float eps = 2e-3f + 5e-4f * hx;
+    unsigned m = 0u;
+#pragma unroll
+    for (int band = 0; band < BANDS; ++band) {
+        const float y0 = ty0 + BH * (float)band;
+        float lo = y0 - my, hi = (y0 + (BH - 1.f)) - my;
+        if (hi < -hy || lo > hy) continue;
+        lo = fmaxf(lo, -hy); hi = fminf(hi, hy);
+        const float rlo = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * lo * lo));
+        const float rhi = __builtin_amdgcn_sqrtf(fmaxf(0.f, tta - det * hi * hi));
+        const float right = (-dys >= lo && -dys <= hi) ? hx : fmaxf((-b * lo + rlo) * inv_a, (-b * hi + rhi) * inv_a);
+        const float left = (dys >= lo && dys <= hi) ? -hx : fminf((-b * lo - rlo) * inv_a, (-b * hi - rhi) * inv_a);
+        const float xr = mx + right + eps, xl = mx + left - eps;
+        if (xr >= tx0 && xl <= tx0 + 7.f) m |= 1u << (2 * band);
+        if (xr >= tx0 + 8.f && xl <= tx0 + 15.f) m |= 2u << (2 * band);
+    }
+    return m;
+}
+
+__device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isects,
+                                           const int32_t* __restrict__ offsets, int& start, int& end) {
+    start = offsets[tile];
+    // n_isects < 0: `offsets` has n_tiles + 1 entries, the last one is the list length (device-side count, gspl_bin_sort_device_count)
+    end = (tile + 1 < n_tiles || n_isects < 0) ? offsets[tile + 1] : (int)n_isects;
+}
+
+// number of per-splat gradient values accumulated per (tile, splat): xy(2) conic(3) opacity(1) colour(D) [+abs xy(2)]
+template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (ABS ? 2 : 0); };
+
+int check_composite_args(int N, int64_t n_isects, int D, int mode, int layout, int width, int height,
+                         int tile_size, int tile_w, int tile_h, const char* who);
+
+}  // namespace gspl
+
+#define GSPL_DISPATCH_D(D_, MODE_, CHW_, CALL)                    \
+    switch (D_) {                                                 \
+        case 1: { constexpr int kD = 1; CALL(kD, MODE_, CHW_); } break; \
+        case 2: { constexpr int kD = 2; CALL(kD, MODE_, CHW_); } break; \
+        case 3: { constexpr int kD = 3; CALL(kD, MODE_, CHW_); } break; \
+        case 4: { constexpr int kD = 4; CALL(kD, MODE_, CHW_); } break; \
+        case 8: { constexpr int kD = 8; CALL(kD, MODE_, CHW_); } break; \
+    }

@@ -373,6 +373,9 @@ __device__ __forceinline__ float row_sum(float v) {
     }
 GSPL_DPP_ADD_INPLACE(row_mirror_add, "row_mirror")
 GSPL_DPP_ADD_INPLACE(row_ror8_add, "row_ror:8")
+GSPL_DPP_ADD_INPLACE(quad_xor1_add, "quad_perm:[1,0,3,2]")
+GSPL_DPP_ADD_INPLACE(quad_xor2_add, "quad_perm:[2,3,0,1]")
+GSPL_DPP_ADD_INPLACE(half_mirror_add, "row_half_mirror")
 
 // Sum over the 64 lanes of the wave; the total is valid in lane 63 (row 3).
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {

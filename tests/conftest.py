@@ -26,6 +26,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / by the driver)")
 
 
+# Collection order (the driver runs `pytest -x`): the hot path's HIP-vs-oracle parity first, the functions either side of it next,
+# everything that spawns processes or drives whole training loops last — so that a failure in a side feature can never keep the
+# hot-path parity tests from running.  Files not listed keep their alphabetical place between the two groups.
+_FIRST = ["test_abi", "test_oracle_golden", "test_oracle_composite", "test_hip_parity", "test_metric_point_parity", "test_renderers_gpu",
+          "test_tile_sizes", "test_sort", "test_sh_batched", "test_camera_models", "test_backward_spread", "test_loss", "test_knn", "test_scores",
+          "test_records", "test_adam", "test_density", "test_formats", "test_upstream_golden"]
+_LAST = ["test_training_loop", "test_package_shims", "test_bench_contract", "test_distributed_gloo", "test_allreduce_step",
+         "test_rccl_single_rank", "test_distributed_renderer"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if name in _FIRST:
+            return (0, _FIRST.index(name))
+        if name in _LAST:
+            return (2, _LAST.index(name))
+        return (1, 0)
+    items.sort(key=rank)        # stable: the order inside a file is kept
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
