@@ -1,48 +1,65 @@
-"""Optimizer surgery the renderers need when they replace a model's tensors (sharding at setup).
+"""Optimizer surgery the sharded renderer needs when it swaps a model's property tensors (sharding at setup).
 
-Inside the reference repository `internal.density_controllers.density_controller.Utils.replace_tensors_to_properties`
-(density_controller.py:148-203) is used as is; stand-alone (tests, bench) the function below has the same behaviour:
-every optimizer group whose name appears in `tensors` gets the tensor as its new (single) parameter and its Adam moments
-reset (or only the `selector` rows of them); names no optimizer knows become non-trainable parameters."""
+Contract (what `HipGSplatDistributedRendererImpl.training_setup` relies on; the reference gets the same effect from its density
+controller utilities, internal/density_controllers/density_controller.py:148-203, which are used when that package is importable):
+    * `tensors` maps property names to the tensors that replace the model's current ones;
+    * a name that an optimizer trains (a param group called `name` with exactly one parameter) becomes a fresh trainable Parameter in
+      that group, and the optimizer state of the old parameter moves to the new one with its per-row moments cleared — all rows, or
+      only the rows `selector` picks;
+    * every other name becomes a frozen Parameter;
+    * the result maps every name to its Parameter.
+"""
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict, List, Tuple
 
 import torch
 
 
-def _own_replace(tensors: Dict[str, torch.Tensor], optimizers: List[torch.optim.Optimizer], selector=None) -> Dict[str, torch.Tensor]:
-    new_parameters = {}
-    for opt in optimizers:
-        for group in opt.param_groups:
-            tensor = tensors.get(group["name"], None)
-            if tensor is None:
+def _groups_by_name(optimizers: List[torch.optim.Optimizer]) -> Dict[str, Tuple[torch.optim.Optimizer, dict]]:
+    index: Dict[str, Tuple[torch.optim.Optimizer, dict]] = {}
+    for optimizer in optimizers:
+        for group in optimizer.param_groups:
+            name = group.get("name")
+            if name is None:
                 continue
-            assert len(group["params"]) == 1
-            assert group["name"] not in new_parameters, "parameter `{}` appears in multiple optimizers".format(group["name"])
-            old = group["params"][0]
-            state = opt.state.get(old, None)
-            new = torch.nn.Parameter(tensor.requires_grad_(True))
-            if state is not None:
-                if selector is not None:
-                    state["exp_avg"][selector] = 0
-                    state["exp_avg_sq"][selector] = 0
+            if name in index:
+                raise ValueError(f"property {name!r} is trained by more than one optimizer group")
+            index[name] = (optimizer, group)
+    return index
+
+
+def _swap_parameters(tensors: Dict[str, torch.Tensor], optimizers: List[torch.optim.Optimizer], selector=None) -> Dict[str, torch.nn.Parameter]:
+    index = _groups_by_name(optimizers)
+    out: Dict[str, torch.nn.Parameter] = {}
+    for name, tensor in tensors.items():
+        owner = index.get(name)
+        if owner is None:
+            out[name] = torch.nn.Parameter(tensor, requires_grad=False)
+            continue
+        optimizer, group = owner
+        if len(group["params"]) != 1:
+            raise ValueError(f"optimizer group {name!r} holds {len(group['params'])} parameters, expected one")
+        previous = group["params"][0]
+        fresh = torch.nn.Parameter(tensor.requires_grad_(True))
+        state = optimizer.state.pop(previous, None)
+        if state is not None:
+            for key in ("exp_avg", "exp_avg_sq"):
+                if key not in state:
+                    continue
+                if selector is None:
+                    state[key] = torch.zeros_like(tensor)
                 else:
-                    state["exp_avg"] = torch.zeros_like(tensor)
-                    state["exp_avg_sq"] = torch.zeros_like(tensor)
-                del opt.state[old]
-                opt.state[new] = state
-            group["params"][0] = new
-            new_parameters[group["name"]] = new
-    for k, v in tensors.items():
-        if k not in new_parameters:
-            new_parameters[k] = torch.nn.Parameter(v, requires_grad=False)
-    return new_parameters
+                    state[key][selector] = 0
+            optimizer.state[fresh] = state
+        group["params"][0] = fresh
+        out[name] = fresh
+    return out
 
 
 def replace_tensors_to_properties(tensors: Dict[str, torch.Tensor], optimizers, selector=None) -> Dict[str, torch.Tensor]:
     try:  # pragma: no cover - only inside the reference repo (needs lightning)
         from internal.density_controllers.density_controller import Utils  # type: ignore
-        return Utils.replace_tensors_to_properties(tensors, optimizers, selector)
     except Exception:
-        return _own_replace(tensors, optimizers, selector)
+        return _swap_parameters(tensors, optimizers, selector)
+    return Utils.replace_tensors_to_properties(tensors, optimizers, selector)

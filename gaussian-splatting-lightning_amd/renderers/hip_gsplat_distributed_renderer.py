@@ -140,12 +140,13 @@ class HipGSplatDistributedRendererImpl(Renderer):
     def gather_cameras(self, viewpoint_camera, n_local: int = 0):
         """Camera of every rank, in rank order.  The same all-gather carries what else the ranks have to agree on before the
         step: every rank's local Gaussian count (the fixed split sizes of a padded exchange) and its visible share."""
-        self._poll_visible()
         if self._world() == 1 and (D.SINGLE_RANK_SHORTCUT or not dist.is_initialized()):
+            self._poll_visible()
             self._peer_rows = [[0, int(n_local), self._visible_permille]]
             return [viewpoint_camera]
         cams = []
-        idx = int(camera_scalars(viewpoint_camera, ("idx",))[0])
+        idx = int(camera_scalars(viewpoint_camera, ("idx",))[0])      # (a device read-back: orders the host past the previous forward)
+        self._poll_visible()
         mine = [idx, int(n_local), self._visible_permille]
         dev = torch.device(viewpoint_camera.device)
         if dev.type == "cuda" and D.is_rccl(self.group):
@@ -198,18 +199,22 @@ class HipGSplatDistributedRendererImpl(Renderer):
 
     def _camera_batch(self, cameras, device):
         """Stacked view matrices [W,4,4], intrinsics [W,3,3] and centres [W,3] of a camera set, built once per set: a training
-        run cycles through a fixed set of (camera, camera, ...) tuples, and the three stacks cost a dozen small launches."""
-        k = lambda v: (v.data_ptr(), v._version) if isinstance(v, torch.Tensor) else float(v)      # no device read-back for tensors
-        key = tuple((k(c.world_to_camera), k(c.camera_center), k(c.fx), k(c.fy), k(c.cx), k(c.cy)) for c in cameras) + (str(device),)
+        run cycles through a fixed set of (camera, camera, ...) tuples, and the three stacks cost a dozen small launches.
+        A cache entry KEEPS its source tensors and is valid only while every one of them is the same object at the same version
+        (as `GSplatV1.preprocess_camera`): an address handed out again by the allocator to a new camera's tensor can never match."""
+        src = tuple(v for c in cameras for v in (c.world_to_camera, c.camera_center, c.fx, c.fy, c.cx, c.cy))
+        key = tuple((id(v), v._version) if isinstance(v, torch.Tensor) else float(v) for v in src) + (str(device),)
         cache = self.__dict__.setdefault("_camera_batches", {})
         hit = cache.get(key)
-        if hit is None:
-            if len(cache) > 4096:
-                cache.clear()
-            hit = cache[key] = (torch.stack([c.world_to_camera.T for c in cameras]).contiguous(),
-                                torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, device) for c in cameras]).contiguous(),
-                                torch.stack([c.camera_center for c in cameras]).contiguous())
-        return hit
+        if hit is not None and len(hit[0]) == len(src) and all((a is b) if isinstance(b, torch.Tensor) else (a == b) for a, b in zip(hit[0], src)):
+            return hit[1]
+        if len(cache) > 256:
+            cache.clear()
+        stacks = (torch.stack([c.world_to_camera.T for c in cameras]).contiguous(),
+                  torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, device) for c in cameras]).contiguous(),
+                  torch.stack([c.camera_center for c in cameras]).contiguous())
+        cache[key] = (src, stacks)
+        return stacks
 
     def non_batch_project(self, cameras, pc, scales, scaling_modifier):
         """Cameras of different sizes: one projection and one SH launch per camera (reference :238-250)."""
@@ -261,6 +266,10 @@ class HipGSplatDistributedRendererImpl(Renderer):
                         word = self.__dict__.get("_visible_word")
                         if word is None:
                             word = self.__dict__["_visible_word"] = torch.empty((1,), dtype=torch.int64).pin_memory()
+                        stale = self._visible_pending
+                        if stale is not None:           # a count nobody picked up: its event goes back to the pool once it has fired
+                            stale[0].synchronize()
+                            ops._EVENTS.setdefault(stale[3], []).append(stale[0])
                         word.copy_(n_vis, non_blocking=True)
                         ev = ops._take_event(opacities.device)
                         ev.record()

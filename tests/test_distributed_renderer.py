@@ -8,7 +8,8 @@ and the per-camera screen-space gradients the distributed density controller rea
 optimizer surgery) and `random_redistribute` (Adam moments must follow their parameters).
 
   * `-m gpu`     : both processes share cuda:0 (gloo, payload staged through the host — RCCL refuses two ranks on one
-                   device); every op is the HIP op; the one-process reference is `HipGSplatV1Renderer`.
+                   device); every op is the HIP op; checked against the fp64 oracle of the full model (`oracle.render_gsplat`)
+                   AND against the one-process `HipGSplatV1Renderer`, both with the tiered tolerances of hip_helpers.
   * `-m "not gpu"`: CPU processes; the HIP ops are replaced IN THIS TEST by the fp64 oracle stages, so the renderer's
                    host logic, the exchange and its autograd route run without a GPU; reference = `oracle.render_gsplat`.
 """
@@ -148,9 +149,17 @@ class _Module:
         self.density_changes += 1
 
 
-def _close(got, ref, rel, name):
+def _close(got, ref, rel, name, tiered=False):
+    """CPU variant (fp64 oracle ops on both sides): every element within `rel`.  GPU variant (`tiered`): the tiers every other
+    HIP-vs-oracle gradient test uses — >= 99.9 % of the elements within `rel`, every element within 0.05 (a splat whose alpha meets
+    the 1/255 threshold within the fp32-vs-fp64 difference of exp/rcp gains or loses one pixel: bounded and counted, never a
+    systematic error)."""
     from hip_helpers import assert_close_scaled
-    assert_close_scaled(got.detach().cpu().double().numpy(), ref.detach().cpu().double().numpy(), rel, name, frac_ok=1.0)
+    g, r = got.detach().cpu().double().numpy(), ref.detach().cpu().double().numpy()
+    if tiered:
+        assert_close_scaled(g, r, rel, name, frac_ok=0.999, rel_all=0.05)
+    else:
+        assert_close_scaled(g, r, rel, name, frac_ok=1.0)
 
 
 def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
@@ -210,17 +219,35 @@ def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
             r[1].retain_grad()
         (out["render"] * weights[rank].to(dev)).sum().backward()
         ref_renders, ref_grads, ref_xy = _reference_full_model(on_gpu, params, cams, weights, bg, dev)
-        diff = (out["render"].detach().cpu() - ref_renders[rank]).abs()
-        assert float(diff.max()) <= (2e-5 if on_gpu else 1e-9), float(diff.max())
-        tol = 2e-4 if on_gpu else 1e-8
         names = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
-        for name, ref in zip(names, ref_grads):
-            got = model.get_property(name).grad
-            assert got is not None and got.shape[0] == hi - lo, name
-            _close(got, ref[lo:hi], tol, name)
-        for i, r in enumerate(out["projection_results_list"]):
-            assert torch.equal(out["visible_mask_list"][i], r[0] > 0)
-            _close(r[1].grad, ref_xy[i].reshape(N, 2)[lo:hi], tol, f"xys grad of camera {i}")
+        if on_gpu:
+            # (1) against the fp64 ORACLE of the one-process pipeline (oracle.render_gsplat on the full model, as the CPU variant);
+            # (2) against the one-process HIP renderer (same kernels, unsharded): sharding must not change anything beyond the
+            # order of the fp32 atomics.
+            from hip_helpers import assert_pixels_close
+            p64 = [p.double() for p in params]
+            orc_renders, orc_grads, orc_xy = _reference_full_model(False, p64, cams, [w.double() for w in weights], bg.double(), torch.device("cpu"))
+            assert_pixels_close(out["render"].detach().cpu().double().numpy(), orc_renders[rank].numpy(), tol=2e-5, name="render vs fp64 oracle")
+            assert float((out["render"].detach().cpu() - ref_renders[rank]).abs().max()) <= 2e-5
+            for name, ref, orc in zip(names, ref_grads, orc_grads):
+                got = model.get_property(name).grad
+                assert got is not None and got.shape[0] == hi - lo, name
+                _close(got, orc[lo:hi], 2e-4, name + " vs fp64 oracle", tiered=True)
+                _close(got, ref[lo:hi], 2e-4, name + " vs one-process HIP", tiered=True)
+            for i, r in enumerate(out["projection_results_list"]):
+                assert torch.equal(out["visible_mask_list"][i], r[0] > 0)
+                _close(r[1].grad, orc_xy[i].reshape(N, 2)[lo:hi], 2e-4, f"xys grad of camera {i} vs fp64 oracle", tiered=True)
+                _close(r[1].grad, ref_xy[i].reshape(N, 2)[lo:hi], 2e-4, f"xys grad of camera {i} vs one-process HIP", tiered=True)
+        else:
+            diff = (out["render"].detach().cpu() - ref_renders[rank]).abs()
+            assert float(diff.max()) <= 1e-9, float(diff.max())
+            for name, ref in zip(names, ref_grads):
+                got = model.get_property(name).grad
+                assert got is not None and got.shape[0] == hi - lo, name
+                _close(got, ref[lo:hi], 1e-8, name)
+            for i, r in enumerate(out["projection_results_list"]):
+                assert torch.equal(out["visible_mask_list"][i], r[0] > 0)
+                _close(r[1].grad, ref_xy[i].reshape(N, 2)[lo:hi], 1e-8, f"xys grad of camera {i}")
         # ---- the reference's own DistributedVanillaDensityControllerImpl consumes these outputs (lightning stubbed; only where the
         # reference tree exists — not on the GPU box): its statistics buffers equal the sums computed by hand
         ref_root = os.environ.get("GSPL_REFERENCE_ROOT", "/root/reference")
@@ -364,3 +391,28 @@ def test_exchange_format_is_a_function_of_the_gathered_rows_only():
     with pytest.raises(ValueError):
         HipGSplatDistributedRenderer(exchange="compressed").instantiate()
     assert HipGSplatDistributedRenderer().exchange == "counted"          # the reference's scheme unless asked otherwise
+
+
+def test_camera_batch_cache_is_keyed_on_tensor_identity_and_version():
+    """the stacked view matrices of a camera set must never be served for other cameras.  The cache entry keeps its
+    source tensors (so their addresses cannot be handed out again while it lives) and is valid only for the same tensor objects
+    at the same version: a new camera object misses, an in-place pose edit misses."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatDistributedRenderer
+    from fakes import FakeCamera
+    r = HipGSplatDistributedRenderer().instantiate()
+    dev = torch.device("cpu")
+    cams = [FakeCamera(c, dev) for c in _cameras(2)]
+    a = r._camera_batch(cams, dev)
+    assert r._camera_batch(cams, dev) is a                               # same objects, same versions: served from the cache
+    assert torch.equal(a[0][1], cams[1].world_to_camera.T) and torch.equal(a[2][0], cams[0].camera_center)
+    fresh = [FakeCamera(c, dev) for c in _cameras(2)]                    # equal values, different tensor objects
+    fresh[1].world_to_camera = fresh[1].world_to_camera.clone()
+    fresh[1].world_to_camera[3, 0] += 0.25
+    b = r._camera_batch(fresh, dev)
+    assert b is not a and float(b[0][1][0, 3]) == pytest.approx(float(a[0][1][0, 3]) + 0.25)
+    cams[0].world_to_camera[3, 2] += 1.0                                 # in-place edit: version counter moves
+    c = r._camera_batch(cams, dev)
+    assert c is not a and float(c[0][0][2, 3]) == pytest.approx(float(a[0][0][2, 3]) + 1.0)
+    held = [e[0] for e in r._camera_batches.values()]
+    assert any(any(v is cams[0].world_to_camera for v in src) for src in held)      # entries hold their sources
