@@ -59,8 +59,12 @@ FP32_PEAK_TFLOPS = 157.3       # vector fp32
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--cameras", type=int, default=16,
+                   help="size of the synthetic camera set the steps cycle through (one camera per rank per step, as the reference's data "
+                        "loader hands them out, internal/dataset.py:146-184); 1 = the fixed camera of rounds 1-2")
+    p.add_argument("--no-stage-rooflines", action="store_true", help="skip the staged pass that times every stage for `stage_rooflines`")
     p.add_argument("--workload", default="S-1080p-1M")
     p.add_argument("--api", default="vanilla", choices=["vanilla", "gsplat"])
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
@@ -91,30 +95,37 @@ def _mark():
     return e
 
 
-def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
-    """One training step (forward, loss, backward).  With state["marks"] = [] the step leaves three events per call
-    (start, before backward, after backward) for the fwd_ms / bwd_ms of the bench line."""
+def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
+    """One training step (forward, loss, backward) on the next camera of `cams` (call k of rank r takes camera (k * world + r) mod
+    len(cams)).  With state["marks"] = [] the step leaves three events per call (start, before backward, after backward) for the
+    fwd_ms / bwd_ms of the bench line."""
     import gspl_amd  # noqa: F401
     from gspl_amd import ops
     m, s, q, o, c = tensors
     W, H = wl["width"], wl["height"]
     bg = torch.zeros(3, device=dev)
     target = torch.full((3, H, W), 0.5, device=dev)
-    state = {}
+    state = {"k": 0}
     if loss_kind == "photometric":
         loss_fn = lambda img: ops.photometric_loss(img, target, 0.2)
     else:
         loss_fn = lambda img: (img - target).abs().mean()
+
+    def next_camera():
+        i = (state["k"] * world + rank) % len(cams)
+        state["k"] += 1
+        state["camera"] = i
+        return i
     if api == "vanilla":
-        settings = ops.GaussianRasterizationSettings(
+        rasts = [ops.GaussianRasterizer(ops.GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
             viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=3,
-            campos=cam["camera_center"].to(dev))
-        rast = ops.GaussianRasterizer(settings)
+            campos=cam["camera_center"].to(dev))) for cam in cams]
 
         def step():
             for t in tensors:
                 t.grad = None
+            rast = rasts[next_camera()]
             marks = state.get("marks")
             if marks is not None:
                 marks.append(_mark())
@@ -130,13 +141,15 @@ def make_step(api, dev, wl, cam, tensors, loss_kind="l1"):
             state["grad_scale"] = None
             return state
     else:
-        vm = cam["world_to_camera"].T.contiguous().to(dev)
-        center = cam["camera_center"].to(dev)
+        vms = [cam["world_to_camera"].T.contiguous().to(dev) for cam in cams]
+        centers = [cam["camera_center"].to(dev) for cam in cams]
         grad_scale = torch.tensor([0.5 * W, 0.5 * H], device=dev)      # what the renderers return as viewspace_points_grad_scale
 
         def step():
             for t in tensors:
                 t.grad = None
+            i = next_camera()
+            cam, vm, center = cams[i], vms[i], centers[i]
             marks = state.get("marks")
             if marks is not None:
                 marks.append(_mark())
@@ -281,6 +294,45 @@ def reference_projection_sh(workload_name, cores):
             "sample": f"{workload_name}: reference project_gaussians + eval_sh (degree 3), fp32, 1 warm-up + min of 3, sum() losses"}
 
 
+def kernel_source_sha16():
+    """Fingerprint of the compositing kernels' sources: a stored PMC traffic figure is only valid for the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("composite_bwd.hip", "composite.hip", "gspl_composite.h"):
+        with open(os.path.join(ROOT, "gaussian-splatting-lightning_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload_key, kernel):
+    """(HBM bytes per launch, where the figure comes from) for the graded kernel, from the newest profiles/*_pmc_traffic.json whose
+    recorded ABI version, kernel name and kernel-source fingerprint match what is loaded NOW (tools/make_pmc_traffic.py writes them;
+    counters cannot be collected inside this run — rocprofv3 PMC passes are separate runs).  Anything else is refused: (None, why)."""
+    from gspl_amd import _lib
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)
+    why = "no profiles/*_pmc_traffic.json"
+    for path in files:
+        name = os.path.basename(path)
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+        except (OSError, ValueError) as e:
+            why = f"{name}: unreadable ({e})"
+            continue
+        entry = (doc.get(workload_key) or {}).get(kernel) or {}
+        if not entry.get("traffic_bytes"):
+            why = f"{name}: no entry for {workload_key} / {kernel}"
+            continue
+        meta = doc.get("_measured_on") or {}
+        if meta.get("abi_version") != _lib.ABI_VERSION or meta.get("kernel_source_sha16") != kernel_source_sha16():
+            why = (f"{name} REFUSED: measured on ABI {meta.get('abi_version')} / sources {meta.get('kernel_source_sha16')}, "
+                   f"loaded ABI {_lib.ABI_VERSION} / sources {kernel_source_sha16()}")
+            continue
+        return entry["traffic_bytes"], f"profiles/{name} ({entry.get('source', 'PMC passes')}; same ABI and kernel sources as this run)"
+    return None, why
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -323,9 +375,10 @@ def main():
     wl = synthetic.WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
     means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
-    # every rank renders its own camera (cameras sharded): a small per-rank dolly keeps the work equal
-    cam_dicts = [synthetic.camera(W, H, wl["fx"], distance=wl.get("distance", 4.0) + 0.01 * r) for r in range(world)]
-    cam = cam_dicts[rank]
+    # The camera set the steps cycle through: rank r takes camera (k * world + r) mod n at its step k (cameras sharded over the
+    # ranks, one per rank per step).  Camera 0 is the pose the workload is defined on.
+    n_cams = max(args.cameras, world)
+    cam_dicts = synthetic.camera_set(W, H, wl["fx"], count=n_cams, distance=wl.get("distance", 4.0))
     # eps 1e-15 as the reference (internal/models/vanilla_gaussian.py:266-300).  The bench tensors are ACTIVATED values
     # (post-exp scales, post-sigmoid opacities), so the reference's learning rates — meant for the raw parameters —
     # are scaled down by 1e3: the optimizer's cost is measured without letting the synthetic scene drift.
@@ -365,10 +418,12 @@ def main():
         def step():
             for t in tensors:
                 t.grad = None
+            mine = cams[(state.setdefault("k", 0) * world + rank) % len(cams)]
+            state["k"] += 1
             marks = state.get("marks")
             if marks is not None:
                 marks.append(_mark())
-            out = renderer(cams[rank], model, bg)
+            out = renderer(mine, model, bg)
             for r in out["projection_results_list"]:      # DistributedVanillaDensityControllerImpl.before_backward
                 r[1].retain_grad()
             loss = loss_fn(out["render"])
@@ -390,7 +445,7 @@ def main():
     else:
         tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
         N = wl["n"]
-        step = make_step(args.api, dev, wl, cam, tensors, args.loss)
+        step = make_step(args.api, dev, wl, cam_dicts, tensors, args.loss, rank, world)
         lrs = LRS
 
         def stats(st, accum, denom, max_radii):
@@ -449,6 +504,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         torch.cuda.synchronize()
         step.state["marks"] = []
+        ops.SPECULATION.update(frames=0, cold=0, misses=0)
         # the roofline needs the launch duration of the graded kernel from HIP events on its stream; an event pair idles the stream
         # for ~6 us on either side of the launch, so only every fourth compositing launch of the timed region is bracketed
         _lib.profile_start(None if args.stage_times else ("gspl_composite_bwd_packed", "gspl_composite_bwd", "gspl_composite_fwd"),
@@ -474,15 +530,12 @@ def main():
     elapsed, prof, marks = timed_region(make_full_step(optimizer, args.optimizer), args.steps, args.warmup)
     phase_fwd = sum(marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)) / args.steps
     phase_bwd = sum(marks[i + 1].elapsed_time(marks[i + 2]) for i in range(0, len(marks), 3)) / args.steps
-    if os.environ.get("GSPL_BENCH_DUMP") and rank == 0:
-        # per-step device times, for hunting outliers: step span = start of step i to start of step i+1
-        starts = marks[0::3]
-        spans = [starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1)]
-        fw = [marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)]
-        srt = sorted(spans)
-        print("step spans ms: median %.3f p90 %.3f p99 %.3f max %.3f; outliers (>2x median): %s" % (
-            srt[len(srt) // 2], srt[int(len(srt) * 0.9)], srt[int(len(srt) * 0.99)], srt[-1],
-            [(i, round(x, 2), round(fw[i], 2)) for i, x in enumerate(spans) if x > 2 * srt[len(srt) // 2]][:40]), file=sys.stderr)
+    speculation = dict(ops.SPECULATION)
+    # device-side span of every step of the timed region: start of step i to start of step i + 1
+    starts = marks[0::3]
+    spans = sorted(starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1))
+    pct = (lambda q: round(spans[min(len(spans) - 1, int(q * len(spans)))], 4)) if spans else (lambda q: None)
+    step_ms = {"p50": pct(0.50), "p90": pct(0.90), "p99": pct(0.99), "max": round(spans[-1], 4) if spans else None}
     renderer_only = None
     if world == 1 and optimizer is not None and not args.no_renderer_only:
         # second timed region of the same run: the step without a parameter update (round 1's `value`)
@@ -491,18 +544,65 @@ def main():
                          "fwd_ms": round(sum(m2[i].elapsed_time(m2[i + 1]) for i in range(0, len(m2), 3)) / args.steps, 4),
                          "bwd_ms": round(sum(m2[i + 1].elapsed_time(m2[i + 2]) for i in range(0, len(m2), 3)) / args.steps, 4)}
 
-    I_sharded = None
-    if mode == "sharded":
-        # every tile-rect intersection of rank 0's camera (the I of the byte model): each rank counts the rects of ITS shard for
-        # that camera, the counts are summed over the ranks (after the timed region; all ranks take part)
-        with torch.no_grad():
-            m, s, q = tensors[0], tensors[1], tensors[2]
-            c0 = cam_dicts[0]
-            vm = c0["world_to_camera"].T.contiguous().to(dev)
-            n_rects = ops.project_gaussians(m, s, 1.0, q, vm[:3], c0["fx"], c0["fy"], c0["cx"], c0["cy"], H, W, 16)[5].sum(dtype=torch.int64)
-            if dist is not None:
-                dist.all_reduce(n_rects, op=dist.ReduceOp.SUM)
-            I_sharded = int(n_rects.item())
+    # ---- the workload the byte / flop models are evaluated on: per camera of the set, averaged --------------------------------
+    # I = every tile-rect intersection of the API benched, I' = list entries the kernels walk after the lossless
+    # tile culling, V = visible splats, valid pairs = (pixel, splat) pairs the compositing blends (COUNTED on the device).
+    per_cam = []
+    with torch.no_grad():
+        if mode == "sharded":
+            m, s_, q = tensors[0], tensors[1], tensors[2]
+            for c0 in cam_dicts:
+                vm = c0["world_to_camera"].T.contiguous().to(dev)
+                pr = ops.project_gaussians(m, s_, 1.0, q, vm[:3], c0["fx"], c0["fy"], c0["cx"], c0["cy"], H, W, 16)
+                cnt = torch.stack([pr[5].sum(dtype=torch.int64), (pr[2] > 0).sum(dtype=torch.int64)])
+                if dist is not None:
+                    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+                per_cam.append({"I": int(cnt[0].item()), "V": int(cnt[1].item())})
+            if rank == 0 and ops.LAST_RASTER is not None:      # lists and blended pairs of rank 0's last frame (its own camera)
+                last = ops.LAST_RASTER
+                count = ops.composite_scores(last["means2d"], last["conics"], last["opacities"], W, H, 16, last["offsets"],
+                                             last["flatten_ids"], mode=last["mode"])[0]
+                for e in per_cam:
+                    e["list_entries"], e["valid_pairs"] = int(last["flatten_ids"].shape[0]), int(count.sum(dtype=torch.int64).item())
+        elif rank == 0:
+            probe = make_step(api, dev, wl, cam_dicts, tensors, args.loss, 0, 1)
+            for i, c0 in enumerate(cam_dicts):
+                with torch.enable_grad():
+                    probe()                                   # one step on camera i: leaves its projected splats and lists in LAST_RASTER
+                last = ops.LAST_RASTER
+                count = ops.composite_scores(last["means2d"], last["conics"], last["opacities"], W, H, 16, last["offsets"],
+                                             last["flatten_ids"], mode=last["mode"])[0]
+                entry = {"list_entries": int(last["flatten_ids"].shape[0]), "valid_pairs": int(count.sum(dtype=torch.int64).item())}
+                if api == "vanilla":      # every tile-rect intersection in the Inria convention: the same binning without culling
+                    entry["I"] = int(ops.bin_gaussians(last["means2d"], last["depths"], last["radii"], H, W, 16, mode=_lib.GSPL_MODE_INRIA)[0].shape[0])
+                    entry["V"] = int((last["radii"] > 0).sum().item())
+                else:
+                    m, s_, q, o, c = tensors
+                    vm = c0["world_to_camera"].T.contiguous().to(dev)
+                    pr = ops.project_gaussians(m, s_, 1.0, q, vm[:3], c0["fx"], c0["fy"], c0["cx"], c0["cy"], H, W, 16)
+                    entry["I"], entry["V"] = int(pr[5].sum().item()), int((pr[2] > 0).sum().item())
+                per_cam.append(entry)
+
+    # ---- stage rooflines: a STAGED pass (one C-ABI call per stage instead of the fused calls) with an event pair around every call,
+    # after the timed regions; the SH kernel once overlapped with the binning on its side stream (as in the step) and once alone.
+    stage_prof = None
+    if rank == 0 and mode == "single" and api == "vanilla" and not args.no_stage_rooflines:
+        def staged_pass(side_stream):
+            os.environ["GSPL_SIDE_STREAM"] = "1" if side_stream else "0"
+            fused, ops.FUSED_INRIA = ops.FUSED_INRIA, False
+            try:
+                fs = make_full_step(optimizer, args.optimizer)
+                for _ in range(3):
+                    fs()
+                torch.cuda.synchronize()
+                _lib.profile_start(None, period=1)
+                for _ in range(len(cam_dicts)):
+                    fs()
+                return _lib.profile_stop()
+            finally:
+                ops.FUSED_INRIA = fused
+                os.environ.pop("GSPL_SIDE_STREAM", None)
+        stage_prof = {"overlapped": staged_pass(True), "alone": staged_pass(False)}
 
     if rank == 0:
         mean = lambda name: (sum(prof[name]) / len(prof[name])) if prof.get(name) else None
@@ -511,42 +611,12 @@ def main():
         stages = {k: round(sum(v) / len(v) * max(1, round(len(v) * PROFILE_PERIOD / args.steps)), 4) for k, v in prof.items() if v}
         P = W * H
         bwd_ms = mean("gspl_composite_bwd_packed") or mean("gspl_composite_bwd")
-        # ---- the frame the byte / flop models are evaluated on: the LAST compositing call of the timed steps -----------------
-        last = ops.LAST_RASTER
-        I = list_entries = valid_pairs = None
-        with torch.no_grad():
-            if last is not None:
-                list_entries = int(last["flatten_ids"].shape[0])
-                # (pixel, splat) pairs the compositing actually blends, COUNTED on the device: per-splat hit-pixel counts of the
-                # same lists (gspl_composite_scores), summed
-                count = ops.composite_scores(last["means2d"], last["conics"], last["opacities"], W, H, 16, last["offsets"],
-                                             last["flatten_ids"], mode=last["mode"])[0]
-                valid_pairs = int(count.sum(dtype=torch.int64).item())
-                if mode != "sharded":
-                    if api == "vanilla":      # every tile-rect intersection in the Inria convention: the same binning without culling
-                        I = int(ops.bin_gaussians(last["means2d"], last["depths"], last["radii"], H, W, 16, mode=_lib.GSPL_MODE_INRIA)[0].shape[0])
-                    else:
-                        m, s, q, o, c = tensors
-                        vm = cam["world_to_camera"].T.contiguous().to(dev)
-                        tiles = ops.project_gaussians(m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)[5]
-                        I = int(tiles.sum().item())
-                else:
-                    I = I_sharded
+        avg = lambda key: (sum(e[key] for e in per_cam) / len(per_cam)) if per_cam and key in per_cam[0] else None
+        I, list_entries, valid_pairs, V = avg("I"), avg("list_entries"), avg("valid_pairs"), avg("V")
         roofline = None
         if bwd_ms:
             kernel = _lib.lib().gspl_composite_bwd_kernel_name().decode()
-            traffic = traffic_source = None
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-                try:
-                    with open(os.path.join(ROOT, "profiles", name)) as f:
-                        entry = json.load(f).get(f"{args.workload}/{api}", {})
-                    entry = entry.get(kernel) or entry.get("composite_bwd_kernel") or {}
-                    if entry.get("traffic_bytes"):
-                        traffic = entry["traffic_bytes"]
-                        traffic_source = f"profiles/{name} ({entry.get('source', 'earlier PMC run, not this run')})"
-                        break
-                except OSError:
-                    pass
+            traffic, traffic_source = pmc_traffic(f"{args.workload}/{api}", kernel)
             t_s = bwd_ms * 1e-3
             bytes_I = (76.0 * I + 20.0 * P) if I is not None else None
             bytes_L = (76.0 * list_entries + 20.0 * P) if list_entries is not None else None
@@ -559,7 +629,38 @@ def main():
                         "frac_on_list_entries": round(bytes_L / t_s / 1e9 / HBM_PEAK_GBS, 5) if bytes_L else None,
                         "valid_pairs": valid_pairs, "flop_per_pair": 70,
                         "valu_frac": round(valid_pairs * 70.0 / t_s / (FP32_PEAK_TFLOPS * 1e12), 5) if valid_pairs else None,
-                        "valu_peak_tflops": FP32_PEAK_TFLOPS}
+                        "valu_peak_tflops": FP32_PEAK_TFLOPS,
+                        "workload_mean_over_cameras": len(per_cam)}
+        # ---- every stage of the step against the HBM roofline: SURVEY.md §8(d) bytes / measured duration / 8 TB/s ------------------
+        stage_rooflines = None
+        if stage_prof is not None and I is not None and V is not None:
+            K = 16
+            N_, Ip = float(wl["n"]), float(list_entries)
+            ov, al = stage_prof["overlapped"], stage_prof["alone"]
+            per_step = lambda pr, names: (sum(sum(pr.get(n, [])) for n in names) / len(cam_dicts)) if any(pr.get(n) for n in names) else None
+            phase = lambda pr, k: (lambda v: (sum(v[k::2]) / max(len(v[k::2]), 1)) if v else None)(pr.get("gspl_inria_preprocess_fwd", []))
+            def entry(ms, nbytes, formula, **extra):
+                if not ms:
+                    return None
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                return {"ms": round(ms, 4), "bytes": int(nbytes), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_model": formula, **extra}
+            bin_names = ("gspl_bin_count", "gspl_bin_emit", "gspl_bin_sort", "gspl_bin_sort_device_count", "gspl_bin_emit_sort")
+            stage_rooflines = {
+                "method": f"staged pass after the timed regions ({len(cam_dicts)} steps, one per camera): stage-by-stage C-ABI calls (GSPL_FUSED_INRIA=0) "
+                          "with a HIP event pair around every call; bytes = SURVEY.md §8(d) per-unit figures x mean units over the camera set",
+                "units": {"N": int(N_), "V": round(V, 1), "I": round(I, 1), "list_entries": round(Ip, 1), "P": P},
+                "inria_preprocess_fwd": entry(phase(al, 0), 76.0 * N_, "76 N"),
+                "sh_fwd_alone": entry(phase(al, 1), (12.0 * K + 24.0) * V, "(12 K + 24) V"),
+                "sh_fwd_overlapped_with_binning": entry(phase(ov, 1), (12.0 * K + 24.0) * V, "(12 K + 24) V"),
+                "binning": entry(per_step(al, bin_names), 72.0 * N_ + 32.0 * V + 44.0 * Ip,
+                                 "depth sort 8 N (1 + 2*4) + emit 32 V + 8 I' + tile sort 36 I'"),
+                "composite_fwd": entry(per_step(al, ("gspl_composite_fwd",)), 40.0 * I + 20.0 * P, "40 I + 20 P"),
+                "composite_bwd": entry(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * I + 20.0 * P, "76 I + 20 P"),
+                "inria_preprocess_bwd_with_sh_bwd": entry(per_step(al, ("gspl_inria_preprocess_bwd",)), (116.0 + 24.0 * K) * V, "(36 + 40 + 40) V + 2 * 12 K V"),
+                "loss_fwd_bwd": entry(per_step(al, ("gspl_loss_l1_ssim_fwd", "gspl_loss_l1_ssim_bwd")), 4.0 * 3 * P * (2 + 3 + 4), "3 P floats: 2 read fwd, 3 maps written, 3 read + 1 written bwd"),
+                "adam": entry(per_step(al, ("gspl_selective_adam",)), 28.0 * 59.0 * N_, "28 B x 59 floats x N (param, grad, two moments read; param, two moments written)"),
+                "densify_stats": entry(per_step(al, ("gspl_densify_stats",)), 29.0 * N_, "grad 12 + radii 4 + three buffers 12 read, up to 12 written, + mask 1"),
+            }
         step_desc = ("renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd"
                      + (" + gradient all-reduce" if mode == "replicated" and args.optimizer != "none" else "")
                      + ("" if args.optimizer == "none" else " + " + args.optimizer + " step") + " + densification stats")
@@ -586,6 +687,13 @@ def main():
             "fwd_ms": round(phase_fwd, 4),
             "bwd_ms": round(phase_bwd, 4),
             "roofline": roofline,
+            "stage_rooflines": stage_rooflines,
+            # device-side span of a step (start to start) over the timed region
+            "step_ms": step_ms,
+            # list-length speculation of the binning (the guess is the previous frame's length x 1.25 + 64 K; a miss repeats emission,
+            # sort and compositing): frames of the timed region, frames without a guess, frames whose guess was too low
+            "speculation": {**speculation, "miss_rate": round(speculation["misses"] / max(speculation["frames"], 1), 4)},
+            "cameras": {"count": len(cam_dicts), "per_camera": per_cam if len(per_cam) <= 64 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = args.workload if args.cpu_sample == "auto" else args.cpu_sample

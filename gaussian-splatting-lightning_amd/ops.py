@@ -911,6 +911,9 @@ def _take_event(dev):
 
 
 _LAST_ISECTS: dict = {}       # (device, tile grid) -> list length of the last frame: the guess of the speculative emission
+# How the guesses fared (bench.py reports the miss rate): frames binned, frames without a guess (first of a size: the host waits),
+# frames whose guess was too low (emission, sort and — in the fused call — compositing are repeated).
+SPECULATION = {"frames": 0, "cold": 0, "misses": 0}
 SPECULATIVE_EMIT = os.environ.get("GSPL_SPECULATIVE_EMIT", "1") != "0"
 
 
@@ -1003,6 +1006,11 @@ def _bin_gaussians_end(p: _PendingBins):
         n_isects = int(p.host_count[0])
         _PINNED_WORDS.append(p.host_count)
         _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
+        SPECULATION["frames"] += 1
+        if p.capacity == 0:
+            SPECULATION["cold"] += 1
+        elif n_isects > p.capacity:
+            SPECULATION["misses"] += 1
     if flat_cap is not None and 0 < n_isects <= p.capacity:
         p.ws2 = None
         return flat_cap[:n_isects], p.offsets
@@ -1256,6 +1264,11 @@ class _InriaFusedFn(torch.autograd.Function):
             for t in holder.get(L.GSPL_BUF_GEOMETRY, []):
                 t.record_stream(side.stream)
         _LAST_ISECTS[key] = int(state.n_isects)
+        SPECULATION["frames"] += 1
+        if hint == 0:
+            SPECULATION["cold"] += 1
+        elif int(state.n_isects) > hint:
+            SPECULATION["misses"] += 1
         holder.pop(L.GSPL_BUF_BINNING, None)           # scratch of the count half and of the tile sort: not needed again
         holder.pop(L.GSPL_BUF_LISTS_WORK, None)
         ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii)

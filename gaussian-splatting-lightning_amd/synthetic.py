@@ -55,6 +55,47 @@ def camera(width: int, height: int, fx: float, fy: float = None, distance: float
             "cx": width / 2.0, "cy": height / 2.0, "width": width, "height": height, "tanfovx": tanx, "tanfovy": tany}
 
 
+def camera_looking_at_origin(width: int, height: int, fx: float, yaw: float, pitch: float, distance: float, fy: float = None):
+    """Camera on a sphere of radius `distance` around the cloud's centre, looking at it (yaw / pitch in radians; 0, 0 is `camera()`:
+    identity rotation, the camera at (0, 0, -distance)).  Same dictionary as `camera()`, matrices in the reference's transposed storage."""
+    import math
+    fy = fx if fy is None else fy
+    c = torch.tensor([math.sin(yaw) * math.cos(pitch), math.sin(pitch), -math.cos(yaw) * math.cos(pitch)], dtype=torch.float64) * distance
+    f = -c / c.norm()                                            # viewing direction (+z of the camera)
+    r = torch.linalg.cross(torch.tensor([0.0, 1.0, 0.0], dtype=torch.float64), f)
+    r = r / r.norm()                                             # +x of the camera
+    d = torch.linalg.cross(f, r)                                 # +y of the camera (image rows grow along it)
+    R = torch.stack([r, d, f])                                   # p_cam = R (p_world - c)
+    w2c = torch.eye(4, dtype=torch.float64)
+    w2c[:3, :3] = R.T                                            # row-vector convention: p_cam = p_world @ w2c[:3,:3] + w2c[3,:3]
+    w2c[3, :3] = -(R @ c)
+    w2c = w2c.float()
+    znear, zfar = 0.01, 100.0
+    tanx, tany = 0.5 * width / fx, 0.5 * height / fy
+    P = torch.zeros(4, 4)
+    P[0, 0], P[1, 1] = 1.0 / tanx, 1.0 / tany
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return {"world_to_camera": w2c, "full_projection": w2c @ P.T, "camera_center": torch.linalg.inv(w2c)[3, :3], "fx": fx, "fy": fy,
+            "cx": width / 2.0, "cy": height / 2.0, "width": width, "height": height, "tanfovx": tanx, "tanfovy": tany}
+
+
+def camera_set(width: int, height: int, fx: float, count: int = 16, distance: float = 4.0):
+    """`count` training views of a synthetic scene, as a data loader would hand them out one per step (internal/dataset.py:146-184):
+    view 0 is `camera()` (the pose the workload's intersection count is quoted on), the others orbit the cloud within +-0.45 rad of
+    yaw, +-0.25 rad of pitch and +-12 % of the distance — different visible sets and tile-list lengths (about -20 % ... +30 %)."""
+    import math
+    cams = [camera(width, height, fx, distance=distance)]
+    for k in range(1, count):
+        a = 2.0 * math.pi * k / count
+        yaw = 0.45 * math.sin(a) + 0.08 * math.sin(3 * a)
+        pitch = 0.25 * math.sin(2 * a + 0.7)
+        dist = distance * (1.0 + 0.12 * math.cos(5 * a + 0.3))
+        cams.append(camera_looking_at_origin(width, height, fx, yaw, pitch, dist))
+    return cams
+
+
 class CameraObject:
     """The fields of the reference's `Camera` (internal/cameras/cameras.py:13-43) the renderers read, on `device`."""
 

@@ -37,6 +37,18 @@ def test_single_gpu_line():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) <= 2e-3
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0.0
+    # round 3: the steps cycle through a camera set; the line says how the list-length guesses fared, how the step times spread,
+    # and carries a roofline for every stage of the step
+    assert line["cameras"]["count"] == 16 and len(line["cameras"]["per_camera"]) == 16
+    assert len({c["I"] for c in line["cameras"]["per_camera"]}) > 8                                  # different views, different lists
+    spec = line["speculation"]
+    assert spec["frames"] == 5 and 0 <= spec["misses"] <= spec["frames"] and spec["miss_rate"] == round(spec["misses"] / spec["frames"], 4)
+    assert line["step_ms"]["p50"] > 0 and line["step_ms"]["p99"] >= line["step_ms"]["p50"]
+    sr = line["stage_rooflines"]
+    for k in ("inria_preprocess_fwd", "sh_fwd_alone", "sh_fwd_overlapped_with_binning", "binning", "composite_fwd", "composite_bwd",
+              "inria_preprocess_bwd_with_sh_bwd", "adam"):
+        assert sr[k]["ms"] > 0 and sr[k]["bytes"] > 0 and abs(sr[k]["frac"] - sr[k]["GBps"] / 8000.0) <= 2e-4, k
+    assert roof["traffic"] is None or "same ABI and kernel sources" in roof["traffic_source"]      # stale PMC files are refused
 
 
 @pytest.mark.gpu
