@@ -493,7 +493,7 @@ class _CompositeFn(torch.autograd.Function):
         if KEEP_LAST_RASTER:
             global LAST_RASTER
             LAST_RASTER = dict(mode=mode, width=width, height=height, means2d=means2d, conics=conics, opacities=opacities,
-                               flatten_ids=flatten_ids, offsets=offsets)
+                               colors=colors, flatten_ids=flatten_ids, offsets=offsets)
         ctx.cfg = (width, height, tile_size, tile_w, tile_h, bool(absgrad), mode, layout)
         ctx.means2d_ref = means2d_in      # the caller's tensor object: `.absgrad` is attached to it in backward
         return out, alphas
@@ -1128,7 +1128,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
         if KEEP_LAST_RASTER:
             global LAST_RASTER
             LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=means2d, conics=conics, opacities=opac,
-                               flatten_ids=flat, offsets=offsets, radii=radii, depths=depths)
+                               colors=colors, flatten_ids=flat, offsets=offsets, radii=radii, depths=depths)
         ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
                    float(s.scale_modifier), colors_precomp is not None, opacities.shape)
         ctx.set_materialize_grads(False)      # the integer `radii` output would otherwise get a zero "gradient" tensor per step
@@ -1285,6 +1285,7 @@ class _InriaFusedFn(torch.autograd.Function):
             nI = int(state.n_isects)
             LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=_view(geom, state.means2d, (N, 2), torch.float32),
                                conics=_view(geom, state.conics, (N, 3), torch.float32), opacities=opac,
+                               colors=_view(geom, state.colors, (N, 3), torch.float32),
                                flatten_ids=(lists[:4 * nI].view(torch.int32) if lists is not None else torch.empty(0, dtype=torch.int32, device=dev)),
                                offsets=_view(img, state.offsets, (tile_w * tile_h,), torch.int32), radii=radii,
                                depths=_view(geom, state.depths, (N,), torch.float32))

@@ -46,7 +46,7 @@ def hip_composite_bwd(mode, means2d, conics, colors, opac, bg, W, H, offsets, fl
     return dict(v_means2d=v_xy, v_means2d_abs=v_abs, v_conics=v_con, v_colors=v_col, v_opacities=v_op, hit=hit)
 
 
-def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0, rel_all=None, frac_1e2=None):
+def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0, rel_all=None, frac_1e2=None, outliers=0, rel_outliers=0.5):
     """ratio = |got - ref| / (|ref| + rms(ref)) elementwise, with three tiers:
          ratio <= rel       for at least `frac_ok` of the elements (the claimed tolerance);
          ratio <= 1e-2      for at least `frac_1e2` of them (default: all when rel_all <= 1e-2, else 1 - 5e-5; measured up to 3e-5);
@@ -71,7 +71,13 @@ def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0, rel_all=None, frac_
     frac = 1.0 - bad.mean()
     assert frac >= frac_ok, f"{name}: {bad.sum()} / {bad.size} outside rel={rel} (worst {worst:.3e})"
     if rel_all is not None:
-        assert worst <= rel_all, f"{name}: worst element {worst:.3e} exceeds the tail cap {rel_all:g} ({int((ratio > rel_all).sum())} elements)"
+        n_over = int((ratio > rel_all).sum())
+        if n_over:
+            print(f"[tail] {name}: {n_over} element(s) beyond the cap {rel_all:g} (worst {worst:.3e}); allowed: {outliers} up to {rel_outliers:g}")
+        # `outliers` elements (a counted handful among millions: single flipped decisions on splats that few pixels see) may pass the
+        # cap, up to `rel_outliers`
+        assert n_over <= outliers and worst <= (rel_outliers if outliers else rel_all), \
+            f"{name}: worst element {worst:.3e}, {n_over} beyond the tail cap {rel_all:g} (allowed {outliers} up to {rel_outliers:g})"
         if rel_all > 1e-2 and rel < 1e-2:
             allowed = (5e-5 if frac_1e2 is None else 1.0 - frac_1e2) * ratio.size
             assert n2 <= max(allowed, 1.0), f"{name}: {n2} elements outside 1e-2 (allowed {allowed:.1f} of {ratio.size})"

@@ -7,7 +7,9 @@
     API with `.absgrad`.
 
 Tolerances: forward >= 99.9 % of the pixels within 1e-5 and ALL within 4e-3 (= one flipped 1/255 decision); gradients >= 99.5 % of the elements within
-1e-4 * (|ref| + rms), all but 5e-5 of them within 1e-2 and ALL within 0.5 * (|ref| + rms) (hip_helpers.assert_close_scaled: the tail is counted and printed).
+1e-4 * (|ref| + rms), all but 5e-5 of them within 1e-2, all but a counted handful (<= 8) within 0.05 and ALL within 0.5 (hip_helpers.assert_close_scaled:
+the tail is counted and printed).  These tiers belong to the FREE-RUNNING oracle; tests/test_locked_parity.py repeats the metric point on the GPU's own
+discrete decisions with no tail at all.
 The fp64 oracle pass takes 10-60 s of host time per case."""
 import numpy as np
 import pytest
@@ -18,10 +20,12 @@ from hip_helpers import assert_close_scaled, assert_pixels_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# Hard cap on EVERY gradient element, relative to |ref| + rms(ref); in addition at most 5e-5 of the elements may exceed 1e-2
-# (hip_helpers.assert_close_scaled explains where the handful of outliers among millions of elements comes from; measured
-# worst cases 2e-2 ... 1.5e-1, 1-4 elements above 5e-2).
-TAIL = 0.5
+# FREE-RUNNING comparison (the oracle re-takes every discrete decision in fp64): cap on the gradient elements relative to
+# |ref| + rms(ref), with at most OUTLIERS elements (of 3-59 million; measured 1-4 of them, worst 1.5e-1) beyond it, none beyond 0.5; in
+# addition at most 5e-5 of the elements may exceed 1e-2.  The comparison that excuses NOTHING — the oracle on the GPU's own discrete
+# decisions, every pixel within 1e-5 and every gradient element within 1e-4 — is tests/test_locked_parity.py.
+TAIL = 0.05
+OUTLIERS = 8
 
 
 def _hip_gsplat(params, cam, deg, bg, absgrad=False):
@@ -51,7 +55,7 @@ def _oracle_gsplat(params, cam, deg, bg):
 def _compare_grads(leaves, dl):
     for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
         assert got.grad is not None, name
-        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=TAIL)
+        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
 
 
 @pytest.mark.parametrize("api", ["vanilla", "gsplat"])
@@ -79,7 +83,7 @@ def test_metric_point_S_1080p_1M_against_the_oracle(api):
         (r["render"] * wimg.double()).sum().backward()
         assert np.mean(radii.cpu().numpy() == r["radii"].numpy()) > 0.9995
         ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * W, 0.5 * H])
-        assert_close_scaled(screen.grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995, rel_all=TAIL)
+        assert_close_scaled(screen.grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
     else:
         render, leaves, _ = _hip_gsplat(params, cam, 3, bg)
         (render * wimg.to(DEV)).sum().backward()
@@ -106,7 +110,7 @@ def test_config2_proxy_S_1080p_6M_projection_lists_and_image():
             m, s, 1.0, q, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W)
         assert np.mean(mid["radii"].cpu().numpy() == radii.numpy()) > 0.9995
         assert_close_scaled(mid["xys"].cpu().numpy(), xys.numpy(), 1e-5, "xys", frac_ok=0.9999, rel_all=1e-3)
-        assert_close_scaled(mid["conics"].cpu().numpy(), conics.numpy(), 1e-4, "conics", frac_ok=0.9995, rel_all=TAIL)
+        assert_close_scaled(mid["conics"].cpu().numpy(), conics.numpy(), 1e-4, "conics", frac_ok=0.9995, rel_all=TAIL, outliers=OUTLIERS)
         # tile lists of the HIP projection's own outputs: bit-exact against the oracle's stable (tile | depth) sort
         flat, offs = ops.bin_gaussians(mid["xys"], mid["depths"], mid["radii"], H, W, 16)
         _, _, flat_ref, offs_ref = O.isect_tiles(O.MODE_GSPLAT, mid["xys"].cpu(), mid["radii"].cpu(), mid["depths"].cpu(), W, H)
@@ -134,7 +138,7 @@ def test_config4_proxy_sh0_absgrad_5M():
     (r["render"] * wimg.double()).sum().backward()
     assert_pixels_close(render.detach().cpu().numpy(), r["render"].detach().numpy())
     _compare_grads(leaves, dl)
-    assert_close_scaled(mid["xys"].grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", frac_ok=0.995, rel_all=TAIL)
+    assert_close_scaled(mid["xys"].grad.cpu().numpy(), r["xys"].grad.numpy(), 1e-4, "xys.grad", frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
     # absgrad: sum over pixels of |per-pixel gradient|; the oracle's analytic backward on the same lists
     ab = mid["xys"].absgrad
     assert ab.shape == (N, 2) and bool((ab >= mid["xys"].grad.abs() - 1e-6).all())
@@ -143,4 +147,4 @@ def test_config4_proxy_sh0_absgrad_5M():
                                                 r["offsets"], r["flatten_ids"])
     g = O.composite_bwd(O.MODE_GSPLAT, d(r["xys"]), d(r["conics"]), d(r["rgbs"]), d(r["opacities"]), bg.double(), W, H, r["offsets"],
                         r["flatten_ids"], alpha_ref, last_ref, wimg.permute(1, 2, 0).double().numpy(), None, absgrad=True)
-    assert_close_scaled(ab.cpu().numpy(), g["v_means2d_abs"], 1e-4, "xys.absgrad", frac_ok=0.995, rel_all=TAIL)
+    assert_close_scaled(ab.cpu().numpy(), g["v_means2d_abs"], 1e-4, "xys.absgrad", frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
