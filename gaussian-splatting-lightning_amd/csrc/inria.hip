@@ -31,6 +31,36 @@ __device__ __forceinline__ void load_inria_cam(const float* __restrict__ viewmat
     for (int i = 0; i < 16; ++i) { c.V[i] = viewmatrix[i]; c.P[i] = projmatrix[i]; }
 }
 
+// Block-cooperative copies of `rows` consecutive rows of W floats between a dense [*, W] array in global memory and LDS, as 16-byte
+// accesses (every fetched line fully used by ONE instruction) whenever the block's first row is 16-byte aligned; the per-Gaussian
+// arithmetic then reads / writes its own row in LDS.  Per-lane strided dword accesses of the AoS rows — the first version — touch
+// W lines per instruction and use 1/W of each: 2.8 TB/s at 1 M Gaussians where this form streams.
+template <int NT>
+__device__ __forceinline__ void rows_to_lds(const float* __restrict__ g, int64_t row0, int rows, int W, float* __restrict__ s) {
+    const float* base = g + row0 * W;
+    const int total = rows * W;
+    if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const int n4 = total >> 2;
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        for (int i = threadIdx.x; i < n4; i += NT) reinterpret_cast<v4f_*>(s)[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(base) + i);
+        for (int i = (n4 << 2) + threadIdx.x; i < total; i += NT) s[i] = base[i];
+    } else {
+        for (int i = threadIdx.x; i < total; i += NT) s[i] = base[i];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void lds_to_rows(float* __restrict__ g, int64_t row0, int rows, int W, const float* __restrict__ s) {
+    float* base = g + row0 * W;
+    const int total = rows * W;
+    if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+        const int n4 = total >> 2;
+        for (int i = threadIdx.x; i < n4; i += NT) reinterpret_cast<float4*>(base)[i] = reinterpret_cast<const float4*>(s)[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < total; i += NT) base[i] = s[i];
+    } else {
+        for (int i = threadIdx.x; i < total; i += NT) base[i] = s[i];
+    }
+}
+
 // common geometry: returns false when culled; fills everything needed by fwd and bwd
 struct InriaGeom {
     float pv[3];        // view-space mean
@@ -73,57 +103,84 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
     int width, int height, int tile_size, float tanfovx, float tanfovy, float scale_modifier,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
     float* __restrict__ conics, float* __restrict__ cov3d) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
-    InriaCam cam;
-    load_inria_cam(viewmatrix, projmatrix, cam);
-    const float p[3] = {means[g * 3 + 0], means[g * 3 + 1], means[g * 3 + 2]};
+    // rows of this block in LDS: inputs means[3] | scales[3] quats[4] (or cov3d_precomp[6]); then, over the same memory, the outputs
+    // cov3d[6] | means2d[2] | conics[3]
+    __shared__ __attribute__((aligned(16))) float s_buf[256 * 11];
+    const int t = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int rows = (int)min((int64_t)256, (int64_t)N - row0);
+    const int g = (int)row0 + t;
+    float* s_means = s_buf;
+    float* s_a = s_buf + 256 * 3;            // scales, or cov3d_precomp
+    float* s_q = s_buf + 256 * 6;
+    rows_to_lds<256>(means, row0, rows, 3, s_means);
+    if (cov3d_precomp) rows_to_lds<256>(cov3d_precomp, row0, rows, 6, s_a);
+    else { rows_to_lds<256>(scales, row0, rows, 3, s_a); rows_to_lds<256>(quats, row0, rows, 4, s_q); }
+    __syncthreads();
 
-    float S6[6];
-    if (cov3d_precomp) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) S6[k] = cov3d_precomp[g * 6 + k];
-    } else {
-        const float s[3] = {scales[g * 3 + 0] * scale_modifier, scales[g * 3 + 1] * scale_modifier, scales[g * 3 + 2] * scale_modifier};
-        const float q[4] = {quats[g * 4 + 0], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
-        float R[9];
-        quat_to_rotmat(q, R);
-        cov3d_from_scale_rot(s, R, S6);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov3d[g * 6 + k] = S6[k];
-
+    float S6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int o_radius = 0;
     float o_xy[2] = {0.f, 0.f}, o_depth = 0.f, o_conic[3] = {0.f, 0.f, 0.f};
-    InriaGeom G;
-    if (inria_geom(cam, p, S6, width, height, tanfovx, tanfovy, G)) {
-        const float inv_det = 1.f / G.det;
-        const float mid = 0.5f * (G.a + G.c);
-        const float lambda = mid + sqrtf(fmaxf(0.1f, mid * mid - G.det));
-        const int radius = (int)ceilf(3.f * sqrtf(lambda));
-        const float pw = 1.f / (G.hom[3] + 1e-7f);
-        const float x2d = ((G.hom[0] * pw + 1.f) * (float)width - 1.f) * 0.5f;
-        const float y2d = ((G.hom[1] * pw + 1.f) * (float)height - 1.f) * 0.5f;
-        const int grid_x = (width + tile_size - 1) / tile_size, grid_y = (height + tile_size - 1) / tile_size;
-        const float ts = (float)tile_size, rf = (float)radius;
-        const int minx = min(grid_x, max(0, (int)((x2d - rf) / ts)));
-        const int miny = min(grid_y, max(0, (int)((y2d - rf) / ts)));
-        const int maxx = min(grid_x, max(0, (int)((x2d + rf + ts - 1.f) / ts)));
-        const int maxy = min(grid_y, max(0, (int)((y2d + rf + ts - 1.f) / ts)));
-        if ((maxx - minx) * (maxy - miny) > 0) {
-            o_radius = radius;
-            o_xy[0] = x2d; o_xy[1] = y2d;
-            o_depth = G.pv[2];
-            o_conic[0] = G.c * inv_det; o_conic[1] = -G.b * inv_det; o_conic[2] = G.a * inv_det;
+    if (t < rows) {
+        InriaCam cam;
+        load_inria_cam(viewmatrix, projmatrix, cam);
+        const float p[3] = {s_means[t * 3 + 0], s_means[t * 3 + 1], s_means[t * 3 + 2]};
+        if (cov3d_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) S6[k] = s_a[t * 6 + k];
+        } else {
+            const float s[3] = {s_a[t * 3 + 0] * scale_modifier, s_a[t * 3 + 1] * scale_modifier, s_a[t * 3 + 2] * scale_modifier};
+            const float4 qv = *reinterpret_cast<const float4*>(s_q + t * 4);
+            const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            float R[9];
+            quat_to_rotmat(q, R);
+            cov3d_from_scale_rot(s, R, S6);
         }
+        InriaGeom G;
+        if (inria_geom(cam, p, S6, width, height, tanfovx, tanfovy, G)) {
+            const float inv_det = 1.f / G.det;
+            const float mid = 0.5f * (G.a + G.c);
+            const float lambda = mid + sqrtf(fmaxf(0.1f, mid * mid - G.det));
+            const int radius = (int)ceilf(3.f * sqrtf(lambda));
+            const float pw = 1.f / (G.hom[3] + 1e-7f);
+            const float x2d = ((G.hom[0] * pw + 1.f) * (float)width - 1.f) * 0.5f;
+            const float y2d = ((G.hom[1] * pw + 1.f) * (float)height - 1.f) * 0.5f;
+            const int grid_x = (width + tile_size - 1) / tile_size, grid_y = (height + tile_size - 1) / tile_size;
+            const float ts = (float)tile_size, rf = (float)radius;
+            const int minx = min(grid_x, max(0, (int)((x2d - rf) / ts)));
+            const int miny = min(grid_y, max(0, (int)((y2d - rf) / ts)));
+            const int maxx = min(grid_x, max(0, (int)((x2d + rf + ts - 1.f) / ts)));
+            const int maxy = min(grid_y, max(0, (int)((y2d + rf + ts - 1.f) / ts)));
+            if ((maxx - minx) * (maxy - miny) > 0) {
+                o_radius = radius;
+                o_xy[0] = x2d; o_xy[1] = y2d;
+                o_depth = G.pv[2];
+                o_conic[0] = G.c * inv_det; o_conic[1] = -G.b * inv_det; o_conic[2] = G.a * inv_det;
+            }
+        }
+        radii[g] = o_radius;            // 4-byte columns: already one full line per 32 lanes
+        depths[g] = o_depth;
     }
-    radii[g] = o_radius;
-    means2d[g * 2 + 0] = o_xy[0]; means2d[g * 2 + 1] = o_xy[1];
-    depths[g] = o_depth;
-    conics[g * 3 + 0] = o_conic[0]; conics[g * 3 + 1] = o_conic[1]; conics[g * 3 + 2] = o_conic[2];
+    __syncthreads();                    // every lane has read its input rows: the memory now takes the output rows
+    float* s_cov = s_buf;
+    float* s_xy = s_buf + 256 * 6;
+    float* s_con = s_buf + 256 * 8;
+    if (t < rows) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_cov[t * 6 + k] = S6[k];
+        s_xy[t * 2 + 0] = o_xy[0]; s_xy[t * 2 + 1] = o_xy[1];
+        s_con[t * 3 + 0] = o_conic[0]; s_con[t * 3 + 1] = o_conic[1]; s_con[t * 3 + 2] = o_conic[2];
+    }
+    __syncthreads();
+    lds_to_rows<256>(cov3d, row0, rows, 6, s_cov);
+    lds_to_rows<256>(means2d, row0, rows, 2, s_xy);
+    lds_to_rows<256>(conics, row0, rows, 3, s_con);
 }
 
 // ACCUM: v_means already holds dL/d(dir) from the SH backward and is accumulated into.
+// (Measured, round 3: the LDS-staged form of this kernel — every array copied through LDS as 16-byte rows, as the forward does —
+// is SLOWER, 40.5 against 34.5 us at 1 M Gaussians: 31 KB of LDS per block and three barriers cost more occupancy than the
+// strided loads cost bandwidth; the kernel carries ~400 flops per Gaussian between its loads and its stores.)
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     int N,

@@ -435,16 +435,18 @@ def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
     g = torch.Generator().manual_seed(4)
     v_out = torch.randn(H, W, D, generator=g)
     v_alpha = torch.randn(H, W, generator=g)
+    # Pixels with a decision (1/255 skip, transmittance stop, clamp) within 2e-5 of its threshold — where fp32 and fp64 may decide
+    # differently — carry NO loss, on both sides; then nothing is excused: every splat, every gradient element within 1e-4.
+    fragile = torch.from_numpy(frag != 0)
+    v_out[fragile] = 0.0
+    v_alpha[fragile] = 0.0
     got = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, final_T, last, c(v_out), c(v_alpha), absgrad=True)
     # the oracle differentiates the discrete path the GPU took (its alphas / last_ids)
     ref = O.composite_bwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, 1.0 - final_T.cpu().double().numpy(),
                           last.cpu().numpy(), v_out.double().numpy(), v_alpha.double().numpy(), fragile_px=frag, absgrad=True)
-    keep = ref["fragile_g"] == 0
-    assert keep.mean() > 0.9            # splats touching a fragile pixel are excused (a pixel touches many splats)
     for k in ("v_means2d", "v_means2d_abs", "v_conics", "v_colors", "v_opacities"):
-        assert_close_scaled(got[k].cpu().numpy()[keep], ref[k][keep], 1e-4, f"{k} mode={mode} D={D}", frac_ok=0.9995, rel_all=2e-3)
-        # the excused splats (they touch a pixel whose skip / stop decision sits within 2e-5 of its threshold) are bounded too
-        assert_close_scaled(got[k].cpu().numpy(), ref[k], 1e-4, f"{k} mode={mode} D={D} incl. fragile", frac_ok=0.9, rel_all=5e-2)
+        assert_close_scaled(got[k].cpu().numpy(), ref[k], 1e-4, f"{k} mode={mode} D={D}", frac_ok=1.0)
+    keep = ref["fragile_g"] == 0          # (only for the hit flags below: a splat seen by a fragile pixel alone has no oracle gradient)
     # ... and so are the fragile pixels of the forward
     assert np.abs(out.cpu().numpy() - out_ref).max() <= 1e-3
     # hit flags (the fork's `has_hit_any_pixels`): a splat some pixel composited has a colour weight alpha*T > 0 there, so with a
