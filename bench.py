@@ -154,7 +154,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             if marks is not None:
                 marks.append(_mark())
             xys, depths, radii, conics, comp, tiles, _ = ops.project_gaussians(
-                m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
+                m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16, return_cov3d=False)
             xys.retain_grad()
             opac = o * comp[:, None]
             # same order as HipGSplatRenderer.forward: count half of the binning, SH, emit half, compositing

@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -61,7 +61,7 @@ _SIGNATURES = {
     "gspl_last_error": (ctypes.c_char_p, []),
     "gspl_composite_bwd_kernel_name": (ctypes.c_char_p, []),
     "gspl_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int,
-                                 c_float, c_float, c_float, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+                                 c_float, c_float, c_float, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int,
                                  _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "gspl_low_priority_stream": (c_void_p, []),

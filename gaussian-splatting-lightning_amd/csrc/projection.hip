@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     int width, int height, int tile_size,
     float scale_modifier, float eps2d, float near_plane, float far_plane, float radius_clip,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
-    float* __restrict__ conics, float* __restrict__ compensations, int32_t* __restrict__ tiles_hit) {
+    float* __restrict__ conics, float* __restrict__ compensations, int32_t* __restrict__ tiles_hit, float* __restrict__ cov3d) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)C * N) return;
     const int cam = (int)(idx / N);
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     bool ok = (pc[2] >= near_plane) && (pc[2] <= far_plane);
 
     float o_xy[2] = {0.f, 0.f}, o_depth = 0.f, o_conic[3] = {0.f, 0.f, 0.f}, o_comp = 0.f;
+    float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int o_radius = 0, o_tiles = 0;
 
     if (ok) {
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
                 o_xy[0] = x2d; o_xy[1] = y2d; o_depth = pc[2];
                 o_conic[0] = cc * inv_det; o_conic[1] = -b * inv_det; o_conic[2] = a * inv_det;
                 o_comp = comp; o_radius = radius; o_tiles = ntiles;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o_cov[k] = S6[k];
             }
         }
     }
@@ -124,6 +127,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     conics[idx * 3 + 0] = o_conic[0]; conics[idx * 3 + 1] = o_conic[1]; conics[idx * 3 + 2] = o_conic[2];
     if (compensations) compensations[idx] = o_comp;
     if (tiles_hit) tiles_hit[idx] = o_tiles;
+    if (cov3d) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov3d[idx * 6 + k] = o_cov[k];
+    }
 }
 
 template <bool ATOMIC, int CAM>
@@ -232,7 +239,7 @@ extern "C" int gspl_project_fwd(int C, int N,
                                 float scale_modifier, float eps2d, float near_plane, float far_plane,
                                 float radius_clip, int camera_model,
                                 int32_t* radii, float* means2d, float* depths, float* conics,
-                                float* compensations, int32_t* tiles_hit, void* stream) {
+                                float* compensations, int32_t* tiles_hit, float* cov3d, void* stream) {
     if (C < 0 || N < 0 || width <= 0 || height <= 0 || tile_size <= 0) return gspl::fail_arg("project_fwd: bad sizes");
     if (camera_model < GSPL_CAMERA_PINHOLE || camera_model > GSPL_CAMERA_FISHEYE) return gspl::fail_arg("project_fwd: unknown camera model");
     if ((int64_t)C * N == 0) return GSPL_OK;
@@ -244,7 +251,7 @@ extern "C" int gspl_project_fwd(int C, int N,
 #define GSPL_PROJECT_FWD(CAM)                                                                                              \
     hipLaunchKernelGGL(gspl::project_fwd_kernel<CAM>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, C, N, means,   \
                        scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier, eps2d, near_plane, far_plane,   \
-                       radius_clip, radii, means2d, depths, conics, compensations, tiles_hit)
+                       radius_clip, radii, means2d, depths, conics, compensations, tiles_hit, cov3d)
     if (camera_model == GSPL_CAMERA_ORTHO) GSPL_PROJECT_FWD(gspl::GSPL_CAM_ORTHO_);
     else if (camera_model == GSPL_CAMERA_FISHEYE) GSPL_PROJECT_FWD(gspl::GSPL_CAM_FISHEYE_);
     else GSPL_PROJECT_FWD(gspl::GSPL_CAM_PINHOLE_);

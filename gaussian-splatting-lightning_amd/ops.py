@@ -97,7 +97,7 @@ class _ProjectFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)
     def forward(ctx, means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier,
-                eps2d, near_plane, far_plane, radius_clip, calc_compensations, want_tiles, camera_model=0):
+                eps2d, near_plane, far_plane, radius_clip, calc_compensations, want_tiles, camera_model=0, want_cov3d=False):
         lib = L.lib()
         means, scales, quats, viewmats, Ks = map(_f32c, (means, scales, quats, viewmats, Ks))
         C, N = viewmats.shape[0], means.shape[0]
@@ -108,11 +108,12 @@ class _ProjectFn(torch.autograd.Function):
         conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
         comps = torch.empty((C, N), dtype=torch.float32, device=dev) if calc_compensations else None
         tiles = torch.empty((C, N), dtype=torch.int32, device=dev) if want_tiles else None
+        cov3d = torch.empty((C, N, 6), dtype=torch.float32, device=dev) if want_cov3d else None
         L.call("gspl_project_fwd", 
             C, N, L.ptr(means), L.ptr(scales), L.ptr(quats), L.ptr(viewmats), L.ptr(Ks),
             int(width), int(height), int(tile_size), float(scale_modifier), float(eps2d), float(near_plane),
             float(far_plane), float(radius_clip), int(camera_model),
-            L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(tiles), L.stream())
+            L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(tiles), L.ptr(cov3d), L.stream())
         ctx.save_for_backward(means, scales, quats, viewmats, Ks, radii)
         ctx.cfg = (int(width), int(height), float(scale_modifier), float(eps2d), bool(calc_compensations), int(camera_model))
         ctx.set_materialize_grads(False)      # unused outputs (radii, tiles, often depths) arrive as None, not as zero tensors
@@ -122,11 +123,14 @@ class _ProjectFn(torch.autograd.Function):
         if tiles is not None:
             ctx.mark_non_differentiable(tiles)
         outs.append(tiles if tiles is not None else torch.empty(0, dtype=torch.int32, device=dev))
+        if cov3d is not None:
+            ctx.mark_non_differentiable(cov3d)
+        outs.append(cov3d if cov3d is not None else torch.empty(0, device=dev))
         return tuple(outs)
 
     @staticmethod
     @_guarded(0)
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, _v_tiles):
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, _v_tiles, _v_cov3d=None):
         lib = L.lib()
         means, scales, quats, viewmats, Ks, radii = ctx.saved_tensors
         width, height, scale_modifier, eps2d, calc_comp, camera_model = ctx.cfg
@@ -151,7 +155,7 @@ class _ProjectFn(torch.autograd.Function):
             width, height, scale_modifier, eps2d, camera_model, L.ptr(radii),
             _raw_ptr(v_means2d), s2, L.ptr(v_depths), _raw_ptr(v_conics), s3, L.ptr(v_comps),
             L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.stream())
-        return (v_means, v_scales, v_quats) + (None,) * 13
+        return (v_means, v_scales, v_quats) + (None,) * 14
 
 
 def fully_fused_projection(
@@ -173,7 +177,7 @@ def fully_fused_projection(
     assert means.dim() == 2 and means.shape[1] == 3, means.shape
     assert quats.shape == (means.shape[0], 4) and scales.shape == (means.shape[0], 3)
     assert viewmats.dim() == 3 and viewmats.shape[1:] == (4, 4) and Ks.shape == (viewmats.shape[0], 3, 3)
-    radii, means2d, depths, conics, comps, _ = _ProjectFn.apply(
+    radii, means2d, depths, conics, comps, _, _ = _ProjectFn.apply(
         means, scales, quats, viewmats, Ks, width, height, tile_size, scale_modifier, eps2d, near_plane, far_plane,
         radius_clip, calc_compensations, False, L.CAMERA_MODELS[camera_model])
     return radii, means2d, depths, conics, (comps if calc_compensations else None)
@@ -209,13 +213,18 @@ def _cached_intrinsics(fx: float, fy: float, cx: float, cy: float, dev):
     return K
 
 
+_COV3D_FULL = (0, 1, 2, 1, 3, 4, 2, 4, 5)       # upper triangle (xx xy xz yy yz zz) -> row-major 3x3
+
+
 def project_gaussians(
         means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor, viewmat: Tensor,
         fx, fy, cx, cy, img_height: int, img_width: int, block_width: int,
-        clip_thresh: float = 0.01, filter_2d_kernel_size: float = 0.3):
+        clip_thresh: float = 0.01, filter_2d_kernel_size: float = 0.3, return_cov3d: bool = True):
     """gsplat-v0 signature (reference call: gsplat_renderer.py:64-79).  viewmat [3|4, 4] world->camera.
-    Returns (xys [N,2], depths [N], radii [N] i32, conics [N,3], compensation [N], num_tiles_hit [N] i32,
-    cov3d).  cov3d is returned as None: no in-scope renderer of the reference consumes it."""
+    Returns (xys [N,2], depths [N], radii [N] i32, conics [N,3], compensation [N], num_tiles_hit [N] i32, cov3d [N,3,3]).
+    cov3d = (R S)(R S)^T with zeros for culled Gaussians, as the in-tree Python returns it (gaussian_projection.py:47,137); written
+    by the projection kernel (24 B per Gaussian), detached — no caller in the reference differentiates it.  `return_cov3d=False`
+    (what the renderers pass: they drop it, gsplat_renderer.py:64) skips the output and returns None in its place."""
     dev = means3d.device
     N = means3d.shape[0]
     viewmat = viewmat.to(torch.float32)
@@ -226,11 +235,12 @@ def project_gaussians(
                          z, z, one]).view(3, 3)
     else:
         K = _cached_intrinsics(float(fx), float(fy), float(cx), float(cy), dev)
-    radii, xys, depths, conics, comps, tiles = _ProjectFn.apply(
+    radii, xys, depths, conics, comps, tiles, cov6 = _ProjectFn.apply(
         means3d, scales, quats, vm[None], K[None], img_width, img_height, block_width, glob_scale,
-        filter_2d_kernel_size, clip_thresh, 1e10, 0.0, True, True, L.GSPL_CAMERA_PINHOLE)
+        filter_2d_kernel_size, clip_thresh, 1e10, 0.0, True, True, L.GSPL_CAMERA_PINHOLE, bool(return_cov3d))
+    cov3d = cov6.view(N, 6)[:, _COV3D_FULL].view(N, 3, 3) if return_cov3d else None
     # views, not selects: their backward is a view of the incoming gradient (select_backward allocates zeros + copies)
-    return xys.view(N, 2), depths.view(N), radii.view(N), conics.view(N, 3), comps.view(N), tiles.view(N), None
+    return xys.view(N, 2), depths.view(N), radii.view(N), conics.view(N, 3), comps.view(N), tiles.view(N), cov3d
 
 
 # =============================================================================================

@@ -44,7 +44,7 @@ def _project(means3D, scales, rotations, viewpoint_camera, scaling_modifier, blo
         means3d=means3D, scales=scales, glob_scale=scaling_modifier, quats=rotations,
         viewmat=vm,
         fx=viewpoint_camera.fx, fy=viewpoint_camera.fy, cx=viewpoint_camera.cx, cy=viewpoint_camera.cy,
-        img_height=H, img_width=W, block_width=block_size, filter_2d_kernel_size=kernel_size, **extra)
+        img_height=H, img_width=W, block_width=block_size, filter_2d_kernel_size=kernel_size, return_cov3d=False, **extra)
 
 
 class HipGSplatRenderer(Renderer):

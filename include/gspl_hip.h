@@ -66,7 +66,8 @@ const char* gspl_last_error(void);
  *      viewmats [C,4,4]  world->camera, standard (non-transposed) row-major, device memory
  *      Ks       [C,3,3]  intrinsics, device memory
  *    Outputs (all [C,N,...]): radii i32 (0 = culled), means2d [.,2], depths, conics [.,3],
- *    compensations (nullable), tiles_hit i32 (nullable; v0 `num_tiles_hit`).
+ *    compensations (nullable), tiles_hit i32 (nullable; v0 `num_tiles_hit`), cov3d [.,6] (nullable): the upper triangle
+ *    (xx, xy, xz, yy, yz, zz) of Sigma = (R S)(R S)^T that `project_gaussians` returns as `cov3d` (gaussian_projection.py:47,137).
  *    Culled Gaussians get zeros in every output (gaussian_projection.py:127-136).
  *    camera_model: GSPL_CAMERA_PINHOLE is the in-tree Python above (1.3 tan(fov) clamp of the Jacobian's x/z, y/z).
  *    GSPL_CAMERA_ORTHO / GSPL_CAMERA_FISHEYE (the `camera_model` option the reference passes through,
@@ -81,7 +82,7 @@ int gspl_project_fwd(int C, int N,
                      float scale_modifier, float eps2d, float near_plane, float far_plane,
                      float radius_clip, int camera_model,
                      int32_t* radii, float* means2d, float* depths, float* conics,
-                     float* compensations /*nullable*/, int32_t* tiles_hit /*nullable*/,
+                     float* compensations /*nullable*/, int32_t* tiles_hit /*nullable*/, float* cov3d /*nullable*/,
                      void* stream);
 
 /*    Backward of the above (autograd of gsplat's op; reference enters it through

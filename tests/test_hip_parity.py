@@ -55,8 +55,11 @@ def test_projection_vs_reference_golden(hip, golden_dir, cam):
     fx, fy, cx, cy, W, H = z[p + "intr"]
     means, scales, quats = [t32(z[k]).requires_grad_(True) for k in ("means", "scales", "quats")]
     viewmat = t32(z[p + "w2c"]).T.contiguous()
-    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(
+    xys, depths, radii, conics, comp, tiles, cov3d = hip.project_gaussians(
         means, scales, 1.0, quats, viewmat, float(fx), float(fy), float(cx), float(cy), int(H), int(W), 16)
+    # cov3d [N,3,3] as the reference returns it (gaussian_projection.py:47,137): (R S)(R S)^T, zeros for culled Gaussians
+    assert cov3d.shape == (means.shape[0], 3, 3) and not cov3d.requires_grad
+    np.testing.assert_allclose(cov3d.cpu().numpy(), z[p + "cov3d"], rtol=2e-5, atol=1e-9)
     r_ref = z[p + "radii"]
     same = radii.cpu().numpy() == r_ref
     assert same.mean() >= 0.999, "radii (ceil may flip on an fp32 rounding boundary for <0.1 %)"
@@ -76,11 +79,17 @@ def test_projection_vs_reference_golden(hip, golden_dir, cam):
 def test_projection_known_answer_vector(hip, golden_dir):
     z = np.load(os.path.join(golden_dir, "ref_kat.npz"))
     fx, fy, cx, cy, W, H = z["intr"]
-    xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(
+    xys, depths, radii, conics, comp, tiles, cov3d = hip.project_gaussians(
         t32(z["means"]), t32(z["scales"]), 1.0, t32(z["quats"]), t32(z["w2c"]).T.contiguous(),
         float(fx), float(fy), float(cx), float(cy), int(H), int(W), 16)
     assert radii.tolist() == [0, 4, 0, 16783]
     m = (radii > 0).cpu().numpy()
+    # the reference's literal expected upper triangles (tests/gaussian_projection_test.py:30-113) and zeros for the culled rows
+    upper = cov3d.cpu().numpy().reshape(4, 9)[:, [0, 1, 2, 4, 5, 8]]
+    np.testing.assert_allclose(upper[m], z["exp_cov3d_upper_masked"].reshape(int(m.sum()), -1), rtol=2e-4)
+    assert not upper[~m].any()
+    assert hip.project_gaussians(t32(z["means"]), t32(z["scales"]), 1.0, t32(z["quats"]), t32(z["w2c"]).T.contiguous(),
+                                 float(fx), float(fy), float(cx), float(cy), int(H), int(W), 16, return_cov3d=False)[6] is None
     np.testing.assert_allclose(conics.cpu().numpy()[m], z["exp_conics_masked"], rtol=1e-4)
     np.testing.assert_allclose(comp.cpu().numpy()[m], z["exp_comp_masked"], rtol=1e-5)
     assert tiles.cpu().numpy()[m].tolist() == [4, 4346]
