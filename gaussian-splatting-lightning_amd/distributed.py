@@ -183,6 +183,18 @@ def all_reduce_and_step(optimizer, params: Iterable[torch.Tensor], group=None, c
     following chunks are still on the wire.  Same result as `all_reduce_gradients` + `optimizer.step()` (averaged gradients,
     one step count per parameter); needs an optimizer with `begin_chunked_step` / `step_rows` (gspl_amd.optimizers.FusedAdam)."""
     params = [p for p in params if p.grad is not None]
+    if not (hasattr(optimizer, "begin_chunked_step") and hasattr(optimizer, "step_rows")):
+        raise TypeError("all_reduce_and_step needs an optimizer with begin_chunked_step / step_rows (gspl_amd.optimizers.FusedAdam); "
+                        f"got {type(optimizer).__name__} — use all_reduce_gradients + optimizer.step(...) instead")
+    # `begin_chunked_step` advances the step count of EVERY parameter of the optimizer that has a gradient: each of them must be
+    # reduced and updated here, or its bias correction would drift without an update
+    owned = {id(p) for g in optimizer.param_groups for p in g["params"] if p.grad is not None}
+    given = {id(p) for p in params}
+    if owned != given:
+        raise ValueError(f"all_reduce_and_step: `params` must be exactly the optimizer's parameters that have a gradient "
+                         f"({len(owned - given)} of them missing, {len(given - owned)} not in the optimizer)")
+    if any(p.dim() == 0 for p in params):
+        raise ValueError("all_reduce_and_step: 0-dim parameters have no rows to chunk")
     if _nothing_to_exchange(group):
         optimizer.step()
         return

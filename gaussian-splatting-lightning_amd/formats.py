@@ -189,27 +189,69 @@ class GaussianProperties:
 # per-rank checkpoints of the Gaussian-sharded trainer -> one checkpoint (utils/merge_distributed_ckpts.py)
 # ---------------------------------------------------------------------------------------------------------------------
 def merge_rank_checkpoints(ckpts: Sequence[dict]) -> dict:
-    """Concatenate, in rank order, everything that is sharded by Gaussian: `gaussian_model.gaussians.*` and
-    `density_controller.*` in the state dict and the Adam moments (`exp_avg`, `exp_avg_sq`) of every optimizer group named
-    after a Gaussian property.  Everything else is taken from the last checkpoint (as the reference script does)."""
+    """One checkpoint from the per-rank checkpoints of the Gaussian-sharded trainer (utils/merge_distributed_ckpts.py), in rank
+    order.  Returns a NEW top-level dict (the inputs are not modified; tensors that are not concatenated are shared):
+
+      * `gaussian_model.gaussians.*` and `density_controller.*` of the state dict are concatenated along the Gaussian axis;
+      * the Adam moments (`exp_avg`, `exp_avg_sq`) of the FIRST optimizer group named after each Gaussian property are concatenated
+        (the reference stops at the first match per property: a second optimizer that happens to reuse a name is left alone);
+      * the renderer hyper-parameter, when it is a distributed renderer, is replaced by the non-distributed one carrying over
+        block_size / anti_aliased / filter_2d_kernel_size / tile_based_culling (`HipGSplatV1Renderer`; the reference swaps in its
+        GSplatV1Renderer), and `renderer.appearance_model.module.*` (DDP-wrapped appearance model) is renamed `renderer.model.*`;
+      * everything else comes from the last checkpoint.
+    The pre-property-dict layout (`gaussian_model._xyz` + `gaussian_model_extra_state_dict`) is not written by any renderer of this
+    package and is rejected."""
     if not ckpts:
         raise ValueError("no checkpoints")
     gp, dp = "gaussian_model.gaussians.", "density_controller."
-    merged = ckpts[-1]
-    sd = merged["state_dict"]
-    keys = [k for k in sd if k.startswith(gp) or k.startswith(dp)]
-    names = [k[len(gp):] for k in keys if k.startswith(gp)]
-    for k in keys:
-        sd[k] = torch.cat([c["state_dict"][k] for c in ckpts], dim=0)
-    for oi, opt in enumerate(merged.get("optimizer_states", [])):
+    last = ckpts[-1]
+    if not any(k.startswith(gp) for k in last["state_dict"]):
+        if "gaussian_model._xyz" in last["state_dict"] or "gaussian_model_extra_state_dict" in last:
+            raise ValueError("checkpoint in the pre-property-dict layout (gaussian_model._xyz / gaussian_model_extra_state_dict): "
+                             "merge it with the reference's utils/merge_distributed_ckpts.py")
+        raise ValueError("no `gaussian_model.gaussians.*` entries in the state dict")
+    merged = dict(last)
+    sd = dict(last["state_dict"])
+    names = []
+    for k in list(sd):
+        if k.startswith(gp) or k.startswith(dp):
+            sd[k] = torch.cat([c["state_dict"][k] for c in ckpts], dim=0)
+            if k.startswith(gp):
+                names.append(k[len(gp):])
+    ddp_prefix = "renderer.appearance_model.module."
+    for k in [k for k in sd if k.startswith(ddp_prefix)]:
+        sd["renderer.model." + k[len(ddp_prefix):]] = sd.pop(k)
+    merged["state_dict"] = sd
+
+    pending = list(names)
+    optimizers = []
+    for oi, opt in enumerate(last.get("optimizer_states", [])):
+        opt = dict(opt)
+        state = dict(opt.get("state", {}))
         for gi, group in enumerate(opt.get("param_groups", [])):
-            if group.get("name") not in names:
+            name = group.get("name")
+            if name not in pending or gi not in state:
                 continue
-            state = opt["state"].get(gi)
-            if state is None:
-                continue
+            pending.remove(name)
+            entry = dict(state[gi])
             for m in ("exp_avg", "exp_avg_sq"):
-                state[m] = torch.cat([c["optimizer_states"][oi]["state"][gi][m] for c in ckpts], dim=0)
+                entry[m] = torch.cat([c["optimizer_states"][oi]["state"][gi][m] for c in ckpts], dim=0)
+            state[gi] = entry
+        opt["state"] = state
+        optimizers.append(opt)
+    if "optimizer_states" in last:
+        merged["optimizer_states"] = optimizers
+
+    hp = last.get("hyper_parameters")
+    renderer = hp.get("renderer") if isinstance(hp, dict) else None
+    if renderer is not None and "Distributed" in type(renderer).__name__:
+        from .renderers import HipGSplatV1Renderer
+        hp = dict(hp)
+        hp["renderer"] = HipGSplatV1Renderer(
+            block_size=getattr(renderer, "block_size", 16), anti_aliased=getattr(renderer, "anti_aliased", True),
+            filter_2d_kernel_size=getattr(renderer, "filter_2d_kernel_size", 0.3),
+            tile_based_culling=getattr(renderer, "tile_based_culling", False))
+        merged["hyper_parameters"] = hp
     return merged
 
 

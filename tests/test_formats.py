@@ -161,3 +161,43 @@ def test_merge_rank_checkpoints(tmp_path):
     # and the merged checkpoint converts to a ply
     F.main(["ckpt2ply", str(d / "epoch=3-step=100.ckpt"), str(tmp_path / "m.ply")])
     assert F.GaussianProperties.load_ply(str(tmp_path / "m.ply")).means.shape[0] == sum(sizes)
+
+
+def test_merge_rank_checkpoints_renderer_swap_first_match_and_no_mutation():
+    """the merged checkpoint names the NON-distributed renderer with the distributed one's options, the DDP-wrapped
+    appearance keys are renamed, only the first optimizer group named after a property is merged, the inputs stay untouched, and the
+    pre-property-dict layout is rejected."""
+    import copy
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatDistributedRenderer, HipGSplatV1Renderer
+
+    def rank_ckpt(rank, n):
+        sd = _state_dict(n=n, seed=rank)
+        sd["renderer.appearance_model.module.w"] = torch.tensor([float(rank)])
+        g1 = {"param_groups": [{"name": "means"}, {"name": "opacities"}],
+              "state": {0: {"exp_avg": torch.full((n, 3), float(rank)), "exp_avg_sq": torch.full((n, 3), 1.0 + rank)},
+                        1: {"exp_avg": torch.full((n, 1), float(rank)), "exp_avg_sq": torch.full((n, 1), 1.0 + rank)}}}
+        g2 = {"param_groups": [{"name": "means"}],            # another optimizer that reuses the name: must be left alone
+              "state": {0: {"exp_avg": torch.full((4,), 9.0), "exp_avg_sq": torch.full((4,), 9.0)}}}
+        return {"state_dict": sd, "optimizer_states": [g1, g2],
+                "hyper_parameters": {"renderer": HipGSplatDistributedRenderer(block_size=16, anti_aliased=False, filter_2d_kernel_size=0.1,
+                                                                              tile_based_culling=True), "other": 5}}
+    ckpts = [rank_ckpt(0, 4), rank_ckpt(1, 6)]
+    before = copy.deepcopy(ckpts)
+    merged = F.merge_rank_checkpoints(ckpts)
+    r = merged["hyper_parameters"]["renderer"]
+    assert isinstance(r, HipGSplatV1Renderer) and (r.block_size, r.anti_aliased, r.filter_2d_kernel_size, r.tile_based_culling) == (16, False, 0.1, True)
+    assert merged["hyper_parameters"]["other"] == 5
+    sd = merged["state_dict"]
+    assert "renderer.model.w" in sd and not any(k.startswith("renderer.appearance_model.module.") for k in sd)
+    assert sd["gaussian_model.gaussians.means"].shape[0] == 10
+    o1, o2 = merged["optimizer_states"]
+    assert o1["state"][0]["exp_avg"].shape == (10, 3) and o1["state"][1]["exp_avg_sq"].shape == (10, 1)
+    assert o2["state"][0]["exp_avg"].shape == (4,)                                    # second match of `means`: untouched
+    for a, b in zip(ckpts, before):                                                   # inputs not modified
+        assert a["state_dict"].keys() == b["state_dict"].keys()
+        assert all(torch.equal(a["state_dict"][k], b["state_dict"][k]) for k in b["state_dict"])
+        assert a["optimizer_states"][0]["state"][0]["exp_avg"].shape == b["optimizer_states"][0]["state"][0]["exp_avg"].shape
+        assert isinstance(a["hyper_parameters"]["renderer"], HipGSplatDistributedRenderer)
+    with pytest.raises(ValueError, match="pre-property-dict"):
+        F.merge_rank_checkpoints([{"state_dict": {"gaussian_model._xyz": torch.zeros(3, 3)}, "gaussian_model_extra_state_dict": {}}])
