@@ -70,8 +70,10 @@ def parse():
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
                    help="l1: mean |render - target| with torch ops; photometric: the reference's training loss "
                         "0.8 L1 + 0.2 (1 - SSIM) (vanilla_metrics.py:66-68) through the fused HIP loss kernels")
-    p.add_argument("--optimizer", default="fused-adam", choices=["none", "fused-adam", "selective-adam", "torch-adam"],
-                   help="optimizer step inside the timed step (default: the package's fused Adam; none = renderer fwd+bwd rate only)")
+    p.add_argument("--optimizer", default="fused-adam", choices=["none", "fused-adam", "selective-adam", "torch-adam", "masked-adam"],
+                   help="optimizer step inside the timed step (default: the package's fused Adam; none = renderer fwd+bwd rate only; "
+                        "masked-adam: --parallelism replicated with the visibility-masked reduce-scatter / all-gather and the optimizer "
+                        "state sharded by row ownership, distributed.MaskedReplicaAdam)")
     p.add_argument("--parallelism", default="auto", choices=["auto", "single", "replicated", "sharded"],
                    help="auto: single for one GPU, sharded for several (Gaussian-sharded renderer with the packed all-to-all, "
                         "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
@@ -389,6 +391,10 @@ def main():
             return None
         if kind == "torch-adam":
             return torch.optim.Adam(groups, eps=1e-15)
+        if kind == "masked-adam":
+            if mode != "replicated":
+                sys.exit("--optimizer masked-adam belongs to --parallelism replicated")
+            return gdist.MaskedReplicaAdam([(str(i), g["params"][0], g["lr"]) for i, g in enumerate(groups)], eps=1e-15)
         from gspl_amd import optimizers as gopt
         return (gopt.FusedAdam if kind == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15)
 
@@ -462,6 +468,14 @@ def main():
             with torch.no_grad():
                 stats(st, accum, denom, max_radii)
                 if optimizer is not None:
+                    if opt_kind == "masked-adam":
+                        # replicas stay identical: rows ANY rank saw are reduce-scattered to their owners, updated there and
+                        # all-gathered back (distributed.MaskedReplicaAdam)
+                        optimizer.step(st["radii"] > 0)
+                        counter["n"] += 1
+                        if force_reduce or counter["n"] % DENSIFY_INTERVAL == 0:
+                            gdist.reduce_densification_stats(accum, denom, max_radii)
+                        return st
                     if mode == "replicated" and opt_kind == "fused-adam":
                         # replicas stay identical: the parameter gradients are averaged over the ranks (DDP of configs/ddp.yaml) in
                         # chunks, and every chunk is updated by the fused Adam while the next ones are still being reduced
@@ -665,7 +679,11 @@ def main():
                      + (" + gradient all-reduce" if mode == "replicated" and args.optimizer != "none" else "")
                      + ("" if args.optimizer == "none" else " + " + args.optimizer + " step") + " + densification stats")
         par = {"single": "single GPU",
-               "replicated": f"replicated Gaussians, {world} camera(s)/step, chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step, all-reduce of the densification stats every {DENSIFY_INTERVAL} steps",
+               "replicated": (f"replicated Gaussians, {world} camera(s)/step, "
+                              + ("visibility-masked reduce-scatter of the gradient rows to their owners + masked Adam on the owner + all-gather of the updated rows"
+                                 if args.optimizer == "masked-adam" else
+                                 "chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step")
+                              + f", all-reduce of the densification stats every {DENSIFY_INTERVAL} steps"),
                "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of splat records (configs/distributed.yaml); "
                           + (f"exchange format of the last step: {renderer.last_exchange}" if mode == "sharded" else "")}[mode]
         line = {

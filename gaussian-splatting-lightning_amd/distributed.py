@@ -234,3 +234,112 @@ def redistribute_rows(local: torch.Tensor, destination: torch.Tensor, group=None
         recv_counts = exchange_counts(send_list, local.device, group)
     send = local.detach()[order].contiguous()
     return _all_to_all_rows_raw(send, send_list, list(recv_counts), group)
+
+
+class MaskedReplicaAdam:
+    """Replicated-Gaussian mode with a VISIBILITY-MASKED exchange and the optimizer state SHARDED by row ownership
+    (SURVEY.md §5.8 / §8e "secondary": reduce-scatter + all-gather on the rows somebody saw, instead of the dense 236 B per Gaussian
+    all-reduce of `all_reduce_and_step`).
+
+    Every rank holds all N Gaussians (the replicas) and renders its own camera; row i of every parameter is OWNED by the rank whose
+    `shard_bounds` contain i, and only the owner keeps Adam moments for it.  One step:
+      1. all-reduce (MAX) of the per-rank visibility bytes [N] -> the rows ANY rank saw (N bytes);
+      2. reduce-scatter by ownership: every rank sends each owner its gradient rows (all parameters side by side, F floats per row) of
+         the seen rows in that owner's range — one variable-size all-to-all — and the owner adds the W contributions in rank order
+         (a fixed order: the sum is bit-identical wherever it is formed) and averages;
+      3. the owner applies the visibility-masked Adam (no bias correction, rows nobody saw untouched: the update of gsplat's
+         `SelectiveAdam`, internal/optimizers.py:26-58) to ITS seen rows;
+      4. all-gather of the UPDATED parameter rows (a second variable-size all-to-all), scattered into every replica.
+    Wire bytes per rank and step: 2 (W-1)/W x F x 4 B x (rows seen), against 2 (W-1)/W x F x 4 B x N for the dense all-reduce; Adam
+    work and moment memory are 1/W.  Replicas stay bit-identical: every rank writes the same received bytes into the same rows.
+    `reshard` carries the moments across a densification (rows appended / pruned identically on every rank).
+    The row arithmetic is a handful of torch ops on compact [rows seen / W, F] buffers (this is the secondary mode; the fused HIP
+    Adam serves the primary paths)."""
+
+    def __init__(self, named_params: Sequence[Tuple[str, torch.Tensor, float]], group=None, betas=(0.9, 0.999), eps: float = 1e-15):
+        self.group = group
+        self.names = [n for n, _, _ in named_params]
+        self.params = [p for _, p, _ in named_params]
+        self.lrs = [float(lr) for _, _, lr in named_params]
+        self.betas, self.eps = betas, float(eps)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._layout()
+        lo, hi = self.bounds[self.rank]
+        dev = self.params[0].device
+        self.exp_avg = torch.zeros((hi - lo, self.F), dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+
+    def _layout(self):
+        self.N = int(self.params[0].shape[0])
+        assert all(int(p.shape[0]) == self.N for p in self.params), "every parameter has one row per Gaussian"
+        self.widths = [p.numel() // max(self.N, 1) for p in self.params]
+        self.F = sum(self.widths)
+        self.bounds = [shard_bounds(self.N, self.world, r) for r in range(self.world)]
+        dev = self.params[0].device
+        self.lr_row = torch.cat([torch.full((w,), lr, dtype=torch.float32, device=dev) for w, lr in zip(self.widths, self.lrs)])
+
+    def _exchange(self, rows: torch.Tensor, send_counts, recv_counts):
+        if self.world == 1:
+            return rows
+        return _all_to_all_rows_raw(rows, list(send_counts), list(recv_counts), self.group)
+
+    @torch.no_grad()
+    def step(self, visible: torch.Tensor):
+        """visible [N] bool: the rows THIS rank's camera saw (its gradient rows elsewhere are zero / absent)."""
+        dev = self.params[0].device
+        seen = visible.reshape(-1).to(torch.uint8)
+        if self.world > 1:
+            wire = _wire(seen, self.group)
+            dist.all_reduce(wire, op=dist.ReduceOp.MAX, group=self.group)
+            seen = wire.to(dev)
+        idx = seen.nonzero().reshape(-1)                                   # ascending: grouped by owner
+        edges = torch.tensor([b[0] for b in self.bounds] + [self.N], device=dev)
+        cuts = torch.searchsorted(idx, edges).tolist()                     # the one host read-back of the step
+        counts = [cuts[r + 1] - cuts[r] for r in range(self.world)]
+        mine = counts[self.rank]
+        lo, _ = self.bounds[self.rank]
+        # 2. reduce-scatter by ownership
+        grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(self.N, -1) for p in self.params], dim=1)
+        recv = self._exchange(grads[idx].contiguous(), counts, [mine] * self.world)
+        g = recv.reshape(self.world, mine, self.F)
+        total = g[0].clone()
+        for r in range(1, self.world):
+            total += g[r]                                                  # rank order: the same sum on every owner
+        total /= self.world
+        # 3. visibility-masked Adam on the owner's seen rows
+        my_idx = idx[cuts[self.rank]:cuts[self.rank + 1]]
+        local = my_idx - lo
+        b1, b2 = self.betas
+        m = self.exp_avg[local].mul_(b1).add_(total, alpha=1 - b1)
+        v = self.exp_avg_sq[local].mul_(b2).addcmul_(total, total, value=1 - b2)
+        self.exp_avg[local] = m
+        self.exp_avg_sq[local] = v
+        rows = torch.cat([p.detach().reshape(self.N, -1)[my_idx] for p in self.params], dim=1)
+        rows -= self.lr_row * m / (v.sqrt() + self.eps)
+        # 4. all-gather of the updated rows
+        out = self._exchange(rows.repeat(self.world, 1) if self.world > 1 else rows, [mine] * self.world, counts)
+        col = 0
+        for p, w in zip(self.params, self.widths):
+            p.detach().reshape(self.N, -1)[idx] = out[:, col:col + w]
+            col += w
+        return int(idx.numel())
+
+    @torch.no_grad()
+    def reshard(self, new_params: Sequence[torch.Tensor], keep: Optional[torch.Tensor] = None, appended: int = 0):
+        """After a densification that every rank performed identically: `keep` [old N] bool = rows that survive (None: all),
+        `appended` new rows at the end (zero moments, as the reference's cat_tensors_to_optimizer gives them).  The moments are
+        gathered, row-edited and cut to the new ownership ranges (472 B per Gaussian once per densification)."""
+        full = [self.exp_avg, self.exp_avg_sq]
+        if self.world > 1:
+            sizes = [b[1] - b[0] for b in self.bounds]
+            full = [_all_to_all_rows_raw(t.repeat(self.world, 1), [t.shape[0]] * self.world, sizes, self.group) for t in full]
+        if keep is not None:
+            full = [t[keep.to(t.device)] for t in full]
+        if appended:
+            full = [torch.cat([t, torch.zeros((appended, t.shape[1]), dtype=t.dtype, device=t.device)]) for t in full]
+        self.params = list(new_params)
+        self._layout()
+        assert full[0].shape[0] == self.N, (full[0].shape, self.N)
+        lo, hi = self.bounds[self.rank]
+        self.exp_avg, self.exp_avg_sq = full[0][lo:hi].contiguous(), full[1][lo:hi].contiguous()
