@@ -52,7 +52,7 @@ def test_single_gpu_line():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["default", "replicated"])
+@pytest.mark.parametrize("mode", ["default", "replicated", "replicated-masked"])
 def test_two_rank_launch_line(mode):
     from conftest import free_port
     port = free_port()
@@ -60,10 +60,11 @@ def test_two_rank_launch_line(mode):
            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "S-800-100k",
            "--share-device", "--dist-backend", "gloo"]
     if mode != "default":
-        cmd += ["--parallelism", mode]
+        cmd += ["--parallelism", "replicated"] + (["--optimizer", "masked-adam"] if mode == "replicated-masked" else [])
     line = _run(cmd)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["parallelism_mode"] == ("sharded" if mode == "default" else mode)      # sharded unless told otherwise
+    assert line["config"]["parallelism_mode"] == ("sharded" if mode == "default" else "replicated")      # sharded unless told otherwise
+    assert ("masked" in line["config"]["parallelism"]) == (mode == "replicated-masked")
     assert abs(line["value"] - 2e3 / line["ms_per_step"]) <= 1e-3 * line["value"]               # whole-job images/s
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None                           # rank 0, N = 1 only
     roof = line["roofline"]                          # the byte model counts every tile-rect intersection, in every mode
