@@ -26,7 +26,7 @@ from .. import distributed as D
 from .. import ops
 from ..optim_utils import replace_tensors_to_properties
 from .hip_gsplat_v1_renderer import GSplatV1
-from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars
+from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars, implementation_tile_size
 
 
 @dataclass
@@ -312,17 +312,17 @@ class HipGSplatDistributedRendererImpl(Renderer):
             pre = (None, None, (W, H))
             projections = (radii.unsqueeze(0), means2d, depths.unsqueeze(0), conics.unsqueeze(0), None)
             isects = self.isect_encode(pre, (projections[0], means2d.unsqueeze(0), projections[2], projections[3], None),
-                                       opac, tile_size=self.config.block_size)
+                                       opac, tile_size=implementation_tile_size(self.config.block_size))
             with self._span("rasterize"):
                 # [3,H,W] straight from the kernel (the reference permutes an [H,W,3] image)
                 rgb, _ = GSplatV1.rasterize(pre, projections, isects, opac, colors=rgbs, background=bg_color,
-                                            tile_size=self.config.block_size, absgrad=False, channels_first=True)
+                                            tile_size=implementation_tile_size(self.config.block_size), absgrad=False, channels_first=True)
                 hard_inverse_depth_im = None
                 if "hard_inverse_depth" in render_types:
                     inverse_depth = 1. / (depths.clamp_min(0.) + 1e-8).unsqueeze(-1)
                     hard_inverse_depth_im, _ = GSplatV1.rasterize(pre, projections, isects, opac + (1 - opac.detach()), colors=inverse_depth,
                                                                   background=torch.zeros((1,), dtype=torch.float, device=bg_color.device),
-                                                                  tile_size=self.config.block_size, absgrad=False, channels_first=True)
+                                                                  tile_size=implementation_tile_size(self.config.block_size), absgrad=False, channels_first=True)
         return {
             "render": rgb,
             "hard_inverse_depth": hard_inverse_depth_im,

@@ -5,7 +5,7 @@ from typing import Optional
 import torch
 
 from .. import ops
-from .renderer import Renderer
+from .renderer import Renderer, implementation_tile_size
 from .hip_gsplat_renderer import HipGSplatRenderer
 from .renderer import camera_hw
 
@@ -32,4 +32,4 @@ class HipGSplatHitPixelCountRenderer(Renderer):
                 opacities = opacities * comp[:, None]
             W, H = camera_hw(viewpoint_camera)
             return ops.hit_pixel_count(xys, depths, radii, conics, num_tiles_hit, opacities, img_height=H, img_width=W,
-                                       block_width=block_size)
+                                       block_width=implementation_tile_size(block_size))

@@ -16,13 +16,14 @@ from typing import Dict, Tuple
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, viewspace_grad_scale
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, viewspace_grad_scale, implementation_tile_size
 
 DEFAULT_BLOCK_SIZE: int = 16
 DEFAULT_ANTI_ALIASED_STATUS: bool = True
 
 
 def _project(means3D, scales, rotations, viewpoint_camera, scaling_modifier, block_size, W, H, kernel_size=0.3, **extra):
+    block_size = implementation_tile_size(block_size)
     kernel_size = extra.pop("filter_2d_kernel_size", kernel_size)
     # the full, contiguous 4x4 world->camera matrix, built once per camera object (the reference hands the kernel a [3,4]
     # transposed view per frame; completing and copying it is a launch per frame)
@@ -107,7 +108,7 @@ class HipGSplatRenderer(Renderer):
         # are not listed.  Passes with other opacities ("hard" depth) bin for themselves inside rasterize_gaussians.
         # The count half is launched here; the emit half after the SH kernel, which keeps the device busy while the host
         # waits for the number of intersections.
-        pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, self.block_size, conics=conics, opacities=opacities)
+        pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, implementation_tile_size(self.block_size), conics=conics, opacities=opacities)
         isects = None
 
         def rasterize(feats, background, return_alpha=False, opac=opacities, absgrad=False, channels_first=False):
@@ -115,7 +116,7 @@ class HipGSplatRenderer(Renderer):
             if isects is None:
                 isects = ops.bin_gaussians_end(pending)
             return ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, feats, opac, img_height=H, img_width=W,
-                                           block_width=self.block_size, background=background, return_alpha=return_alpha,
+                                           block_width=implementation_tile_size(self.block_size), background=background, return_alpha=return_alpha,
                                            absgrad=absgrad, isects=isects if opac is opacities else None,
                                            channels_first=channels_first)
 
@@ -183,7 +184,7 @@ class HipGSplatRenderer(Renderer):
         if anti_aliased is True:
             opacities = opacities * comp[:, None]
         rgb = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, img_height=H, img_width=W,
-                                      block_width=block_size, background=bg_color, return_alpha=False)
+                                      block_width=implementation_tile_size(block_size), background=bg_color, return_alpha=False)
         return {"render": rgb.permute(2, 0, 1), "viewspace_points": xys,
                 "viewspace_points_grad_scale": viewspace_grad_scale(W, H, xys),
                 "visibility_filter": radii > 0, "radii": radii}
@@ -216,7 +217,7 @@ class HipGSplatRenderer(Renderer):
         if anti_aliased is True:
             opacities = opacities * comp[:, None]
         rgb = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, img_height=H, img_width=W,
-                                      block_width=block_size, background=bg_color, return_alpha=False)
+                                      block_width=implementation_tile_size(block_size), background=bg_color, return_alpha=False)
         return {"render": rgb.permute(2, 0, 1), "viewspace_points": xys,
                 "viewspace_points_grad_scale": viewspace_grad_scale(W, H, xys),
                 "visibility_filter": radii > 0, "radii": radii}

@@ -15,7 +15,7 @@ from typing import Any, Tuple
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw
+from .renderer import Renderer, RendererConfig, RendererOutputInfo, RendererOutputTypes, camera_hw, implementation_tile_size
 
 
 @dataclass
@@ -134,7 +134,7 @@ class HipGSplatV1RendererModule(Renderer):
         opacities = opacities.unsqueeze(0)
         if self.config.anti_aliased:
             opacities = opacities * compensations
-        isects = self.isect_encode(preprocessed_camera, projections, opacities, tile_size=self.config.block_size)
+        isects = self.isect_encode(preprocessed_camera, projections, opacities, tile_size=implementation_tile_size(self.config.block_size))
 
         means2d = means2d.squeeze(0)
         projection_for_rasterization = radii, means2d, depths, conics, compensations
@@ -142,7 +142,7 @@ class HipGSplatV1RendererModule(Renderer):
 
         def rasterize(input_features, background, return_alpha=False, opac=opacities, absgrad=True, channels_first=False, track_hits=False):
             c, a = GSplatV1.rasterize(preprocessed_camera, projection_for_rasterization, isects, opacities=opac,
-                                      colors=input_features, background=background, tile_size=self.config.block_size,
+                                      colors=input_features, background=background, tile_size=implementation_tile_size(self.config.block_size),
                                       absgrad=absgrad, channels_first=channels_first, track_hits=track_hits)
             return (c, a.squeeze(0).squeeze(-1)) if return_alpha else c
 

@@ -13,7 +13,7 @@ import torch
 
 from .. import ops
 from .hip_gsplat_renderer import DEFAULT_ANTI_ALIASED_STATUS, DEFAULT_BLOCK_SIZE, _project
-from .renderer import Renderer, camera_hw
+from .renderer import Renderer, camera_hw, implementation_tile_size
 
 
 class HipPythonPreprocessGSplatRenderer(Renderer):
@@ -36,7 +36,7 @@ class HipPythonPreprocessGSplatRenderer(Renderer):
         if self.anti_aliased is True:
             opacities = opacities * comp[:, None]
         rgb = ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, img_height=img_height,
-                                      img_width=img_width, block_width=self.block_size, background=bg_color, return_alpha=False,
+                                      img_width=img_width, block_width=implementation_tile_size(self.block_size), background=bg_color, return_alpha=False,
                                       channels_first=True)
         return {
             "render": rgb,

@@ -130,3 +130,20 @@ def viewspace_grad_scale(W: int, H: int, like: torch.Tensor) -> torch.Tensor:
             _GRAD_SCALES.clear()
         t = _GRAD_SCALES[k] = (0.5 * torch.tensor([[W, H]])).to(like)
     return t
+
+
+_TILE_NOTE = set()
+
+
+def implementation_tile_size(block_size: int) -> int:
+    """The kernels of this package bin and composite on 16 x 16 tiles.  `block_size` is a configuration field of the reference's
+    gsplat renderers (gsplat_renderer.py:6,34-43, gsplat_v1_renderer.py:23-41) that selects the tile side of ITS rasterizer: the
+    rendered image and every gradient are independent of it (it decides how the per-tile lists are cut, nothing else), so a renderer
+    configured with another value renders the same result on 16 x 16 tiles; said once per value.  (The op-level entry points —
+    `ops.isect_tiles`, `ops.rasterize_to_pixels`, ... — still refuse other tile sizes: there the per-tile lists ARE the interface.)"""
+    if int(block_size) != 16 and block_size not in _TILE_NOTE:
+        _TILE_NOTE.add(block_size)
+        import warnings
+        warnings.warn(f"block_size={block_size}: this rasterizer tiles the image 16 x 16; the image and the gradients do not depend on "
+                      f"the tile size, the configured value is kept for the checkpoint only", stacklevel=3)
+    return 16

@@ -342,3 +342,33 @@ def test_gsplat_renderer_sees_pose_updates_and_other_devices_current():
     g = L.device_guard(params[0].to(DEV))
     with g:
         assert g.prev == -1 and torch.cuda.current_device() == 0      # already current: nothing switched, nothing to restore
+
+
+@pytest.mark.parametrize("block_size", [8, 32])
+def test_renderers_accept_the_reference_block_size_field(block_size):
+    """`block_size` is a configuration field of the reference's gsplat renderers (gsplat_renderer.py:6,34-43,
+    gsplat_v1_renderer.py:23-41) that selects the tile side of ITS rasterizer; the image and the gradients do not depend on it.
+    The renderers here keep the field (checkpoint hparams) and render on 16 x 16 tiles: the same bits as block_size = 16, forward
+    and backward, for the v0 and the v1 plugin."""
+    import warnings
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatRenderer, HipGSplatV1Renderer
+    params, cam, wimg, bg = _scene(n=3000)
+    camera = FakeCamera(cam, DEV)
+
+    def run(make):
+        model = FakeGaussianModel(*[p.to(DEV) for p in params])
+        out = make()(camera, model, bg.to(DEV))
+        (out["render"] * wimg.to(DEV)).sum().backward()
+        return out["render"].detach(), model.means.grad.clone(), model.opacities_.grad.clone()
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for make16, makeB in ((lambda: HipGSplatV1Renderer(block_size=16).instantiate(), lambda: HipGSplatV1Renderer(block_size=block_size).instantiate()),
+                              (lambda: HipGSplatRenderer(block_size=16), lambda: HipGSplatRenderer(block_size=block_size))):
+            a, b = run(make16), run(makeB)
+            assert torch.equal(a[0], b[0])                                   # the image: bit-identical
+            for x, y in zip(a[1:], b[1:]):                                   # gradients: the same kernels on the same lists (fp32 atomics order only)
+                assert_close_scaled(y.cpu().numpy(), x.cpu().numpy(), 2e-5, "gradient", frac_ok=1.0)
+    assert HipGSplatV1Renderer(block_size=block_size).block_size == block_size      # the field itself is kept
+    assert any("16 x 16" in str(w.message) for w in caught) or block_size == 16
