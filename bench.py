@@ -65,6 +65,9 @@ def parse():
                    help="size of the synthetic camera set the steps cycle through (one camera per rank per step, as the reference's data "
                         "loader hands them out, internal/dataset.py:146-184); 1 = the fixed camera of rounds 1-2")
     p.add_argument("--no-stage-rooflines", action="store_true", help="skip the staged pass that times every stage for `stage_rooflines`")
+    p.add_argument("--no-workload-stats", action="store_true",
+                   help="skip the per-camera pass that counts I, I', V and the blended pairs after the timed regions (profiler runs: the last "
+                        "launches of the process are then the last timed step); the line carries no roofline")
     p.add_argument("--workload", default="S-1080p-1M")
     p.add_argument("--api", default="vanilla", choices=["vanilla", "gsplat"])
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
@@ -563,7 +566,9 @@ def main():
     # tile culling, V = visible splats, valid pairs = (pixel, splat) pairs the compositing blends (COUNTED on the device).
     per_cam = []
     with torch.no_grad():
-        if mode == "sharded":
+        if args.no_workload_stats:
+            pass
+        elif mode == "sharded":
             m, s_, q = tensors[0], tensors[1], tensors[2]
             for c0 in cam_dicts:
                 vm = c0["world_to_camera"].T.contiguous().to(dev)
@@ -628,7 +633,7 @@ def main():
         avg = lambda key: (sum(e[key] for e in per_cam) / len(per_cam)) if per_cam and key in per_cam[0] else None
         I, list_entries, valid_pairs, V = avg("I"), avg("list_entries"), avg("valid_pairs"), avg("V")
         roofline = None
-        if bwd_ms:
+        if bwd_ms and per_cam:
             kernel = _lib.lib().gspl_composite_bwd_kernel_name().decode()
             traffic, traffic_source = pmc_traffic(f"{args.workload}/{api}", kernel)
             t_s = bwd_ms * 1e-3

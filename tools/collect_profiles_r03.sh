@@ -12,13 +12,13 @@ b --no-cpu-baseline --parallelism sharded --no-stage-rooflines > $O/${tag}_bench
 b --no-cpu-baseline --cameras 1 --no-stage-rooflines > $O/${tag}_bench_fixed_camera.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-renderer-only --no-stage-rooflines > /tmp/log_$tag.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-renderer-only --no-stage-rooflines --no-workload-stats > /tmp/log_$tag.txt 2>&1
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1); python /root/repo/tools/prof_summary.py stats $f 64 /root/repo/$O/${tag}_kernel_stats.csv > /dev/null
 f=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1); python /root/repo/tools/prof_summary.py seq $f composite_fwd /root/repo/$O/${tag}_sequence.txt > /dev/null
 pmc() {    # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python /root/repo/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-renderer-only --no-stage-rooflines > /tmp/logp_$name.txt 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -- python /root/repo/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-renderer-only --no-stage-rooflines --no-workload-stats > /tmp/logp_$name.txt 2>&1
   f=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1); python /root/repo/tools/prof_summary.py pmc $f /root/repo/$O/${tag}_pmc_$name.csv > /dev/null
 }
 pmc FETCH_SIZE FETCH_SIZE
