@@ -369,6 +369,6 @@ def test_renderers_accept_the_reference_block_size_field(block_size):
             a, b = run(make16), run(makeB)
             assert torch.equal(a[0], b[0])                                   # the image: bit-identical
             for x, y in zip(a[1:], b[1:]):                                   # gradients: the same kernels on the same lists (fp32 atomics order only)
-                assert_close_scaled(y.cpu().numpy(), x.cpu().numpy(), 2e-5, "gradient", frac_ok=1.0)
+                assert_close_scaled(y.cpu().numpy(), x.cpu().numpy(), 1e-4, "gradient", frac_ok=1.0)
     assert HipGSplatV1Renderer(block_size=block_size).block_size == block_size      # the field itself is kept
     assert any("16 x 16" in str(w.message) for w in caught) or block_size == 16
