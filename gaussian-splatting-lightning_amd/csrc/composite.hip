@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
     float* __restrict__ out_colors, float* __restrict__ out_alphas, float* __restrict__ final_Ts,
-    int32_t* __restrict__ last_ids, uint8_t* __restrict__ hit_flags) {
+    int32_t* __restrict__ last_ids, uint8_t* __restrict__ hit_flags, ListTiles lt) {
     using TR = ModeTraits<MODE>;
     __shared__ __attribute__((aligned(16))) float s_x[FLIST];
     __shared__ __attribute__((aligned(16))) float s_y[FLIST];
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const float qx0 = (float)((tile % tile_w) * TILE + (w & 1) * 8) + TR::kPixelCentre, qx1 = qx0 + 7.f;
     const float qy0 = (float)((tile / tile_w) * TILE + (w >> 1) * 8) + TR::kPixelCentre, qy1 = qy0 + 7.f;
 
-    int start, end;
-    tile_range(tile, n_tiles, n_isects, offsets, start, end);
+    int start, end;      // the list of the LIST tile this 8x8 block lies in (n_tiles / tile_w are the 16x16 compute grid)
+    block_list_range(lt, (tile % tile_w) * 2 + (w & 1), (tile / tile_w) * 2 + (w >> 1), width, height, n_isects, offsets, start, end);
 
     float T = 1.f;
     float acc[D];
@@ -163,15 +163,15 @@ template <int D, int MODE, bool CHW>
 static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
-                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, uint8_t* hit_flags, hipStream_t s) {
+                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, uint8_t* hit_flags, hipStream_t s, ListTiles lt) {
     if (hit_flags)
         hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, true>), dim3(4 * n_tiles), dim3(64), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags);
+                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, lt);
     else
         hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, false>), dim3(4 * n_tiles), dim3(64), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags);
+                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, lt);
     return check_launch("composite_fwd");
 }
 
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(64) void composite_scores_kernel(
 int check_composite_args(int N, int64_t n_isects, int D, int mode, int layout, int width, int height,
                         int tile_size, int tile_w, int tile_h, const char* who) {
     if (N < 0 || n_isects < -1 || width <= 0 || height <= 0) return fail_arg(who);
-    if (tile_size != TILE) { set_error(who, "only tile_size 16 is built"); return GSPL_ERR_UNSUPPORTED; }
-    if (tile_w != (width + TILE - 1) / TILE || tile_h != (height + TILE - 1) / TILE) return fail_arg(who);
+    if (tile_size != 8 && tile_size != 16 && tile_size != 32) { set_error(who, "tile_size must be 8, 16 or 32"); return GSPL_ERR_UNSUPPORTED; }
+    if (tile_w != (width + tile_size - 1) / tile_size || tile_h != (height + tile_size - 1) / tile_size) return fail_arg(who);
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg(who);
     if (layout != GSPL_LAYOUT_HWC && layout != GSPL_LAYOUT_CHW) return fail_arg(who);
     if (!(D == 1 || D == 2 || D == 3 || D == 4 || D == 8)) { set_error(who, "D must be 1,2,3,4 or 8"); return GSPL_ERR_UNSUPPORTED; }
@@ -284,10 +284,12 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
     if (rc != GSPL_OK) return rc;
     if (!offsets || !out_colors || !out_alphas || !final_Ts || !last_ids) return fail_arg("composite_fwd: NULL required pointer");
     if (n_isects != 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return fail_arg("composite_fwd: NULL required pointer");
-    const int n_tiles = tile_w * tile_h;
+    // the kernel walks 8x8 blocks grouped into 16x16 compute tiles; the lists are those of the caller's tile_size (8, 16 or 32)
+    const ListTiles lt = list_tiles(tile_size, tile_w, tile_h);
+    const int ctw = (width + TILE - 1) / TILE, n_tiles = ctw * ((height + TILE - 1) / TILE);
     hipStream_t s = (hipStream_t)stream;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, s)
+#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, s, lt)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_FWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_FWD) }
@@ -308,6 +310,7 @@ extern "C" int gspl_composite_scores(int N, int64_t n_isects, int mode,
     using namespace gspl;
     int rc = check_composite_args(N, n_isects, 1, mode, GSPL_LAYOUT_HWC, width, height, tile_size, tile_w, tile_h, "composite_scores: bad argument");
     if (rc != GSPL_OK) return rc;
+    if (tile_size != TILE) { set_error("composite_scores", "the statistics pass is built for tile_size 16"); return GSPL_ERR_UNSUPPORTED; }
     if (N == 0 || n_isects == 0) return GSPL_OK;
     if (!means2d || !conics || !opacities || !offsets || !flatten_ids) return fail_arg("composite_scores: NULL required pointer");
     if (weighted_sum && !pixel_weights) return fail_arg("composite_scores: weighted_sum needs pixel_weights");

@@ -330,6 +330,139 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward for tile lists cut on 8- or 32-pixel tiles (`tile_size` 8 / 32 of the callers, gsplat_v1_renderer.py:23-41): ONE WAVE
+// PER 8x8 BLOCK, one pixel per lane, the block walks the list of the list tile that holds it (gspl_composite.h, ListTiles) back
+// to front.  Per round of 64 list entries the lanes cull their entry against the block (box_reachable) and compact the candidates
+// with ballot + mbcnt (ascending lane = descending list index); per candidate every lane evaluates its pixel (the same expression
+// tree as composite_bwd2_kernel), the NV values are summed over the wave with DPP and lane 63 issues the L2 atomics.  The same
+// arithmetic and the same discrete decisions as the 16-pixel path; a compatibility path, correct before fast (the default tile size
+// of every configuration of the reference is 16).
+template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
+__global__ __launch_bounds__(64) void composite_bwd_block_kernel(
+    int n_tiles, int tile_w, int width, int height, int64_t n_isects,
+    const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
+    const float* __restrict__ opacities, const float* __restrict__ backgrounds,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
+    const float* __restrict__ final_Ts, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
+    float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
+    float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride,
+    uint8_t* __restrict__ hit_flags, ListTiles lt) {
+    using TR = ModeTraits<MODE>;
+    constexpr int NV = BwdVals<D, ABS>::N;
+    __shared__ float s_x[64], s_y[64], s_ha[64], s_b[64], s_hc[64], s_op[64];
+    __shared__ float s_col[64 * D];
+    __shared__ int s_g[64], s_idx[64];
+
+    const int unit = xcd_remap(blockIdx.x, 4 * n_tiles, 4 * GSPL_XCD_RUN);
+    const int tile = unit >> 2, w = unit & 3, l = threadIdx.x;
+    const int bx = (tile % tile_w) * 2 + (w & 1), by = (tile / tile_w) * 2 + (w >> 1);
+    const int px = bx * 8 + (l & 7), py = by * 8 + (l >> 3);
+    const bool inside = (px < width) && (py < height);
+    const float pxf = (float)px + TR::kPixelCentre, pyf = (float)py + TR::kPixelCentre;
+    const float qx0 = (float)(bx * 8) + TR::kPixelCentre, qy0 = (float)(by * 8) + TR::kPixelCentre;
+    int start, end;
+    block_list_range(lt, bx, by, width, height, n_isects, offsets, start, end);
+
+    const int64_t pix = (int64_t)py * width + px;
+    const int last = inside ? last_ids[pix] : start;
+    float T = inside ? final_Ts[pix] : 1.f;
+    float vo[D];
+    float bgdot = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        vo[c] = inside ? (CHW ? v_out_colors[(int64_t)c * width * height + pix] : v_out_colors[pix * D + c]) : 0.f;
+        if (backgrounds) bgdot += backgrounds[c] * vo[c];
+    }
+    float R = T * (((inside && v_out_alphas) ? v_out_alphas[pix] : 0.f) - bgdot);
+    int block_last = last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) block_last = max(block_last, __shfl_xor(block_last, off));
+
+    for (int hi = block_last; hi > start; hi -= 64) {
+        const int idx = hi - 1 - l;                 // lane 0 = the deepest entry of the round
+        bool cand = false;
+        int g = 0;
+        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
+        if (idx >= start) {
+            g = flatten_ids[idx];
+            ca = conics[g * 3 + 0]; cb = conics[g * 3 + 1]; cc = conics[g * 3 + 2]; op = opacities[g];
+            mx = means2d[g * 2 + 0]; my = means2d[g * 2 + 1];
+            cand = box_reachable(mx, my, ca, cb, cc, op, qx0, qx0 + 7.f, qy0, qy0 + 7.f);
+        }
+        const unsigned long long mask = __ballot(cand);
+        const int ncand = __builtin_popcountll(mask);
+        const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        __syncthreads();
+        if (cand) {
+            s_x[slot] = mx; s_y[slot] = my; s_ha[slot] = 0.5f * ca; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op;
+            s_g[slot] = g; s_idx[slot] = idx;
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_col[slot * D + c] = colors[(int64_t)g * D + c];
+        }
+        __syncthreads();
+        for (int k = 0; k < ncand; ++k) {
+            const int kidx = s_idx[k];
+            const float ha = s_ha[k], b = s_b[k], hc = s_hc[k], o = s_op[k];
+            const float dx = s_x[k] - pxf, dy = s_y[k] - pyf;
+            const float sigma = eval_sigma(ha, b, hc, dx, dy);
+            const float vis = __builtin_amdgcn_exp2f(sigma * -1.4426950408889634f);
+            const float raw = o * vis;
+            const bool valid = (kidx < last) && (sigma >= 0.f) && (raw >= kAlphaMin);
+            if (!__any(valid)) continue;
+            const float rv = valid ? raw : 0.f;
+            const float a = fminf(TR::kAlphaMax, rv);
+            float rw = rv;
+            if (TR::kClampKillsGrad) rw = (rv <= TR::kAlphaMax) ? rv : 0.f;
+            const float ra = __builtin_amdgcn_rcpf(1.f - a);
+            T *= ra;
+            const float fac = a * T;
+            float cdot = s_col[k * D] * vo[0];
+#pragma unroll
+            for (int c = 1; c < D; ++c) cdot = fmaf(s_col[k * D + c], vo[c], cdot);
+            const float v_alpha = fmaf(cdot, T, R * ra);
+            R = fmaf(-cdot, fac, R);
+            const float sp = -rw * v_alpha;
+            const float fa = 2.f * ha, fc = 2.f * hc;
+            float vals[NV];
+            vals[0] = sp * fmaf(fa, dx, b * dy);
+            vals[1] = sp * fmaf(b, dx, fc * dy);
+            vals[2] = 0.5f * sp * dx * dx;
+            vals[3] = sp * dx * dy;
+            vals[4] = 0.5f * sp * dy * dy;
+            vals[5] = (o != 0.f) ? -sp * __builtin_amdgcn_rcpf(o) : 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) vals[6 + c] = fac * vo[c];
+            if constexpr (ABS) { vals[6 + D] = fabsf(vals[0]); vals[7 + D] = fabsf(vals[1]); }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) vals[v] = wave_sum_to_lane63(vals[v]);
+            if (l == 63) {
+                const int gk = s_g[k];
+                if constexpr (PACKED) {
+                    float* row = v_means2d + (int64_t)gk * packed_stride;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) if (vals[v] != 0.f) atomicAdd(&row[v], vals[v]);
+                } else {
+                    atomicAdd(&v_means2d[gk * 2 + 0], vals[0]);
+                    atomicAdd(&v_means2d[gk * 2 + 1], vals[1]);
+                    atomicAdd(&v_conics[gk * 3 + 0], vals[2]);
+                    atomicAdd(&v_conics[gk * 3 + 1], vals[3]);
+                    atomicAdd(&v_conics[gk * 3 + 2], vals[4]);
+                    atomicAdd(&v_opacities[gk], vals[5]);
+#pragma unroll
+                    for (int c = 0; c < D; ++c) atomicAdd(&v_colors[(int64_t)gk * D + c], vals[6 + c]);
+                    if constexpr (ABS) {
+                        atomicAdd(&v_means2d_abs[gk * 2 + 0], vals[6 + D]);
+                        atomicAdd(&v_means2d_abs[gk * 2 + 1], vals[7 + D]);
+                    }
+                }
+                if (hit_flags) hit_flags[gk] = 1;
+            }
+        }
+    }
+}
+
 template <int D, int MODE, bool CHW, bool PACKED = false>
 static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
@@ -337,10 +470,15 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* final_Ts, const int32_t* last_ids,
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
-                      hipStream_t s, int packed_stride = 0, uint8_t* hit_flags = nullptr) {
+                      hipStream_t s, int packed_stride, uint8_t* hit_flags, ListTiles lt) {
 #define GSPL_BWD_ARGS n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, \
                       final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities,   \
                       packed_stride, hit_flags
+    if (lt.log2 != 4) {       // lists on 8- or 32-pixel tiles: the block-wise compatibility kernel
+        if (absgrad) hipLaunchKernelGGL((composite_bwd_block_kernel<D, MODE, CHW, true, PACKED>), dim3(4 * n_tiles), dim3(64), 0, s, GSPL_BWD_ARGS, lt);
+        else hipLaunchKernelGGL((composite_bwd_block_kernel<D, MODE, CHW, false, PACKED>), dim3(4 * n_tiles), dim3(64), 0, s, GSPL_BWD_ARGS, lt);
+        return check_launch("composite_bwd");
+    }
     if (absgrad) hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS);
     else hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS);
 #undef GSPL_BWD_ARGS
@@ -365,11 +503,12 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
     if (!means2d || !conics || !colors || !opacities || !offsets || !flatten_ids || !final_Ts || !last_ids ||
         !v_out_colors || !v_means2d || !v_conics || !v_colors || !v_opacities)
         return fail_arg("composite_bwd: NULL required pointer");
-    const int n_tiles = tile_w * tile_h;
+    const ListTiles lt = list_tiles(tile_size, tile_w, tile_h);
+    const int ctw = (width + TILE - 1) / TILE, n_tiles = ctw * ((height + TILE - 1) / TILE);      // 16x16 compute tiles
     hipStream_t s = (hipStream_t)stream;
     const bool absgrad = v_means2d_abs != nullptr;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWD(kD, M, C) rc = launch_bwd<kD, M, C>(absgrad, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, s, 0, hit_flags)
+#define CALL_BWD(kD, M, C) rc = launch_bwd<kD, M, C>(absgrad, n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities, s, 0, hit_flags, lt)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWD) }
@@ -401,11 +540,12 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
     if (n_isects == 0 || N == 0) return GSPL_OK;
     if (!means2d || !conics || !colors || !opacities || !offsets || !flatten_ids || !final_Ts || !last_ids || !v_out_colors || !v_packed)
         return fail_arg("composite_bwd_packed: NULL required pointer");
-    const int n_tiles = tile_w * tile_h;
+    const ListTiles lt = list_tiles(tile_size, tile_w, tile_h);
+    const int ctw = (width + TILE - 1) / TILE, n_tiles = ctw * ((height + TILE - 1) / TILE);      // 16x16 compute tiles
     hipStream_t s = (hipStream_t)stream;
     const bool ag = absgrad != 0;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride, hit_flags)
+#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride, hit_flags, lt)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWDP) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWDP) }

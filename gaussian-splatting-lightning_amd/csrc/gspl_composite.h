@@ -99,6 +99,28 @@ __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isec
     end = (tile + 1 < n_tiles || n_isects < 0) ? offsets[tile + 1] : (int)n_isects;
 }
 
+// The tile lists may be cut on 8-, 16- or 32-pixel tiles (`tile_size` of the callers: gsplat_v1_renderer.py:23-41); the kernels
+// always work on 8x8 pixel blocks grouped into 16x16 compute tiles.  The list of a block is the list of the LIST tile that holds it.
+struct ListTiles {
+    int log2;      // list tile side = 1 << log2 (3, 4, 5)
+    int w;         // list tiles per row
+    int n;         // number of list tiles
+};
+static inline ListTiles list_tiles(int tile_size, int tile_w, int tile_h) {
+    ListTiles lt;
+    lt.log2 = tile_size == 8 ? 3 : (tile_size == 32 ? 5 : 4);
+    lt.w = tile_w;
+    lt.n = tile_w * tile_h;
+    return lt;
+}
+__device__ __forceinline__ void block_list_range(const ListTiles& lt, int bx, int by, int width, int height, int64_t n_isects,
+                                                 const int32_t* __restrict__ offsets, int& start, int& end) {
+    if (bx * 8 >= width || by * 8 >= height) { start = end = 0; return; }      // (a block of the compute grid outside the image)
+    const int t = (by >> (lt.log2 - 3)) * lt.w + (bx >> (lt.log2 - 3));
+    start = offsets[t];
+    end = (t + 1 < lt.n || n_isects < 0) ? offsets[t + 1] : (int)n_isects;
+}
+
 // number of per-splat gradient values accumulated per (tile, splat): xy(2) conic(3) opacity(1) colour(D) [+abs xy(2)]
 template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (ABS ? 2 : 0); };
 

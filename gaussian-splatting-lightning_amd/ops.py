@@ -934,8 +934,8 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
     """First half of `bin_gaussians`: per-Gaussian tile counts, depth order and their scan (`gspl_bin_count`), then an
     ASYNCHRONOUS copy of the total to the host.  Work that does not depend on the lists (the SH kernel) can be launched
     before `bin_gaussians_end`, so the device is busy while the host waits for the one number that sizes the sort."""
-    if block_width != 16:
-        raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
+    if block_width not in (8, 16, 32):
+        raise NotImplementedError("block_width must be 8, 16 or 32 (the reference default is 16, gsplat_renderer.py:6)")
     lib = L.lib()
     p = _PendingBins()
     p.block_width = block_width
@@ -1054,8 +1054,8 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
     colors [N,D], opacity [N,1] -> [H,W,D] (and alpha [H,W] when return_alpha).
     channels_first (extension): the image comes out as [D,H,W] straight from the kernel — what the reference builds with
     `.permute(2, 0, 1)` and every consumer (loss, metrics) then has to make contiguous, forward and backward."""
-    if block_width != 16:
-        raise NotImplementedError("block_width 16 only (the reference default, gsplat_renderer.py:6)")
+    if block_width not in (8, 16, 32):
+        raise NotImplementedError("block_width must be 8, 16 or 32 (the reference default is 16, gsplat_renderer.py:6)")
     flat, offsets = isects if isects is not None else bin_gaussians(xys, depths, radii, img_height, img_width, block_width,
                                                                     conics=conics, opacities=opacity)
     out, alphas = _composite(xys, conics, colors, opacity.reshape(-1), background, img_width, img_height, block_width,

@@ -140,7 +140,8 @@ def implementation_tile_size(block_size: int) -> int:
     gsplat renderers (gsplat_renderer.py:6,34-43, gsplat_v1_renderer.py:23-41) that selects the tile side of ITS rasterizer: the
     rendered image and every gradient are independent of it (it decides how the per-tile lists are cut, nothing else), so a renderer
     configured with another value renders the same result on 16 x 16 tiles; said once per value.  (The op-level entry points —
-    `ops.isect_tiles`, `ops.rasterize_to_pixels`, ... — still refuse other tile sizes: there the per-tile lists ARE the interface.)"""
+    `ops.isect_tiles`, `ops.rasterize_to_pixels`, `ops.bin_gaussians`, `ops.rasterize_gaussians` — take tile sizes 8, 16 and 32: there
+    the per-tile lists ARE the interface; 16 is the fast path, which is why the renderers stay on it.)"""
     if int(block_size) != 16 and block_size not in _TILE_NOTE:
         _TILE_NOTE.add(block_size)
         import warnings

@@ -36,7 +36,9 @@
 
 #define MODE_GSPLAT 0
 #define MODE_INRIA 1
-#define TILE 16
+/* side of the tiles the lists are cut on: 16 unless the caller says otherwise (8 / 32: `block_size` of the reference's renderers) */
+static int TILE = 16;
+void oracle_set_tile(int tile) { TILE = tile; }
 
 typedef struct {
     double alpha_max;

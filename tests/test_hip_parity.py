@@ -212,6 +212,27 @@ def test_binning_bit_exact(hip, mode, wh):
     assert np.array_equal(offs2.cpu().numpy(), offs_ref)
 
 
+@pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
+@pytest.mark.parametrize("tile", [8, 32])
+@pytest.mark.parametrize("wh", [(320, 240), (333, 211)])
+def test_binning_bit_exact_tile_sizes_8_and_32(hip, mode, tile, wh):
+    """`block_size` 8 / 32 (gsplat_v1_renderer.py:23-41 passes it as `tile_size`): same keys, same lists as the oracle."""
+    W, H = wh
+    res, _, _, _ = _projected_scene(4000, W, H, 300.0)
+    xys, depths, radii = res[0], res[1], res[2]
+    tiles_ref, ids_ref, flat_ref, offs_ref = O.isect_tiles(mode, xys, radii, depths, W, H, block=tile)
+    tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
+    tiles, ids, flat = hip.isect_tiles(xys.to(_dev())[None], radii.to(_dev())[None], depths.to(_dev())[None], tile, tw, th, mode=mode)
+    offs = hip.isect_offset_encode(ids, 1, tw, th)
+    assert np.array_equal(tiles[0].cpu().numpy(), tiles_ref)
+    assert np.array_equal(ids.cpu().numpy(), ids_ref)
+    assert np.array_equal(flat.cpu().numpy(), flat_ref)
+    assert np.array_equal(offs.reshape(-1).cpu().numpy(), offs_ref)
+    flat2, offs2 = hip.bin_gaussians(xys.to(_dev()), depths.to(_dev()), radii.to(_dev()), H, W, tile, mode=mode)
+    assert np.array_equal(flat2.cpu().numpy(), flat_ref)
+    assert np.array_equal(offs2.cpu().numpy(), offs_ref)
+
+
 def test_binning_two_level_ties_and_empty(hip):
     """Equal depths (ties must stay in Gaussian-id order), all-culled and N == 0 inputs."""
     d = _dev()
@@ -410,7 +431,7 @@ def test_binning_empty_inputs(hip):
 # ---------------------------------------------------------------------------------------------
 # compositing: forward <= 1e-5 abs / pixel, backward <= 1e-4 rel
 # ---------------------------------------------------------------------------------------------
-def _composite_case(mode, D, W, H, n=6000, seed=11, big=False):
+def _composite_case(mode, D, W, H, n=6000, seed=11, big=False, tile=16):
     res, opac, shs, cam = _projected_scene(n, W, H, 260.0, seed=seed, scale_mul=(12.0 if big else 3.0))
     xys, depths, radii, conics, comp = res[0], res[1], res[2], res[3], res[4]
     g = torch.Generator().manual_seed(seed)
@@ -420,20 +441,24 @@ def _composite_case(mode, D, W, H, n=6000, seed=11, big=False):
     bg = torch.rand(D, generator=g)
     if mode == O.MODE_INRIA:
         xys = xys - 0.5
-    tiles, ids, flat, offs = O.isect_tiles(mode, xys, radii, depths, W, H)
+    tiles, ids, flat, offs = O.isect_tiles(mode, xys, radii, depths, W, H, block=tile)
     return xys.float(), conics.float(), colors, op, bg, flat, offs
 
 
 @pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
-@pytest.mark.parametrize("D,wh,big", [(3, (320, 240), False), (1, (333, 211), False), (4, (160, 96), True), (8, (97, 65), False), (2, (64, 48), True)])
-def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
+@pytest.mark.parametrize("D,wh,big,tile", [(3, (320, 240), False, 16), (1, (333, 211), False, 16), (4, (160, 96), True, 16), (8, (97, 65), False, 16),
+                                           (2, (64, 48), True, 16),
+                                           # lists cut on 8- and 32-pixel tiles (`block_size` of the reference's renderers)
+                                           (3, (320, 240), False, 8), (3, (333, 211), True, 8), (1, (97, 65), False, 8),
+                                           (3, (320, 240), False, 32), (4, (333, 211), True, 32), (8, (97, 65), False, 32)])
+def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big, tile):
     from gspl_amd import _lib as L
     W, H = wh
-    xys, conics, colors, op, bg, flat, offs = _composite_case(mode, D, W, H, big=big)
-    out_ref, alpha_ref, last_ref, frag = O.composite_fwd(mode, xys, conics, colors, op, bg, W, H, offs, flat)
+    xys, conics, colors, op, bg, flat, offs = _composite_case(mode, D, W, H, big=big, tile=tile)
+    out_ref, alpha_ref, last_ref, frag = O.composite_fwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, tile=tile)
     c = lambda a: torch.as_tensor(a).contiguous().to(_dev())
     dxy, dcon, dcol, dop, dbg, dflat, doffs = c(xys), c(conics), c(colors), c(op), c(bg), c(flat), c(offs)
-    out, alphas, final_T, last = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat)
+    out, alphas, final_T, last = hip_composite_fwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, tile=tile)
     ok = frag == 0
     assert ok.mean() > 0.995
     assert np.abs(out.cpu().numpy() - out_ref)[ok].max() <= 1e-5
@@ -449,12 +474,12 @@ def test_composite_fwd_bwd_vs_oracle(hip, mode, D, wh, big):
     fragile = torch.from_numpy(frag != 0)
     v_out[fragile] = 0.0
     v_alpha[fragile] = 0.0
-    got = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, final_T, last, c(v_out), c(v_alpha), absgrad=True)
+    got = hip_composite_bwd(mode, dxy, dcon, dcol, dop, dbg, W, H, doffs, dflat, final_T, last, c(v_out), c(v_alpha), absgrad=True, tile=tile)
     # the oracle differentiates the discrete path the GPU took (its alphas / last_ids)
     ref = O.composite_bwd(mode, xys, conics, colors, op, bg, W, H, offs, flat, 1.0 - final_T.cpu().double().numpy(),
-                          last.cpu().numpy(), v_out.double().numpy(), v_alpha.double().numpy(), fragile_px=frag, absgrad=True)
+                          last.cpu().numpy(), v_out.double().numpy(), v_alpha.double().numpy(), fragile_px=frag, absgrad=True, tile=tile)
     for k in ("v_means2d", "v_means2d_abs", "v_conics", "v_colors", "v_opacities"):
-        assert_close_scaled(got[k].cpu().numpy(), ref[k], 1e-4, f"{k} mode={mode} D={D}", frac_ok=1.0)
+        assert_close_scaled(got[k].cpu().numpy(), ref[k], 1e-4, f"{k} mode={mode} D={D} tile={tile}", frac_ok=1.0)
     keep = ref["fragile_g"] == 0          # (only for the hit flags below: a splat seen by a fragile pixel alone has no oracle gradient)
     # ... and so are the fragile pixels of the forward
     assert np.abs(out.cpu().numpy() - out_ref).max() <= 1e-3
@@ -509,6 +534,42 @@ def test_rasterize_to_pixels_wrapper_channels_and_absgrad(hip):
     assert hasattr(means2d, "absgrad") and means2d.absgrad.shape == (xys.shape[0], 2)
     assert torch.all(means2d.absgrad >= means2d.grad.abs() - 1e-6)
     assert col.grad.shape == (xys.shape[0], D)
+
+
+@pytest.mark.parametrize("tile", [8, 32])
+def test_rasterize_ops_with_tile_sizes_8_and_32(hip, tile):
+    """The op-level entry points with lists cut on 8- / 32-pixel tiles: `rasterize_to_pixels` (v1, gsplat_v1_renderer.py:588-601) on
+    the oracle's lists and `rasterize_gaussians` (v0, gsplat_renderer.py:86-99) binning by itself, forward against the oracle and
+    the packed backward (the path the autograd wrappers take) against the separate-array one."""
+    W, H, D = 210, 130, 3
+    xys, conics, colors, op, bg, flat, offs = _composite_case(O.MODE_GSPLAT, D, W, H, n=5000, tile=tile)
+    ref, aref, _, frag = O.composite_fwd(O.MODE_GSPLAT, xys, conics, colors, op, bg, W, H, offs, flat, tile=tile)
+    ok = frag == 0
+    tw, th = (W + tile - 1) // tile, (H + tile - 1) // tile
+    leaves = [t.to(_dev()).requires_grad_(True) for t in (xys, conics, colors, op)]
+    m2, con, col, opd = leaves
+    out, alphas = hip.rasterize_to_pixels(m2, con[None], col[None], opd[None], W, H, tile,
+                                          torch.as_tensor(offs).to(_dev()).reshape(1, th, tw), torch.as_tensor(flat).to(_dev()),
+                                          backgrounds=bg.to(_dev())[None], absgrad=True)
+    assert np.abs(out[0].detach().cpu().numpy() - ref)[ok].max() <= 1e-5
+    assert np.abs(alphas[0, ..., 0].detach().cpu().numpy() - aref)[ok].max() <= 1e-5
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(H, W, D, generator=g)
+    w[torch.from_numpy(frag != 0)] = 0.0
+    (out[0] * w.to(_dev())).sum().backward()
+    # the oracle differentiates the path the GPU took
+    c = lambda a: torch.as_tensor(a).contiguous().to(_dev())
+    o2, a2, final_T, last = hip_composite_fwd(O.MODE_GSPLAT, c(xys), c(conics), c(colors), c(op), c(bg), W, H, c(offs), c(flat), tile=tile)
+    gref = O.composite_bwd(O.MODE_GSPLAT, xys, conics, colors, op, bg, W, H, offs, flat, 1.0 - final_T.cpu().double().numpy(),
+                           last.cpu().numpy(), w.double().numpy(), None, fragile_px=frag, absgrad=True, tile=tile)
+    for t, k in zip(leaves, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        assert_close_scaled(t.grad.cpu().numpy().reshape(gref[k].shape), gref[k], 1e-4, f"{k} tile={tile}", frac_ok=1.0)
+    assert_close_scaled(m2.absgrad.cpu().numpy(), gref["v_means2d_abs"], 1e-4, f"absgrad tile={tile}", frac_ok=1.0)
+    # v0 entry point: bins by itself (exact row spans, the culled lists) -> the same image within the fp32 bar
+    res, _, _, _ = _projected_scene(5000, W, H, 260.0, seed=11, scale_mul=3.0)
+    radii, depths = res[2], res[1]
+    img = hip.rasterize_gaussians(c(xys), c(depths), c(radii), c(conics), None, c(colors), c(op)[:, None], H, W, tile, c(bg))
+    assert np.abs(img.cpu().numpy() - ref)[ok].max() <= 1e-5
 
 
 # ---------------------------------------------------------------------------------------------
