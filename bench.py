@@ -80,6 +80,8 @@ def parse():
     p.add_argument("--parallelism", default="auto", choices=["auto", "single", "replicated", "sharded"],
                    help="auto: single for one GPU, sharded for several (Gaussian-sharded renderer with the packed all-to-all, "
                         "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
+    p.add_argument("--no-overlap-sh-update", action="store_true",
+                   help="keep the whole optimizer step on the caller's stream (default on one GPU: the shs_rest update overlaps the next frame's binning)")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
     p.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg and print it (no GPU needed)")
     p.add_argument("--stage-times", action="store_true",
@@ -106,7 +108,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
     fwd_ms / bwd_ms of the bench line."""
     import gspl_amd  # noqa: F401
     from gspl_amd import ops
-    m, s, q, o, c = tensors
+    m, s, q, o, dc, rest = tensors          # the reference model's six parameters (shs_dc and shs_rest apart, vanilla_gaussian.py:266-300)
     W, H = wl["width"], wl["height"]
     bg = torch.zeros(3, device=dev)
     target = torch.full((3, H, W), 0.5, device=dev)
@@ -135,7 +137,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             if marks is not None:
                 marks.append(_mark())
             screen = torch.empty_like(m).requires_grad_(True)      # gradient carrier, as HipVanillaRenderer creates it (values unused)
-            render, radii = rast(means3D=m, means2D=screen, opacities=o, shs=c, scales=s, rotations=q)
+            render, radii = rast(means3D=m, means2D=screen, opacities=o, shs=dc, shs_rest=rest, scales=s, rotations=q)
             loss = loss_fn(render)
             if marks is not None:
                 marks.append(_mark())
@@ -164,7 +166,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             opac = o * comp[:, None]
             # same order as HipGSplatRenderer.forward: count half of the binning, SH, emit half, compositing
             pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, 16, conics=conics, opacities=opac)
-            rgbs = ops.sh_view_colors(3, m, center, c, None, radii > 0)
+            rgbs = ops.sh_view_colors(3, m, center, dc, rest, radii > 0)
             img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
                                           isects=ops.bin_gaussians_end(pending), channels_first=True)
             loss = loss_fn(img)
@@ -399,7 +401,10 @@ def main():
                 sys.exit("--optimizer masked-adam belongs to --parallelism replicated")
             return gdist.MaskedReplicaAdam([(str(i), g["params"][0], g["lr"]) for i, g in enumerate(groups)], eps=1e-15)
         from gspl_amd import optimizers as gopt
-        return (gopt.FusedAdam if kind == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15)
+        # single GPU: the update of shs_rest (45 of a Gaussian's 59 floats) runs on the rasterizer's colour stream, under the next
+        # frame's geometry and binning kernels (FusedAdam(deferred=...): same kernel, bit-identical parameters)
+        deferred = ("shs_rest",) if (mode == "single" and not args.no_overlap_sh_update) else None
+        return (gopt.FusedAdam if kind == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15, deferred=deferred)
 
     DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
     counter = {"n": 0}
@@ -452,10 +457,11 @@ def main():
         visible = None
         api = "gsplat"
     else:
-        tensors = [t.to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs)]
+        # the reference model's parameters: the SH coefficients are two of them, shs_dc [N,1,3] and shs_rest [N,15,3]
+        tensors = [t.contiguous().to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs[:, :1], shs[:, 1:])]
         N = wl["n"]
         step = make_step(args.api, dev, wl, cam_dicts, tensors, args.loss, rank, world)
-        lrs = LRS
+        lrs = LRS[:4] + (LRS[4], LRS[4] / 20.0)
 
         def stats(st, accum, denom, max_radii):
             densification_stats(st, accum, denom, max_radii)
@@ -541,7 +547,8 @@ def main():
             elapsed = float(t.item())
         return elapsed, prof, marks
 
-    groups = [{"params": [t], "lr": lr * 1e-3} for t, lr in zip(tensors, lrs)]
+    GROUP_NAMES = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+    groups = [{"params": [t], "lr": lr * 1e-3, "name": n} for t, lr, n in zip(tensors, lrs, GROUP_NAMES)]
     optimizer = make_optimizer(args.optimizer, groups)
     ops.KEEP_LAST_RASTER = True
     elapsed, prof, marks = timed_region(make_full_step(optimizer, args.optimizer), args.steps, args.warmup)
@@ -596,7 +603,7 @@ def main():
                     entry["I"] = int(ops.bin_gaussians(last["means2d"], last["depths"], last["radii"], H, W, 16, mode=_lib.GSPL_MODE_INRIA)[0].shape[0])
                     entry["V"] = int((last["radii"] > 0).sum().item())
                 else:
-                    m, s_, q, o, c = tensors
+                    m, s_, q = tensors[:3]
                     vm = c0["world_to_camera"].T.contiguous().to(dev)
                     pr = ops.project_gaussians(m, s_, 1.0, q, vm[:3], c0["fx"], c0["fy"], c0["cx"], c0["cy"], H, W, 16)
                     entry["I"], entry["V"] = int(pr[5].sum().item()), int((pr[2] > 0).sum().item())
@@ -677,12 +684,15 @@ def main():
                 "composite_bwd": entry(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * I + 20.0 * P, "76 I + 20 P"),
                 "inria_preprocess_bwd_with_sh_bwd": entry(per_step(al, ("gspl_inria_preprocess_bwd",)), (116.0 + 24.0 * K) * V, "(36 + 40 + 40) V + 2 * 12 K V"),
                 "loss_fwd_bwd": entry(per_step(al, ("gspl_loss_l1_ssim_fwd", "gspl_loss_l1_ssim_bwd")), 4.0 * 3 * P * (2 + 3 + 4), "3 P floats: 2 read fwd, 3 maps written, 3 read + 1 written bwd"),
-                "adam": entry(per_step(al, ("gspl_selective_adam",)), 28.0 * 59.0 * N_, "28 B x 59 floats x N (param, grad, two moments read; param, two moments written)"),
+                "adam": entry(per_step(al, ("gspl_selective_adam", "gspl_selective_adam_limited")), 28.0 * 59.0 * N_, "28 B x 59 floats x N (param, grad, two moments read; param, two moments written)"),
                 "densify_stats": entry(per_step(al, ("gspl_densify_stats",)), 29.0 * N_, "grad 12 + radii 4 + three buffers 12 read, up to 12 written, + mask 1"),
             }
         step_desc = ("renderer fwd + " + ("L1 loss" if args.loss == "l1" else "0.8 L1 + 0.2 (1-SSIM) loss (fused)") + " + full bwd"
                      + (" + gradient all-reduce" if mode == "replicated" and args.optimizer != "none" else "")
-                     + ("" if args.optimizer == "none" else " + " + args.optimizer + " step") + " + densification stats")
+                     + ("" if args.optimizer == "none" else " + " + args.optimizer + " step")
+                     + (" (shs_rest update on the colour stream, under the next frame's geometry + binning)"
+                        if (mode == "single" and args.optimizer in ("fused-adam", "selective-adam") and not args.no_overlap_sh_update) else "")
+                     + " + densification stats")
         par = {"single": "single GPU",
                "replicated": (f"replicated Gaussians, {world} camera(s)/step, "
                               + ("visibility-masked reduce-scatter of the gradient rows to their owners + masked Adam on the owner + all-gather of the updated rows"

@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "gspl_loss_photometric_fwd": (c_int, [c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_loss_l1_ssim_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, _P]),
     "gspl_selective_adam": (c_int, [c_int, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, _P]),
+    "gspl_selective_adam_limited": (c_int, [c_int, _P, c_int, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "gspl_radix_sort_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "gspl_radix_sort_pairs_u32": (c_int, [c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     "gspl_radix_sort_keys_u64": (c_int, [c_int64, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
@@ -104,20 +105,20 @@ _SIGNATURES = {
                                    _P, _P, _P, _P, _P, _P, _P]),
     "gspl_composite_bwd_packed": (c_int, [c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
-    "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "gspl_inria_preprocess_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_int, c_float, c_float, c_float,
                                           _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
-    "gspl_rasterize_inria_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float,
+    "gspl_rasterize_inria_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float,
                                          ALLOC_FN, _P, c_int64, _P, _P, ctypes.POINTER(InriaState), _P, _P]),
-    "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
-                                         _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
+                                         _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_profile_enable": (c_int, [c_int]),
     "gspl_profile_read": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),
     "gspl_rasterize_inria_geometry_bytes": (c_size_t, [c_int]),
     "gspl_rasterize_inria_image_bytes": (c_size_t, [c_int, c_int]),
-    "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+    "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_float, c_float, c_float,
-                                          _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                          _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _LIB = None

@@ -114,7 +114,14 @@ __global__ __launch_bounds__(256) void selective_adam_kernel(AdamBatchDev batch,
 extern "C" int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors, int N, const uint8_t* visible,
                                    float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
                                    void* stream) {
+    return gspl_selective_adam_limited(n_tensors, tensors, N, visible, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt, 0, stream);
+}
+
+extern "C" int gspl_selective_adam_limited(int n_tensors, const gspl_adam_tensor* tensors, int N, const uint8_t* visible,
+                                           float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
+                                           int max_blocks, void* stream) {
     using namespace gspl;
+    if (max_blocks < 0) return fail_arg("selective_adam: bad sizes");
     if (n_tensors < 0 || n_tensors > GSPL_ADAM_MAX_TENSORS || N < 0) return fail_arg("selective_adam: bad sizes");
     if (n_tensors == 0 || N == 0) return GSPL_OK;
     if (!tensors) return fail_arg("selective_adam: NULL tensor table");
@@ -131,7 +138,9 @@ extern "C" int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensor
     }
     for (int k = n_tensors; k < GSPL_ADAM_MAX_TENSORS; ++k) b.t[k] = b.t[0];
     const int64_t want = ((longest >> 2) + 255) / 256;
-    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(want, 16384));
+    // max_blocks > 0: a launch that runs NEXT TO other work (the deferred update on the colour stream) keeps to that many workgroups
+    // per tensor, so that it leaves wave slots on every CU to the kernels of the other stream; the loop is grid-strided either way
+    const int gx = (int)std::max<int64_t>(1, std::min<int64_t>(want, max_blocks > 0 ? max_blocks : 16384));
     hipLaunchKernelGGL(selective_adam_kernel, dim3(gx, n_tensors), dim3(256), 0, (hipStream_t)stream, b, N, visible,
                        beta1, beta2, eps, 1.f / bias_correction1, 1.f / bias_correction2_sqrt);
     return check_launch("selective_adam");

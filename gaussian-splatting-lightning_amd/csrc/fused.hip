@@ -145,7 +145,7 @@ extern "C" size_t gspl_rasterize_inria_image_bytes(int width, int height) {
 extern "C" int gspl_rasterize_inria_fwd(
     int N, int degree, int n_coeffs,
     const float* means3D, const float* scales, const float* rotations, const float* cov3D_precomp,
-    const float* shs, const float* colors_precomp, const float* opacities,
+    const float* shs, const float* shs_rest, const float* colors_precomp, const float* opacities,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
     int width, int height, float tanfovx, float tanfovy, float scale_modifier,
     gspl_alloc_fn alloc, void* alloc_ctx, int64_t capacity_hint,
@@ -193,7 +193,7 @@ extern "C" int gspl_rasterize_inria_fwd(
         if (!host) return fail_arg("rasterize_inria_fwd: no pinned host word");
         // geometry; then two independent chains: the colour (SH) kernel on the side stream, the count / depth-sort half of the
         // binning on the caller's stream; the host meanwhile waits for the one number that sizes the tile sort
-        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
+        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, shs_rest, colors_precomp, viewmatrix, projmatrix,
                                        campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
                                        st->colors, st->clamped, st->cov3d, nullptr, GSPL_INRIA_GEOMETRY, s);
         if (rc != GSPL_OK) return rc;
@@ -206,7 +206,7 @@ extern "C" int gspl_rasterize_inria_fwd(
             (void)hipStreamWaitEvent(ss, ev_geo, 0);
         }
         hipStream_t cs = (ss && ss != s) ? ss : s;
-        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, colors_precomp, viewmatrix, projmatrix,
+        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, shs_rest, colors_precomp, viewmatrix, projmatrix,
                                        campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
                                        st->colors, st->clamped, st->cov3d, st->sh_jac, GSPL_INRIA_COLOURS, cs);
         if (rc == GSPL_OK && ev_col) (void)hipEventRecord(ev_col, cs);
@@ -273,12 +273,12 @@ extern "C" int gspl_rasterize_inria_fwd(
 
 extern "C" int gspl_rasterize_inria_bwd(
     int degree, int n_coeffs,
-    const float* means3D, const float* scales, const float* rotations, const float* shs, const float* opacities,
+    const float* means3D, const float* scales, const float* rotations, const float* shs, const float* shs_rest, const float* opacities,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
     float tanfovx, float tanfovy, float scale_modifier,
     const int32_t* radii, const gspl_inria_state* st, const float* v_out_color,
     float* packed /* [N, 9] scratch */, uint8_t* hit_flags,
-    float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_colors_precomp, float* v_opacities,
+    float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_shs_rest, float* v_colors_precomp, float* v_opacities,
     float* v_scales, float* v_rotations, float* v_cov3D, void* stream) {
     using namespace gspl;
     if (!st || st->N < 0) return fail_arg("rasterize_inria_bwd: bad state");
@@ -301,7 +301,7 @@ extern "C" int gspl_rasterize_inria_bwd(
                                        packed, 9, 0, hit_flags, s);
         if (rc != GSPL_OK) return rc;
     }
-    return gspl_inria_preprocess_bwd(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, viewmatrix, projmatrix, campos, width, height,
+    return gspl_inria_preprocess_bwd(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
                                      tanfovx, tanfovy, scale_modifier, radii, st->clamped, packed, packed + 2, packed + 6, 9, v_means3D, v_scales,
-                                     v_rotations, v_cov3D, v_shs, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac, s);
+                                     v_rotations, v_cov3D, v_shs, v_shs_rest, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac, s);
 }

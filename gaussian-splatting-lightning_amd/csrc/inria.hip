@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void masked_copy3_kernel(int N, const int32_t*
 
 extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                                          const float* means, const float* scales, const float* quats,
-                                         const float* cov3d_precomp, const float* shs, const float* colors_precomp,
+                                         const float* cov3d_precomp, const float* shs, const float* shs_rest, const float* colors_precomp,
                                          const float* viewmatrix, const float* projmatrix, const float* campos,
                                          int width, int height, int tile_size,
                                          float tanfovx, float tanfovy, float scale_modifier,
@@ -299,20 +299,24 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
         hipLaunchKernelGGL(masked_copy3_kernel, dim3(grid), dim3(256), 0, s, N, radii, colors_precomp, 3, colors, clamped);
         return check_launch("inria_preprocess_fwd(colors_precomp)");
     }
+    // shs_rest == NULL: `shs` holds all n_coeffs rows of a Gaussian ([N, n_coeffs, 3]); otherwise `shs` is the DC row ([N, 1, 3]) and
+    // `shs_rest` the others ([N, n_coeffs - 1, 3]) — the two parameters of the reference's model, read where they are
     const int stride = 3 * n_coeffs;
+    if (shs_rest) return sh_fwd_launch(N, 1, degree, means, campos, shs, 3, shs_rest, stride - 3, nullptr, radii,
+                                       GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream, sh_jac);
     return sh_fwd_launch(N, 1, degree, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
                          GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream, sh_jac);
 }
 
 extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                                          const float* means, const float* scales, const float* quats,
-                                         const float* cov3d, const float* shs,
+                                         const float* cov3d, const float* shs, const float* shs_rest,
                                          const float* viewmatrix, const float* projmatrix, const float* campos,
                                          int width, int height, float tanfovx, float tanfovy, float scale_modifier,
                                          const int32_t* radii, const uint8_t* clamped,
                                          const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
                                          float* v_means, float* v_scales, float* v_quats,
-                                         float* v_cov3d_precomp, float* v_shs, float* v_colors_precomp,
+                                         float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
                                          float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac, void* stream) {
     using namespace gspl;
     if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
@@ -333,8 +337,12 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
         if (degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("inria_preprocess_bwd: bad degree / n_coeffs");
         const int stride = 3 * n_coeffs;
         // dL/d(dir) lands in v_means; the geometry kernel accumulates on top
-        int rc = sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
-                               GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream, sh_jac);
+        if ((shs_rest == nullptr) != (v_shs_rest == nullptr)) return fail_arg("inria_preprocess_bwd: shs_rest and v_shs_rest go together");
+        int rc = shs_rest
+            ? sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, 3, shs_rest, stride - 3, nullptr, radii,
+                            GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs_rest, v_means, stream, sh_jac)
+            : sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
+                            GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream, sh_jac);
         if (rc != GSPL_OK) return rc;
         accum = true;
     }

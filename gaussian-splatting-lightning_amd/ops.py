@@ -275,6 +275,7 @@ class _SHFn(torch.autograd.Function):
             mask8 = masks.contiguous().view(torch.uint8) if masks.dtype == torch.bool else masks.to(torch.uint8).contiguous()
         colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
         clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev) if (flags & L.GSPL_SH_ADD_HALF_CLAMP) else None
+        _await_updates(dc, rest)
         L.call("gspl_sh_fwd", N, int(degree), L.ptr(dirs), L.ptr(origin), L.ptr(dc), dc_stride, rest_ptr, rest_stride,
                                 L.ptr(mask8), int(flags), L.ptr(colors), L.ptr(clamped), L.stream())
         ctx.save_for_backward(dirs, origin, dc, rest, mask8, clamped)
@@ -355,6 +356,7 @@ class _SHBatchedFn(torch.autograd.Function):
         clamped = torch.empty((C, N, 3), dtype=torch.uint8, device=dev)
         if N > 0:
             with torch.cuda.device(dev):
+                _await_updates(dc, rest)
                 L.call("gspl_sh_fwd_batched", C, N, int(degree), L.ptr(means), L.ptr(origins), L.ptr(dc), dc_stride, rest_ptr, rest_stride,
                        L.ptr(radii), L.GSPL_SH_ADD_HALF_CLAMP, L.ptr(colors), L.ptr(clamped), L.stream())
         ctx.save_for_backward(means, origins, dc, rest, radii, clamped)
@@ -650,6 +652,7 @@ class _side_stream:
     _streams: dict = {}
     _handles: dict = {}
     _low: dict = {}
+    _torch: dict = {}
 
     def __init__(self, dev):
         import os
@@ -678,6 +681,47 @@ class _side_stream:
     def join(self):
         if self.enabled:
             torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+
+def colour_stream(dev):
+    """(raw handle, torch stream) of the stream the fused rasterizer launches its colour (SH) kernel on, next to the binning on the
+    caller's stream: the library's lowest-priority stream when there is one (torch cannot create a stream below the default
+    priority), else the package's side stream; (None, None) with GSPL_SIDE_STREAM=0."""
+    side = _side_stream(dev)
+    if not side.enabled:
+        return None, None
+    hk = (dev.type, dev.index)
+    raw = _side_stream._handles.get(hk)
+    if raw is None:
+        with torch.cuda.device(dev):
+            raw = (L.lib().gspl_low_priority_stream() or 0) if SIDE_LOW_PRIORITY else 0
+        low = bool(raw)
+        if not raw:
+            raw = side.stream.cuda_stream      # (~10 us of Python per look-up: cached)
+        _side_stream._handles[hk] = raw
+        _side_stream._low[hk] = low
+        _side_stream._torch[hk] = torch.cuda.ExternalStream(raw, device=dev) if low else side.stream
+    return raw, _side_stream._torch[hk]
+
+
+# Parameter updates in flight on another stream (optimizers.FusedAdam(deferred=...): the Adam update of the SH coefficients runs on the
+# colour stream, under the next frame's geometry / binning kernels): data_ptr -> (event recorded after the update, raw handle of the
+# stream it was launched on).  Every kernel of this package that reads a parameter which may be deferred — the SH colour kernels —
+# calls `_await_updates` on the stream it launches on; the optimizer retires its entries at its next step.
+PENDING_UPDATES: dict = {}
+
+
+def _await_updates(*tensors, on_raw_stream=None):
+    """Make the current stream wait for the in-flight updates of `tensors` (no-op for updates launched on `on_raw_stream`, which
+    stream order already covers)."""
+    if not PENDING_UPDATES:
+        return
+    for t in tensors:
+        if t is None:
+            continue
+        ent = PENDING_UPDATES.get(t.data_ptr())
+        if ent is not None and ent[1] != on_raw_stream:
+            torch.cuda.current_stream(t.device).wait_event(ent[0])
 
 
 class _PendingBins:
@@ -1081,10 +1125,28 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool = False
 
 
+def _split_sh(sh, sh_rest):
+    """(sh, sh_rest, n_coeffs) of the rasterizer's colour input: `sh` [N, K, 3] alone, or the reference model's two parameters
+    `shs_dc` [N, 1, 3] and `shs_rest` [N, K - 1, 3] (internal/models/vanilla_gaussian.py:266-300), which the kernels then read — and
+    whose gradients they write — in place: `get_shs()`'s per-step `torch.cat` (and its backward's two slice copies) never run."""
+    if sh is None:
+        if sh_rest is not None:
+            raise ValueError("shs_rest without shs")
+        return None, None, 0
+    if sh_rest is None:
+        return sh, None, sh.shape[1]
+    sh_rest = _f32c(sh_rest)
+    if sh.dim() != 3 or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != sh.shape[0] or sh_rest.shape[2] != 3:
+        raise ValueError(f"shs / shs_rest must be [N,1,3] and [N,K-1,3], got {tuple(sh.shape)} and {tuple(sh_rest.shape)}")
+    if sh_rest.shape[1] == 0:
+        return sh, None, 1
+    return sh, sh_rest, 1 + sh_rest.shape[1]
+
+
 class _InriaRasterizeFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest=None):
         lib = L.lib()
         s: GaussianRasterizationSettings = settings
         dev = means3D.device
@@ -1095,7 +1157,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
         opac = _f32c(opacities).reshape(-1)
         viewm, projm, campos = _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos)
         bg = _f32c(s.bg)
-        n_coeffs = sh.shape[1] if sh is not None else 0
+        sh, sh_rest, n_coeffs = _split_sh(sh, sh_rest)
         radii = torch.empty((N,), dtype=torch.int32, device=dev)
         means2d = torch.empty((N, 2), dtype=torch.float32, device=dev)
         depths = torch.empty((N,), dtype=torch.float32, device=dev)
@@ -1109,9 +1171,11 @@ class _InriaRasterizeFn(torch.autograd.Function):
         tile_w, tile_h = (W + tile - 1) // tile, (H + tile - 1) // tile
         def preprocess(phases):
             if N > 0:
+                if phases & L.GSPL_INRIA_COLOURS:
+                    _await_updates(sh, sh_rest)
                 L.call("gspl_inria_preprocess_fwd",
                        N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
-                       L.ptr(sh), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
+                       L.ptr(sh), L.ptr(sh_rest), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
                        float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
                        L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
                        L.ptr(sh_jac) if (phases & L.GSPL_INRIA_COLOURS) else None, phases, L.stream())
@@ -1134,7 +1198,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
             L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat) if n_isects else None,
             L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), None, L.stream())
         ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
-                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac)
+                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac, sh_rest)
         if KEEP_LAST_RASTER:
             global LAST_RASTER
             LAST_RASTER = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=means2d, conics=conics, opacities=opac,
@@ -1151,7 +1215,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
     def backward(ctx, v_out, _v_radii):
         lib = L.lib()
         (means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
-         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac) = ctx.saved_tensors
+         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac, sh_rest) = ctx.saved_tensors
         H, W, tile, tile_w, tile_h, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, opac_shape = ctx.cfg
         N = means3D.shape[0]
         dev = means3D.device
@@ -1175,16 +1239,17 @@ class _InriaRasterizeFn(torch.autograd.Function):
         v_quats = None if use_cov else torch.empty((N, 4), dtype=torch.float32, device=dev)
         v_cov = torch.empty((N, 6), dtype=torch.float32, device=dev) if use_cov else None
         v_sh = None if has_precomp_colors else torch.empty_like(sh)
+        v_sh_rest = None if sh_rest is None else torch.empty_like(sh_rest)
         v_cp = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_precomp_colors else None
         if N > 0:
             L.call("gspl_inria_preprocess_bwd", 
-                N, degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3d), L.ptr(sh),
+                N, degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3d), L.ptr(sh), L.ptr(sh_rest),
                 L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tanfovx, tanfovy, scale_modifier,
                 L.ptr(radii), L.ptr(clamped), L.ptr(packed), L.ptr(packed, offset_bytes=8), L.ptr(packed, offset_bytes=24), RS,
-                L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_cp), L.ptr(v_ndc),
+                L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_sh_rest), L.ptr(v_cp), L.ptr(v_ndc),
                 L.ptr(packed, offset_bytes=20), L.ptr(v_opac), L.ptr(sh_jac), L.stream())
-        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings
-        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
+        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest
 
 
 # ---- the same rasterizer through ONE C-ABI call per direction (gspl_rasterize_inria_fwd/bwd, csrc/fused.hip) -----------------
@@ -1219,7 +1284,7 @@ def _view(buf: Tensor, ptr: int, shape, dtype) -> Tensor:
 class _InriaFusedFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest=None):
         import ctypes
         s: GaussianRasterizationSettings = settings
         dev = means3D.device
@@ -1229,7 +1294,7 @@ class _InriaFusedFn(torch.autograd.Function):
         sh, colors_precomp, scales, rotations, cov3D_precomp = map(_f32c, (sh, colors_precomp, scales, rotations, cov3D_precomp))
         opac = _f32c(opacities).reshape(-1)
         viewm, projm, campos, bg = _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos), _f32c(s.bg)
-        n_coeffs = sh.shape[1] if sh is not None else 0
+        sh, sh_rest, n_coeffs = _split_sh(sh, sh_rest)
         out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((N,), dtype=torch.int32, device=dev)
         tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
@@ -1243,23 +1308,18 @@ class _InriaFusedFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             side_handle = None
             low = False
+            raw = None
             if side.enabled:
-                hk = (dev.type, dev.index)
-                raw = _side_stream._handles.get(hk)
-                if raw is None:
-                    # a stream of the device's LOWEST priority from the library (torch cannot create one below the default):
-                    # the colour kernel yields to the key pass and the depth sort it runs next to
-                    raw = (L.lib().gspl_low_priority_stream() or 0) if SIDE_LOW_PRIORITY else 0
-                    low = bool(raw)
-                    if not raw:
-                        raw = side.stream.cuda_stream      # (~10 us of Python per look-up: cached)
-                    _side_stream._handles[hk] = raw
-                    _side_stream._low[hk] = low
-                low = _side_stream._low.get(hk, False)
+                # a stream of the device's LOWEST priority from the library: the colour kernel yields to the key pass and the depth
+                # sort it runs next to
+                raw, _ = colour_stream(dev)
+                low = _side_stream._low.get((dev.type, dev.index), False)
                 side_handle = ctypes.c_void_p(raw)
+            # coefficient updates still in flight (FusedAdam(deferred=...)): on the colour stream itself stream order covers them
+            _await_updates(sh, sh_rest, on_raw_stream=raw)
             try:
                 L.call("gspl_rasterize_inria_fwd", N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
-                       L.ptr(cov3D_precomp), L.ptr(sh), L.ptr(colors_precomp), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg),
+                       L.ptr(cov3D_precomp), L.ptr(sh), L.ptr(sh_rest), L.ptr(colors_precomp), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg),
                        W, H, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), _ALLOC_CB, None, hint,
                        L.ptr(out), L.ptr(radii), ctypes.byref(state), L.stream(), side_handle)
             except RuntimeError:
@@ -1281,7 +1341,7 @@ class _InriaFusedFn(torch.autograd.Function):
             SPECULATION["misses"] += 1
         holder.pop(L.GSPL_BUF_BINNING, None)           # scratch of the count half and of the tile sort: not needed again
         holder.pop(L.GSPL_BUF_LISTS_WORK, None)
-        ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii)
+        ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest)
         ctx.holder, ctx.state = holder, state
         ctx.cfg = (H, W, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), colors_precomp is not None,
                    cov3D_precomp is not None, opacities.shape)
@@ -1305,7 +1365,7 @@ class _InriaFusedFn(torch.autograd.Function):
     @_guarded(0)
     def backward(ctx, v_out, _v_radii):
         import ctypes
-        means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii = ctx.saved_tensors
+        means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest = ctx.saved_tensors
         H, W, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, use_cov, opac_shape = ctx.cfg
         N = means3D.shape[0]
         dev = means3D.device
@@ -1318,20 +1378,21 @@ class _InriaFusedFn(torch.autograd.Function):
         v_quats = None if use_cov else E(N, 4)
         v_cov = E(N, 6) if use_cov else None
         v_sh = None if has_precomp_colors else torch.empty_like(sh)
+        v_sh_rest = None if sh_rest is None else torch.empty_like(sh_rest)
         v_cp = E(N, 3) if has_precomp_colors else None
         if N > 0:
             with torch.cuda.device(dev):
-                L.call("gspl_rasterize_inria_bwd", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh), L.ptr(opac),
-                       L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
-                       ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_cp),
-                       L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
+                L.call("gspl_rasterize_inria_bwd", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh), L.ptr(sh_rest),
+                       L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
+                       ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_sh_rest),
+                       L.ptr(v_cp), L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
             if hit is not None and ctx.means2D_ref is not None:
                 ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
         else:
             for t in (v_means, v_ndc, v_opac):
                 t.zero_()
         ctx.holder = None
-        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -1344,7 +1405,10 @@ class GaussianRasterizer(torch.nn.Module):
         self.raster_settings = raster_settings
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, shs_rest=None):
+        """`shs_rest` (extension; also accepted as `shs=(shs_dc, shs_rest)`): the model's two SH parameters as they are stored."""
+        if isinstance(shs, (tuple, list)):
+            shs, shs_rest = shs
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -1352,7 +1416,9 @@ class GaussianRasterizer(torch.nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         # one C-ABI call per direction (csrc/fused.hip) unless GSPL_FUSED_INRIA=0 selects the stage-by-stage orchestration
         fn = _InriaFusedFn if FUSED_INRIA else _InriaRasterizeFn
-        return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings)
+        if shs_rest is not None and shs_rest.shape[1] == 0:
+            shs_rest = None
+        return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings, shs_rest)
 
 
 # =============================================================================================

@@ -17,13 +17,29 @@ import torch
 from . import _lib as L
 
 
+# Workgroups (of 256 threads) per tensor of a deferred update: it shares the device with the next frame's geometry and binning kernels,
+# and a grid that fills every wave slot of every CU keeps those kernels waiting for slots.
+DEFERRED_BLOCKS = int(__import__("os").environ.get("GSPL_ADAM_DEFERRED_BLOCKS", "512"))
+
+
 class _FusedAdamBase(torch.optim.Optimizer):
     _bias_correction = True
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 amsgrad: bool = False, maximize: bool = False, **unsupported):
+                 amsgrad: bool = False, maximize: bool = False, deferred=None, **unsupported):
         """The keyword arguments of `torch.optim.Adam` are accepted so that configurations written for it construct this
-        class; the ones the kernel does not implement must keep their default values."""
+        class; the ones the kernel does not implement must keep their default values.
+
+        deferred (extension, off by default): parameter-group names (the reference names its groups: "shs_rest", ...,
+        vanilla_gaussian.py:266-300) and / or parameter tensors whose update is launched on the rasterizer's COLOUR stream
+        (`ops.colour_stream`) instead of the caller's.  Meant for the SH coefficients: 45 of the 59 floats of a Gaussian, i.e. three
+        quarters of the step's memory traffic, and the one parameter the next frame needs LAST — geometry and binning (a dozen small
+        latency-bound launches that leave HBM idle) run on the caller's stream at the same time, and the colour kernel of the next
+        frame follows the update in stream order.  Same kernel, same inputs: bit-identical parameters.  The contract that comes
+        with it: (1) the optimizer takes the gradients of the deferred parameters (`p.grad` is None after `step()`), (2) kernels of
+        this package that read a deferred parameter wait for its update by themselves (`ops._await_updates`); anything else that reads
+        one between `step()` and the next render — a checkpoint written right after the step, foreign torch code — calls `join()`
+        first (`state_dict()` and the next `step()` do)."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         if weight_decay != 0.0 or amsgrad or maximize:
@@ -34,6 +50,9 @@ class _FusedAdamBase(torch.optim.Optimizer):
             if k in ("capturable", "differentiable") and v:
                 raise NotImplementedError(f"fused Adam: {k}=True is not implemented")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._deferred_names = {d for d in (deferred or ()) if isinstance(d, str)}
+        self._deferred_ids = {id(d) for d in (deferred or ()) if isinstance(d, torch.Tensor)}
+        self._inflight = []      # [(event, tensors kept alive for the launch, data_ptrs registered in ops.PENDING_UPDATES)]
 
     def _prepare(self, p, group):
         """State of one parameter with its step counter advanced (once per optimizer step)."""
@@ -50,7 +69,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
         st["step"] = int(st["step"]) + 1
         return st
 
-    def _run(self, batches, visibility: Optional[torch.Tensor]):
+    def _run(self, batches, visibility: Optional[torch.Tensor], max_blocks: int = 0):
         """batches: {(device, rows, b1, b2, eps, step): [(param, grad, exp_avg, exp_avg_sq, lr, row_elems), ...]} -> launches."""
         for (dev, N, b1, b2, eps, step), items in batches.items():
             vis = None
@@ -68,15 +87,17 @@ class _FusedAdamBase(torch.optim.Optimizer):
                         raise RuntimeError("fused Adam: exp_avg / exp_avg_sq must be contiguous fp32 tensors of the parameter's shape")
                     table[k] = L.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr, row)
                 with torch.cuda.device(dev):
-                    L.call("gspl_selective_adam", len(chunk), ctypes.cast(table, ctypes.c_void_p), N, L.ptr(vis),
-                           float(b1), float(b2), float(eps), float(bc1), float(bc2s), L.stream())
+                    L.call("gspl_selective_adam_limited", len(chunk), ctypes.cast(table, ctypes.c_void_p), N, L.ptr(vis),
+                           float(b1), float(b2), float(eps), float(bc1), float(bc2s), int(max_blocks), L.stream())
 
     def _launch(self, visibility: Optional[torch.Tensor]):
         L.lib()
+        self.join()
         # tensors are batched per (N, betas, eps, step count): the reference has one parameter per group, all [N, ...]
-        batches = {}
+        batches, later = {}, {}
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            defer_group = group.get("name") in self._deferred_names
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -85,8 +106,58 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 N = p.shape[0] if p.dim() > 0 else 1
                 row = p.numel() // max(N, 1)
                 key = (p.device, N, b1, b2, group["eps"], st["step"] if self._bias_correction else 0)
-                batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), row))
+                dst = later if (defer_group or id(p) in self._deferred_ids) else batches
+                dst.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), row))
         self._run(batches, visibility)
+        if later:
+            self._run_deferred(later, visibility)
+
+    def _run_deferred(self, later, visibility):
+        """The update of the deferred parameters on the colour stream of their device (see `__init__`)."""
+        from . import ops
+        by_dev = {}
+        for key, items in later.items():
+            by_dev.setdefault(key[0], {})[key] = items
+        for dev, dev_batches in by_dev.items():
+            raw, side = ops.colour_stream(dev)
+            if side is None:                                   # GSPL_SIDE_STREAM=0: everything on the caller's stream
+                self._run(dev_batches, visibility)
+                continue
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)                              # the gradients (and everything else enqueued so far) are ready
+            with torch.cuda.stream(side):
+                self._run(dev_batches, visibility, max_blocks=DEFERRED_BLOCKS)
+                done = torch.cuda.Event()
+                done.record(side)
+            keep, ptrs = [visibility], []
+            for items in dev_batches.values():
+                for (p, g, m, v, _lr, _row) in items:
+                    keep.append(g)                             # alive until the caller's stream has waited for the update: the
+                    p.grad = None                              # allocator must not hand the block to later work on that stream
+                    ops.PENDING_UPDATES[p.data_ptr()] = (done, raw)
+                    ptrs.append(p.data_ptr())
+            self._inflight.append((done, keep, ptrs, dev))
+
+    def join(self):
+        """Make the current stream wait for the deferred updates in flight (no host synchronisation) and retire them."""
+        if not self._inflight:
+            return
+        from . import ops
+        for done, _keep, ptrs, dev in self._inflight:
+            torch.cuda.current_stream(dev).wait_event(done)
+            for ptr in ptrs:
+                if ops.PENDING_UPDATES.get(ptr, (None,))[0] is done:
+                    del ops.PENDING_UPDATES[ptr]
+        self._inflight = []
+
+    def state_dict(self):
+        self.join()
+        return super().state_dict()
+
+    def zero_grad(self, set_to_none: bool = True):
+        if not set_to_none:
+            self.join()
+        return super().zero_grad(set_to_none=set_to_none)
 
     # ---- the same update in ROW CHUNKS (multi-GPU: a chunk is updated as soon as the all-reduce of its gradient rows has
     #      finished, while the collectives of the following chunks are still on the wire; distributed.all_reduce_and_step) ----
@@ -94,6 +165,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
     def begin_chunked_step(self):
         """Advances the step counters of every parameter that has a gradient; returns {parameter: (group, state)}."""
         L.lib()
+        self.join()
         ready = {}
         for group in self.param_groups:
             for p in group["params"]:
@@ -121,8 +193,8 @@ class SelectiveAdam(_FusedAdamBase):
     """`SelectiveAdam(params, eps, betas).step(visibility)`: gsplat's visibility-masked Adam (no bias correction)."""
     _bias_correction = False
 
-    def __init__(self, params, eps: float = 1e-8, betas=(0.9, 0.999), lr: float = 1e-3):
-        super().__init__(params, lr=lr, betas=betas, eps=eps)
+    def __init__(self, params, eps: float = 1e-8, betas=(0.9, 0.999), lr: float = 1e-3, deferred=None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, deferred=deferred)
 
     @torch.no_grad()
     def step(self, visibility: torch.Tensor):
@@ -157,9 +229,14 @@ from typing import Tuple  # noqa: E402
 
 @dataclass
 class HipFusedAdam(_OptimizerConfig):
-    """Drop-in for `internal.optimizers.Adam` (internal/optimizers.py:14-22): same update, one launch per step."""
+    """Drop-in for `internal.optimizers.Adam` (internal/optimizers.py:14-22): same update, one launch per step.
+    `overlap_sh_update`: run the update of the "shs_rest" group under the next frame's geometry / binning (`FusedAdam(deferred=...)`,
+    read its contract first); off by default."""
+    overlap_sh_update: bool = False
 
     def instantiate(self, params, lr: float, *args, **kwargs):
+        if self.overlap_sh_update:
+            kwargs.setdefault("deferred", ("shs_rest",))
         return FusedAdam(params, lr, *args, **kwargs)
 
 

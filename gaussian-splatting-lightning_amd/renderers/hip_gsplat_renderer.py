@@ -16,7 +16,7 @@ from typing import Dict, Tuple
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, viewspace_grad_scale, implementation_tile_size
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, viewspace_grad_scale, implementation_tile_size, model_sh_pair
 
 DEFAULT_BLOCK_SIZE: int = 16
 DEFAULT_ANTI_ALIASED_STATUS: bool = True
@@ -123,7 +123,7 @@ class HipGSplatRenderer(Renderer):
         visible = radii > 0
         rgb = None
         if self.is_type_required(bits, self._RGB_REQUIRED):
-            rgbs = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center, pc.get_features, None,
+            rgbs = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center, *model_sh_pair(pc),
                                       visible, detach_means=True)
             # [3,H,W] straight from the kernel: the reference permutes an [H,W,3] image, which costs the loss a 25 MB copy in
             # the forward and another one for the incoming gradient in the backward

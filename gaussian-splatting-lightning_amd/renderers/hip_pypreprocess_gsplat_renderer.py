@@ -13,7 +13,7 @@ import torch
 
 from .. import ops
 from .hip_gsplat_renderer import DEFAULT_ANTI_ALIASED_STATUS, DEFAULT_BLOCK_SIZE, _project
-from .renderer import Renderer, camera_hw, implementation_tile_size
+from .renderer import Renderer, camera_hw, implementation_tile_size, model_sh_pair
 
 
 class HipPythonPreprocessGSplatRenderer(Renderer):
@@ -31,7 +31,7 @@ class HipPythonPreprocessGSplatRenderer(Renderer):
         # the culled rows of the projection carry radius 0 and zero tiles: the mask the reference returns next to them
         mask = radii > 0
         # view directions, SH, +0.5 and the clamp in one kernel (pypreprocess_gsplat_renderer.py:37-40)
-        rgbs = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center, pc.get_features, None, mask)
+        rgbs = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center, *model_sh_pair(pc), mask)
         opacities = pc.get_opacity
         if self.anti_aliased is True:
             opacities = opacities * comp[:, None]

@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars, model_sh_pair
 
 
 def _tan_half(fov):
@@ -66,20 +66,23 @@ class HipVanillaRenderer(Renderer):
         else:
             scales, rotations = pc.get_scaling, pc.get_rotation
 
-        shs = colors_precomp = None
+        shs = shs_rest = colors_precomp = None
         if override_color is None:
+            # shs_dc / shs_rest where the model stores them (the reference passes `pc.get_features`, a torch.cat per step,
+            # vanilla_renderer.py:99-109): same coefficients, same gradients, no copy in either direction
+            dc, rest = model_sh_pair(pc)
             if self.convert_SHs_python:
                 # the "python" colour path of the reference, served by the fused HIP SH kernel
                 colors_precomp = ops.sh_view_colors(pc.active_sh_degree, pc.get_xyz, viewpoint_camera.camera_center,
-                                                    pc.get_features, None, detach_means=False)
+                                                    dc, rest, detach_means=False)
             else:
-                shs = pc.get_features
+                shs, shs_rest = dc, rest
         else:
             colors_precomp = override_color
 
         rendered_image, radii = rasterizer(
             means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
-            opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+            opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, shs_rest=shs_rest)
         return {
             rendered_image_key: rendered_image,
             "viewspace_points": screenspace_points,

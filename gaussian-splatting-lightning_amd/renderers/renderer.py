@@ -132,6 +132,18 @@ def viewspace_grad_scale(W: int, H: int, like: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def model_sh_pair(pc):
+    """(shs_dc, shs_rest) — the model's two SH parameters as they are stored (internal/models/gaussian.py:218-254) — when the model
+    has them, else (`get_features`, None): a pre-activated model keeps one "shs" tensor (vanilla_gaussian.py:370-390).  The kernels
+    read either form in place; `get_features` on a two-parameter model is a `torch.cat` of 192 B per Gaussian every step."""
+    if not getattr(pc, "is_pre_activated", False) and hasattr(pc, "get_shs_dc") and hasattr(pc, "get_shs_rest"):
+        try:
+            return pc.get_shs_dc(), pc.get_shs_rest()
+        except KeyError:
+            pass
+    return pc.get_features, None
+
+
 _TILE_NOTE = set()
 
 

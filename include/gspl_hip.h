@@ -327,7 +327,10 @@ enum { GSPL_INRIA_GEOMETRY = 1, GSPL_INRIA_COLOURS = 2, GSPL_INRIA_ALL = 3 };
 int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                               const float* means, const float* scales /*nullable*/,
                               const float* quats /*nullable*/, const float* cov3d_precomp /*nullable*/,
-                              const float* shs /*[N,n_coeffs,3] nullable*/,
+                              const float* shs /*[N,n_coeffs,3] nullable; with shs_rest: the DC rows [N,1,3]*/,
+                              const float* shs_rest /*nullable [N,n_coeffs-1,3]: the reference's model keeps the coefficients as two
+                                                      parameters, shs_dc and shs_rest (vanilla_gaussian.py:266-300, `get_shs` = a
+                                                      torch.cat per step); given both, they are read where they are*/,
                               const float* colors_precomp /*nullable*/,
                               const float* viewmatrix, const float* projmatrix, const float* campos,
                               int width, int height, int tile_size,
@@ -346,7 +349,7 @@ int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
 int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               const float* means, const float* scales /*nullable*/,
                               const float* quats /*nullable*/, const float* cov3d /*[N,6] from fwd*/,
-                              const float* shs /*nullable*/,
+                              const float* shs /*nullable*/, const float* shs_rest /*nullable, as in the forward*/,
                               const float* viewmatrix, const float* projmatrix, const float* campos,
                               int width, int height,
                               float tanfovx, float tanfovy, float scale_modifier,
@@ -355,6 +358,7 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                               int grad_stride /* 0: dense [N,2],[N,3],[N,3]; k: columns of one packed [N,k] buffer */,
                               float* v_means, float* v_scales /*nullable*/, float* v_quats /*nullable*/,
                               float* v_cov3d_precomp /*nullable*/, float* v_shs /*nullable*/,
+                              float* v_shs_rest /*nullable; given iff shs_rest is: v_shs is then [N,1,3], this one [N,n_coeffs-1,3]*/,
                               float* v_colors_precomp /*nullable*/, float* v_means2d_ndc,
                               const float* v_opacities_packed /*nullable: the opacity column of the packed buffer */,
                               float* v_opacities /*nullable: [N], receives that column densely (the optimizer's
@@ -388,7 +392,8 @@ size_t gspl_rasterize_inria_geometry_bytes(int N);
 size_t gspl_rasterize_inria_image_bytes(int width, int height);
 int gspl_rasterize_inria_fwd(int N, int degree, int n_coeffs,
                              const float* means3D, const float* scales /*nullable*/, const float* rotations /*nullable*/,
-                             const float* cov3D_precomp /*nullable*/, const float* shs /*nullable*/, const float* colors_precomp /*nullable*/,
+                             const float* cov3D_precomp /*nullable*/, const float* shs /*nullable*/,
+                             const float* shs_rest /*nullable: see gspl_inria_preprocess_fwd*/, const float* colors_precomp /*nullable*/,
                              const float* opacities,
                              const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
                              int width, int height, float tanfovx, float tanfovy, float scale_modifier,
@@ -396,14 +401,15 @@ int gspl_rasterize_inria_fwd(int N, int degree, int n_coeffs,
                              float* out_color, int32_t* radii, gspl_inria_state* state,
                              void* stream, void* side_stream /*nullable: colours on `stream`*/);
 /*    Backward: packed [N,9] f32 scratch and hit_flags [N] u8 (nullable) are cleared inside; every v_* is caller-allocated
- *    ([N,3], [N,3] NDC-scaled, [N,n_coeffs,3] | [N,3], [N], [N,3], [N,4] | [N,6]; the ones that do not apply are NULL). */
+ *    ([N,3], [N,3] NDC-scaled, [N,n_coeffs,3] (or [N,1,3] and [N,n_coeffs-1,3] with shs_rest) | [N,3], [N], [N,3], [N,4] | [N,6]; the ones that do not apply are NULL). */
 int gspl_rasterize_inria_bwd(int degree, int n_coeffs,
-                             const float* means3D, const float* scales, const float* rotations, const float* shs, const float* opacities,
+                             const float* means3D, const float* scales, const float* rotations, const float* shs, const float* shs_rest,
+                             const float* opacities,
                              const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
                              float tanfovx, float tanfovy, float scale_modifier,
                              const int32_t* radii, const gspl_inria_state* state, const float* v_out_color,
                              float* packed, uint8_t* hit_flags /*nullable*/,
-                             float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_colors_precomp, float* v_opacities,
+                             float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_shs_rest, float* v_colors_precomp, float* v_opacities,
                              float* v_scales, float* v_rotations, float* v_cov3D, void* stream);
 
 /* A per-device stream of the LOWEST priority the device offers, created on first use and kept: a `side_stream` for
@@ -510,6 +516,11 @@ int gspl_selective_adam(int n_tensors, const gspl_adam_tensor* tensors /* host a
                         const uint8_t* visible /*nullable, device [N]*/,
                         float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
                         void* stream);
+/* The same update with at most `max_blocks` workgroups per tensor (0 = no limit): for a launch that shares the device with the
+ * kernels of another stream (optimizers.FusedAdam(deferred=...): the shs_rest update next to the following frame's binning). */
+int gspl_selective_adam_limited(int n_tensors, const gspl_adam_tensor* tensors, int N, const uint8_t* visible /*nullable*/,
+                                float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
+                                int max_blocks, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 10. Stable LSD radix sort of the binning stage, exported for the parity tests.

@@ -122,3 +122,100 @@ def test_fused_adam_resumes_a_torch_adam_state_and_accepts_its_kwargs():
         gopt.FusedAdam([my_p], lr=1e-3, amsgrad=True)
     with pytest.raises(TypeError):
         gopt.FusedAdam([my_p], lr=1e-3, nonsense=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fused", "selective"])
+def test_deferred_update_is_bit_identical_and_keeps_its_gradient_alive(kind):
+    """`FusedAdam(deferred=("shs_rest",))`: the update of that group runs on the rasterizer's colour stream with a bounded grid.
+    Same kernel, same inputs: after several steps on given gradients every parameter and moment equals the all-on-one-stream run
+    bit for bit — also when the caller's stream allocates and overwrites memory right after `step()` (the optimizer has taken the
+    gradient of the deferred parameter and keeps it alive until the caller's stream has waited for the update)."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import ops
+    from gspl_amd.optimizers import FusedAdam, SelectiveAdam
+    n = 300001
+    names = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+    lrs = [1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3, 1.25e-4]
+
+    def run(deferred):
+        params = _model(n, 1, "cuda")
+        cls = FusedAdam if kind == "fused" else SelectiveAdam
+        opt = cls([{"params": [p], "lr": lr, "name": nm} for p, lr, nm in zip(params, lrs, names)], eps=1e-15,
+                  deferred=("shs_rest",) if deferred else None)
+        g = torch.Generator().manual_seed(5)
+        for it in range(5):
+            vis = (torch.rand(n, generator=g) < 0.7).cuda()
+            for a in params:
+                a.grad = (torch.randn(a.shape, generator=g) * (0.1 if it % 2 else 1.0)).cuda()
+            opt.step() if kind == "fused" else opt.step(vis)
+            if deferred:
+                assert params[5].grad is None and params[5].data_ptr() in ops.PENDING_UPDATES
+                # the caller's stream goes on allocating and writing: blocks of the size of the gradient the update is still reading
+                junk = [torch.full_like(params[5], float("nan")) for _ in range(3)]
+                del junk
+            for a in params:
+                a.grad = None
+        sd = opt.state_dict()                      # joins
+        assert not ops.PENDING_UPDATES and not opt._inflight
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in params], [opt.state[p][k].clone() for p in params for k in ("exp_avg", "exp_avg_sq")]
+
+    base_p, base_m = run(False)
+    got_p, got_m = run(True)
+    for a, b in zip(base_p + base_m, got_p + got_m):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("consumer", ["fused", "staged", "sh_view_colors", "sh_view_colors_batched"])
+def test_readers_of_a_deferred_parameter_see_the_finished_update(consumer):
+    """The kernels of the package that read shs_rest — the fused Inria call (colour kernel on the colour stream itself: stream
+    order), the staged rasterizer, `sh_view_colors` and its batched form (they wait for the update's event) — launched RIGHT AFTER a
+    `step()` whose shs_rest update is still running on the colour stream, give the very image / colours (the forward pass is
+    deterministic) that they give once the device has been synchronised."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import ops, synthetic
+    from gspl_amd.optimizers import FusedAdam
+    from oracle import gsplat_oracle as O
+    dev = torch.device("cuda:0")
+    W, H, n = 320, 208, 400000
+    means, scales, quats, opac, shs = O.synthetic_scene(n, seed=3)
+    cam = synthetic.camera_set(W, H, 300.0, count=2)[1]
+    params = [t.clone().contiguous().to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs[:, :1], shs[:, 1:])]
+    m, s, q, o, dc, rest = params
+    names = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+    opt = FusedAdam([{"params": [p], "lr": 1e-2, "name": nm} for p, nm in zip(params, names)], eps=1e-15, deferred=("shs_rest",))
+    settings = ops.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+        viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=3, campos=cam["camera_center"].to(dev))
+    center = cam["camera_center"].to(dev)
+
+    def read():
+        with torch.no_grad():
+            if consumer == "sh_view_colors":
+                return ops.sh_view_colors(3, m, center, dc, rest, None)
+            if consumer == "sh_view_colors_batched":
+                return ops.sh_view_colors_batched(3, m, torch.stack([center, center + 0.1]), dc, rest, None)
+            return ops.GaussianRasterizer(settings)(means3D=m, means2D=torch.empty_like(m), opacities=o, shs=dc, shs_rest=rest, scales=s, rotations=q)[0]
+
+    fused = ops.FUSED_INRIA
+    ops.FUSED_INRIA = consumer != "staged"
+    try:
+        g = torch.Generator().manual_seed(2)
+        before = read()
+        for it in range(4):
+            for p in params:
+                p.grad = torch.randn(p.shape, generator=g).to(dev)
+            torch.cuda.synchronize()
+            opt.step()
+            first = read()                         # the update of shs_rest is in flight on the colour stream
+            torch.cuda.synchronize()
+            assert rest.data_ptr() in ops.PENDING_UPDATES
+            settled = read()
+            assert torch.equal(first, settled), f"step {it}: a reader saw shs_rest before its update had finished"
+            assert not torch.equal(settled, before)
+            before = settled
+    finally:
+        ops.FUSED_INRIA = fused
+        opt.join()

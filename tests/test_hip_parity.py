@@ -733,6 +733,47 @@ def test_inria_api_precomputed_cov3d_and_colors_and_scale_modifier(hip):
                                                                     scales=s3, rotations=q3)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_inria_rasterizer_reads_shs_dc_and_shs_rest_in_place(hip, fused):
+    """`GaussianRasterizer(shs=shs_dc, shs_rest=shs_rest)` — the model's two SH parameters as stored (gaussian.py:218-254) — against
+    `shs=torch.cat((shs_dc, shs_rest), 1)` (what the reference passes, vanilla_renderer.py:99-109): same image bit for bit, the
+    coefficient gradients equal to the slices of the merged gradient (the SH backward has no atomics: bit for bit as well),
+    for a partial active degree too."""
+    means, scales, quats, opac, shs, cam, wimg, bg = _e2e_scene(n=6000)
+    W, H = cam["width"], cam["height"]
+    old = hip.FUSED_INRIA
+    hip.FUSED_INRIA = fused
+    try:
+        for deg in (3, 1, 0):
+            settings = hip.GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg.to(_dev()), scale_modifier=1.0,
+                viewmatrix=cam["world_to_camera"].to(_dev()), projmatrix=cam["full_projection"].to(_dev()), sh_degree=deg,
+                campos=cam["camera_center"].to(_dev()))
+            rast = hip.GaussianRasterizer(settings)
+            m, s, q, o = [t.requires_grad_(True) for t in _cuda(means, scales, quats, opac)]
+            merged = shs.float().to(_dev()).requires_grad_(True)
+            img0, r0 = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, shs=merged, scales=s, rotations=q)
+            (img0 * wimg.to(_dev())).sum().backward()
+            g_means0 = m.grad.clone()
+            m.grad = None
+            dc = shs[:, :1].float().contiguous().to(_dev()).requires_grad_(True)
+            rest = shs[:, 1:].float().contiguous().to(_dev()).requires_grad_(True)
+            img1, r1 = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, shs=dc, shs_rest=rest, scales=s, rotations=q)
+            assert torch.equal(img0, img1) and torch.equal(r0, r1)
+            (img1 * wimg.to(_dev())).sum().backward()
+            # the per-splat colour gradient the SH backward consumes comes out of float atomics (run-to-run order): compare scaled
+            assert_close_scaled(dc.grad.cpu().numpy(), merged.grad[:, :1].cpu().numpy(), 1e-5, f"v_shs_dc deg={deg}")
+            assert_close_scaled(rest.grad.cpu().numpy(), merged.grad[:, 1:].cpu().numpy(), 1e-5, f"v_shs_rest deg={deg}")
+            assert_close_scaled(m.grad.cpu().numpy(), g_means0.cpu().numpy(), 1e-5, f"v_means deg={deg}")
+            n_active = (deg + 1) ** 2
+            assert float(rest.grad[:, n_active - 1:].abs().max()) == 0.0 if n_active < 16 else True
+            # tuple form
+            img2, _ = rast(means3D=m, means2D=torch.zeros_like(m), opacities=o, shs=(dc, rest), scales=s, rotations=q)
+            assert torch.equal(img2, img0)
+    finally:
+        hip.FUSED_INRIA = old
+
+
 def test_fused_inria_device_side_list_length_and_guesses(hip):
     """The fused Inria call (gspl_rasterize_inria_fwd) launches emission, sort and compositing BEFORE the host has the list length:
     the sort reads it on the device, sized by a guess from the last frame.  Frames whose guess is far too low (the frame is

@@ -180,8 +180,11 @@ def test_reference_consumer_code_drives_the_plugin_and_matches_the_restatement_c
         def __init__(self, raster_settings):
             self.s = raster_settings
 
-        def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                     shs_rest=None):
             s = self.s
+            if shs_rest is not None:      # the plugin hands over the model's two SH parameters as they are stored
+                shs = torch.cat((shs, shs_rest), dim=1)
             r = O.render_inria(means3D, scales, rotations, opacities, shs, s.sh_degree, s.viewmatrix, s.projmatrix, s.campos,
                                s.tanfovx, s.tanfovy, s.image_width, s.image_height, s.bg)
             sc = torch.tensor([0.5 * s.image_width, 0.5 * s.image_height])
