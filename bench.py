@@ -560,6 +560,8 @@ def main():
     spans = sorted(starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1))
     pct = (lambda q: round(spans[min(len(spans) - 1, int(q * len(spans)))], 4)) if spans else (lambda q: None)
     step_ms = {"p50": pct(0.50), "p90": pct(0.90), "p99": pct(0.99), "max": round(spans[-1], 4) if spans else None}
+    raw_spans = [starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1)]
+    step_ms["slowest"] = [[i, round(v, 3)] for v, i in sorted(((v, i) for i, v in enumerate(raw_spans)), reverse=True)[:3]]
     renderer_only = None
     if world == 1 and optimizer is not None and not args.no_renderer_only:
         # second timed region of the same run: the step without a parameter update (round 1's `value`)
@@ -683,7 +685,7 @@ def main():
                 "composite_fwd": entry(per_step(al, ("gspl_composite_fwd",)), 40.0 * I + 20.0 * P, "40 I + 20 P"),
                 "composite_bwd": entry(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * I + 20.0 * P, "76 I + 20 P"),
                 "inria_preprocess_bwd_with_sh_bwd": entry(per_step(al, ("gspl_inria_preprocess_bwd",)), (116.0 + 24.0 * K) * V, "(36 + 40 + 40) V + 2 * 12 K V"),
-                "loss_fwd_bwd": entry(per_step(al, ("gspl_loss_l1_ssim_fwd", "gspl_loss_l1_ssim_bwd")), 4.0 * 3 * P * (2 + 3 + 4), "3 P floats: 2 read fwd, 3 maps written, 3 read + 1 written bwd"),
+                "loss_fwd_bwd": entry(per_step(al, ("gspl_loss_l1_ssim_fwd", "gspl_loss_photometric_fwd", "gspl_loss_l1_ssim_bwd")), 4.0 * 3 * P * (2 + 3 + 4), "3 P floats: 2 read fwd, 3 maps written, 3 read + 1 written bwd"),
                 "adam": entry(per_step(al, ("gspl_selective_adam", "gspl_selective_adam_limited")), 28.0 * 59.0 * N_, "28 B x 59 floats x N (param, grad, two moments read; param, two moments written)"),
                 "densify_stats": entry(per_step(al, ("gspl_densify_stats",)), 29.0 * N_, "grad 12 + radii 4 + three buffers 12 read, up to 12 written, + mask 1"),
             }

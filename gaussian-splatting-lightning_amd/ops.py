@@ -1254,7 +1254,12 @@ class _InriaRasterizeFn(torch.autograd.Function):
 
 # ---- the same rasterizer through ONE C-ABI call per direction (gspl_rasterize_inria_fwd/bwd, csrc/fused.hip) -----------------
 FUSED_INRIA = os.environ.get("GSPL_FUSED_INRIA", "1") != "0"
-SIDE_LOW_PRIORITY = os.environ.get("GSPL_SIDE_LOW_PRIORITY", "1") != "0"
+# The colour stream at the device's lowest priority (a stream from the library; torch cannot create one below the default) or at the
+# default priority (the package's torch side stream).  Round 3, 16 rotating cameras, two runs each on one box: no difference for the
+# colour kernel alone (1.280 / 1.280 vs 1.292 / 1.273 ms per step), and with the deferred shs_rest update on the same stream the
+# default priority is the faster one (1.251 / 1.257 vs 1.266 / 1.264) — and the only two runs with 6-9 ms stalls of single steps had
+# the low-priority stream carrying the update.  Default: the default priority.
+SIDE_LOW_PRIORITY = os.environ.get("GSPL_SIDE_LOW_PRIORITY", "0") != "0"
 _ALLOC_TLS = __import__("threading").local()
 
 

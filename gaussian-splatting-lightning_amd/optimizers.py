@@ -17,9 +17,10 @@ import torch
 from . import _lib as L
 
 
-# Workgroups (of 256 threads) per tensor of a deferred update: it shares the device with the next frame's geometry and binning kernels,
-# and a grid that fills every wave slot of every CU keeps those kernels waiting for slots.
-DEFERRED_BLOCKS = int(__import__("os").environ.get("GSPL_ADAM_DEFERRED_BLOCKS", "512"))
+# Workgroups (of 256 threads) per tensor of a deferred update, 0 = no limit.  The update shares the device with the next frame's
+# geometry and binning kernels; a bounded grid leaves them wave slots on every CU.  Measured (round 3, S-1080p-1M, colour stream at the
+# default priority): 512 / 1024 / 2048 / unlimited -> 1.251 / 1.264 / 1.255 / 1.250 ms per step: no gain from the limit, default off.
+DEFERRED_BLOCKS = int(__import__("os").environ.get("GSPL_ADAM_DEFERRED_BLOCKS", "0"))
 
 
 class _FusedAdamBase(torch.optim.Optimizer):
