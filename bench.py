@@ -511,14 +511,19 @@ def main():
     PROFILE_PERIOD = 1 if args.stage_times else 4
 
     def timed_region(full_step, steps, warmup):
-        for _ in range(warmup):
-            full_step(force_reduce=True)
         # Host hygiene: a full (generation-2) pass of Python's cyclic GC walks every object torch has imported — 30-40 ms during
-        # which no kernel is launched, once every ~130 steps.  Freezing what exists after warm-up keeps later collections to
-        # the objects of the steps themselves.
+        # which no kernel is launched, once every ~130 steps.  Freezing what exists once the first warm-up steps have created their
+        # lazily-built objects keeps later collections to the objects of the steps themselves.  The collection sits INSIDE the
+        # warm-up (before its last steps), not between warm-up and timed region: tens of milliseconds of idle device right before the
+        # timed steps is what a training loop never has.
         import gc
+        early = min(warmup, 2) if os.environ.get("GSPL_BENCH_GC_LATE") is None else warmup
+        for _ in range(early):
+            full_step(force_reduce=True)
         gc.collect()
         gc.freeze()
+        for _ in range(warmup - early):
+            full_step(force_reduce=True)
         if dist is not None:
             dist.barrier()
             # RCCL writes its version banner through C stdio, which on a pipe would come out at exit, AFTER the JSON line:
@@ -548,6 +553,9 @@ def main():
         return elapsed, prof, marks
 
     GROUP_NAMES = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+    if os.environ.get("GSPL_BENCH_RESERVE_GB"):
+        _r = torch.empty(int(float(os.environ["GSPL_BENCH_RESERVE_GB"]) * (1 << 30)), dtype=torch.uint8, device=dev)
+        del _r
     groups = [{"params": [t], "lr": lr * 1e-3, "name": n} for t, lr, n in zip(tensors, lrs, GROUP_NAMES)]
     optimizer = make_optimizer(args.optimizer, groups)
     ops.KEEP_LAST_RASTER = True
@@ -562,6 +570,8 @@ def main():
     step_ms = {"p50": pct(0.50), "p90": pct(0.90), "p99": pct(0.99), "max": round(spans[-1], 4) if spans else None}
     raw_spans = [starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1)]
     step_ms["slowest"] = [[i, round(v, 3)] for v, i in sorted(((v, i) for i, v in enumerate(raw_spans)), reverse=True)[:3]]
+    if os.environ.get("GSPL_BENCH_DUMP_STEPS"):
+        print("step spans (ms):", " ".join(f"{v:.3f}" for v in raw_spans), file=sys.stderr)
     renderer_only = None
     if world == 1 and optimizer is not None and not args.no_renderer_only:
         # second timed region of the same run: the step without a parameter update (round 1's `value`)
