@@ -91,9 +91,9 @@ CONTROLLER_KW = dict(percent_dense=0.01, densification_interval=40, opacity_rese
 EXTENT = 4.4
 
 
-def _restated_setup(init, dev, absgrad=False, **override):
+def _restated_setup(init, dev, absgrad=False, optimizer=None, **override):
     model = T.TrainableGaussians(init["means"].to(dev), init["scales"].to(dev), init["quats"].to(dev), init["opac"].to(dev), init["shs"].to(dev))
-    opts = model.make_optimizers(EXTENT)
+    opts = model.make_optimizers(EXTENT) if optimizer is None else model.make_optimizers(EXTENT, **optimizer)
     ctrl = T.DensityControllerOracle(model.n_gaussians, dev, EXTENT, absgrad=absgrad, **{**CONTROLLER_KW, **override})
     return model, opts, ctrl
 
@@ -123,13 +123,13 @@ class _cpu_normal:
         torch.normal = self.orig
 
 
-def _run_restated(render, dev, steps, absgrad=False, camera_cls=None):
+def _run_restated(render, dev, steps, absgrad=False, camera_cls=None, optimizer=None):
     from fakes import FakeCamera
     cams = _cameras()
     gt, init = _gt_and_init()
     bg = torch.zeros(3)
     targets = [t.to(dev) for t in _targets(gt, cams, bg)]
-    model, opts, ctrl = _restated_setup(init, dev, absgrad)
+    model, opts, ctrl = _restated_setup(init, dev, absgrad, optimizer=optimizer)
     cam_objs = [FakeCamera(c, dev) for c in cams]
     torch.manual_seed(999)
     with _cpu_normal():
@@ -240,15 +240,21 @@ def test_reference_consumer_code_drives_the_plugin_and_matches_the_restatement_c
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["vanilla", "gsplat-absgrad"])
+@pytest.mark.parametrize("which", ["vanilla", "vanilla-fused-adam-deferred", "gsplat-absgrad"])
 def test_training_loop_survives_density_changes_on_the_hip_renderers(which):
     import gspl_amd  # noqa: F401
     from gspl_amd.renderers import HipGSplatRenderer, HipVanillaRenderer
     dev = torch.device("cuda:0")
     steps = 290          # one opacity reset (step 150), densification until step 260
-    if which == "vanilla":
+    if which.startswith("vanilla"):
         plugin = HipVanillaRenderer()
-        hist, ps, model = _run_restated(lambda c, m, b: plugin(c, m, b), dev, steps)
+        optimizer = None
+        if which == "vanilla-fused-adam-deferred":
+            # the package's fused Adam with the shs_rest update on the colour stream, through densify / prune / opacity reset: the
+            # controller replaces the parameters and swaps the optimizer state between a step and the next render
+            from gspl_amd.optimizers import FusedAdam
+            optimizer = dict(cls=FusedAdam, deferred=("shs_rest",))
+        hist, ps, model = _run_restated(lambda c, m, b: plugin(c, m, b), dev, steps, optimizer=optimizer)
         hist_o, ps_o, _ = _run_restated(OracleVanillaRenderer(), torch.device("cpu"), steps)
         _check_history(hist, "HipVanillaRenderer")
         print(f"PSNR HIP {ps:.3f} dB, oracle renderer {ps_o:.3f} dB; final N {hist[-1][1]} vs {hist_o[-1][1]}")
