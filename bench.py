@@ -168,7 +168,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, 16, conics=conics, opacities=opac)
             rgbs = ops.sh_view_colors(3, m, center, dc, rest, radii > 0)
             img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
-                                          isects=ops.bin_gaussians_end(pending), channels_first=True)
+                                          isects=ops.bin_gaussians_end(pending, lazy=True), channels_first=True)
             loss = loss_fn(img)
             if marks is not None:
                 marks.append(_mark())

@@ -483,9 +483,13 @@ class _CompositeFn(torch.autograd.Function):
         dev = means2d.device
         tile_w, tile_h = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
         offsets = offsets.to(torch.int32).contiguous()
-        flatten_ids = flatten_ids.to(torch.int32).contiguous()
         assert offsets.numel() == tile_w * tile_h
-        n_isects = flatten_ids.shape[0]
+        lazy = flatten_ids if isinstance(flatten_ids, LazyLists) else None
+        if lazy is not None and lazy.settled:
+            flatten_ids, lazy = lazy.flat, None
+        if lazy is None:
+            flatten_ids = flatten_ids.to(torch.int32).contiguous()
+            n_isects = flatten_ids.shape[0]
         shape = (height, width, D) if layout == L.GSPL_LAYOUT_HWC else (D, height, width)
         out = torch.empty(shape, dtype=torch.float32, device=dev)
         alphas = torch.empty((height, width), dtype=torch.float32, device=dev)
@@ -495,10 +499,23 @@ class _CompositeFn(torch.autograd.Function):
         # SelectiveAdam, internal/optimizers.py:39): which splats some pixel actually composited
         hit = torch.zeros((N,), dtype=torch.uint8, device=dev) if track_hits else None
         with torch.cuda.device(dev):
-            L.call("gspl_composite_fwd",
-                   N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
-                   width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
-                   L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.ptr(hit), L.stream())
+            if lazy is not None:
+                # lists whose length is still on its way to the host (LazyLists): composite on the capacity-sized buffer, the end of
+                # the last list is read on the device; THEN look at the count, and repeat the launch if the guess had been too low
+                L.call("gspl_composite_fwd",
+                       N, -1, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
+                       width, height, tile_size, tile_w, tile_h, L.ptr(lazy.offsets_ext), L.ptr(lazy.flat_cap),
+                       L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.ptr(hit), L.stream())
+                held = lazy.settle()
+                flatten_ids, offsets = lazy.flat, lazy.offsets.to(torch.int32).contiguous()
+                n_isects = flatten_ids.shape[0]
+                if not held and hit is not None:
+                    hit.zero_()
+            if lazy is None or not held:
+                L.call("gspl_composite_fwd",
+                       N, n_isects, D, mode, layout, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opacities), L.ptr(backgrounds),
+                       width, height, tile_size, tile_w, tile_h, L.ptr(offsets), L.ptr(flatten_ids) if n_isects else None,
+                       L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), L.ptr(hit), L.stream())
         if hit is not None:
             means2d_in.has_hit_any_pixels = hit.view(torch.bool)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids)
@@ -1035,39 +1052,67 @@ def _emit(p: "_PendingBins"):
            L.ptr(p.big_list), L.ptr(p.spans), p.block_width, p.tile_w, p.tile_h, p.capacity, L.ptr(p.ws2), p.ws2_bytes, L.stream())
 
 
-def bin_gaussians_end(p: _PendingBins):
+class LazyLists:
+    """The per-tile lists of a binning whose LENGTH the host does not know yet (`bin_gaussians_end(p, lazy=True)`): the records were
+    emitted with room for a guess, the sort reads the real length on the device, and the compositing call that receives this object
+    in place of `flatten_ids` is launched on the capacity-sized buffer with the device-side end of the last list (n_isects = -1)
+    BEFORE the host looks at the count — by then the device is long past it, so the frame has no blocking wait.  A guess that was
+    too low repeats emission, sort and that compositing launch.  After the first compositing call (or `resolve()`), `flat` is the
+    exact-length tensor; `offsets` is valid (as device memory) from the start."""
+    __slots__ = ("p", "flat_cap", "flat", "offsets", "offsets_ext", "settled", "held")
+
+    def __init__(self, p: "_PendingBins", flat_cap: Tensor):
+        self.p, self.flat_cap, self.flat = p, flat_cap, None
+        self.offsets, self.offsets_ext = p.offsets, p.offsets_buf
+        self.settled = self.held = False
+
+    def settle(self) -> bool:
+        """Wait for the count (a formality once later work has been enqueued) and fix the lists: True if the guess held."""
+        if not self.settled:
+            with L.device_guard(self.p.dev):
+                n_isects = _bin_count_arrived(self.p)
+                self.held = 0 < n_isects <= self.p.capacity
+                if self.held:
+                    self.flat = self.flat_cap[:n_isects]
+                    self.p.ws2 = None
+                else:
+                    self.flat, self.offsets = _bin_finish(self.p, n_isects)
+            self.settled, self.flat_cap = True, None
+        return self.held
+
+    def resolve(self):
+        """(flatten_ids, offsets) as tensors (waits for the count if nobody has yet)."""
+        self.settle()
+        return self.flat, self.offsets
+
+
+def bin_gaussians_end(p: _PendingBins, lazy: bool = False):
     """Second half: waits for the count, then (emits and) sorts the (tile, Gaussian) lists.
-    Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
+    Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32).  lazy=True: (LazyLists, offsets) when the emission was speculative —
+    for callers that hand the lists straight to a compositing call of this module (see `LazyLists`)."""
     with L.device_guard(p.dev):
-        return _bin_gaussians_end(p)
+        return _bin_gaussians_end(p, lazy)
 
 
-def _bin_gaussians_end(p: _PendingBins):
+def _bin_count_arrived(p: _PendingBins) -> int:
+    """The list length of the frame (blocks until the scan kernel's store to pinned memory is visible) + the speculation book-keeping."""
+    p.event.synchronize()
+    _EVENTS[p.dev.index].append(p.event)
+    n_isects = int(p.host_count[0])
+    _PINNED_WORDS.append(p.host_count)
+    _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
+    SPECULATION["frames"] += 1
+    if p.capacity == 0:
+        SPECULATION["cold"] += 1
+    elif n_isects > p.capacity:
+        SPECULATION["misses"] += 1
+    return n_isects
+
+
+def _bin_finish(p: _PendingBins, n_isects: int):
+    """Emission (again, if the guess was too low or there was none) and sort with the list length known to the host."""
     lib = L.lib()
-    n_isects = 0
     N, dev = p.N, p.dev
-    flat_cap = None
-    if N > 0 and p.ws2 is not None and DEVICE_SIDE_LIST_LENGTH:
-        # The records were emitted speculatively: sort them BEFORE the host knows how many there are (the sort reads the length on
-        # the device, its grid is sized by the capacity), so that the device has the whole sort queued while the host waits for the
-        # count — and check the guess afterwards.
-        flat_cap = torch.empty((p.capacity,), dtype=torch.int32, device=dev)
-        L.call("gspl_bin_sort_device_count", N, p.tile_w, p.tile_h, L.ptr(p.cum, offset_bytes=8 * (N - 1)), p.capacity, L.ptr(flat_cap),
-               L.ptr(p.offsets_buf), L.ptr(p.ws2), p.ws2_bytes, L.stream())
-    if N > 0:
-        p.event.synchronize()
-        _EVENTS[dev.index].append(p.event)
-        n_isects = int(p.host_count[0])
-        _PINNED_WORDS.append(p.host_count)
-        _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
-        SPECULATION["frames"] += 1
-        if p.capacity == 0:
-            SPECULATION["cold"] += 1
-        elif n_isects > p.capacity:
-            SPECULATION["misses"] += 1
-    if flat_cap is not None and 0 < n_isects <= p.capacity:
-        p.ws2 = None
-        return flat_cap[:n_isects], p.offsets
     flat = torch.empty((n_isects,), dtype=torch.int32, device=dev)
     if n_isects > 0 and (p.ws2 is None or p.capacity < n_isects):
         p.capacity = n_isects
@@ -1080,14 +1125,29 @@ def _bin_gaussians_end(p: _PendingBins):
     return flat, p.offsets
 
 
+def _bin_gaussians_end(p: _PendingBins, lazy: bool = False):
+    N, dev = p.N, p.dev
+    if N > 0 and p.ws2 is not None and DEVICE_SIDE_LIST_LENGTH:
+        # The records were emitted speculatively: sort them BEFORE the host knows how many there are (the sort reads the length on
+        # the device, its grid is sized by the capacity), so that the device has the whole sort queued while the host waits for the
+        # count — and check the guess afterwards.
+        flat_cap = torch.empty((p.capacity,), dtype=torch.int32, device=dev)
+        L.call("gspl_bin_sort_device_count", N, p.tile_w, p.tile_h, L.ptr(p.cum, offset_bytes=8 * (N - 1)), p.capacity, L.ptr(flat_cap),
+               L.ptr(p.offsets_buf), L.ptr(p.ws2), p.ws2_bytes, L.stream())
+        lz = LazyLists(p, flat_cap)
+        return (lz, p.offsets) if lazy else lz.resolve()
+    n_isects = _bin_count_arrived(p) if N > 0 else 0
+    return _bin_finish(p, n_isects)
+
+
 def bin_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, img_height: int, img_width: int, block_width: int = 16,
-                  mode: int = L.GSPL_MODE_GSPLAT, conics: Optional[Tensor] = None, opacities: Optional[Tensor] = None):
+                  mode: int = L.GSPL_MODE_GSPLAT, conics: Optional[Tensor] = None, opacities: Optional[Tensor] = None, lazy: bool = False):
     """Binning half of `rasterize_gaussians`, exposed so that several compositing passes over the same
     projection (rgb + depth variants, gsplat_renderer.py:101-185) share one sort.
     With `conics` and `opacities` (the ones the compositing call will use) tile hits that cannot reach
     alpha >= 1/255 anywhere in the tile are not listed — same images and gradients, ~40 % shorter lists.
     Returns (flatten_ids [I] i32, offsets [tile_h*tile_w] i32)."""
-    return bin_gaussians_end(bin_gaussians_begin(xys, depths, radii, img_height, img_width, block_width, mode, conics, opacities))
+    return bin_gaussians_end(bin_gaussians_begin(xys, depths, radii, img_height, img_width, block_width, mode, conics, opacities), lazy)
 
 
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
@@ -1101,7 +1161,7 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
     if block_width not in (8, 16, 32):
         raise NotImplementedError("block_width must be 8, 16 or 32 (the reference default is 16, gsplat_renderer.py:6)")
     flat, offsets = isects if isects is not None else bin_gaussians(xys, depths, radii, img_height, img_width, block_width,
-                                                                    conics=conics, opacities=opacity)
+                                                                    conics=conics, opacities=opacity, lazy=True)
     out, alphas = _composite(xys, conics, colors, opacity.reshape(-1), background, img_width, img_height, block_width,
                              offsets, flat, absgrad, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_CHW if channels_first else L.GSPL_LAYOUT_HWC)
     return (out, alphas) if return_alpha else out

@@ -312,7 +312,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
             pre = (None, None, (W, H))
             projections = (radii.unsqueeze(0), means2d, depths.unsqueeze(0), conics.unsqueeze(0), None)
             isects = self.isect_encode(pre, (projections[0], means2d.unsqueeze(0), projections[2], projections[3], None),
-                                       opac, tile_size=implementation_tile_size(self.config.block_size))
+                                       opac, tile_size=implementation_tile_size(self.config.block_size), lazy=True)
             with self._span("rasterize"):
                 # [3,H,W] straight from the kernel (the reference permutes an [H,W,3] image)
                 rgb, _ = GSplatV1.rasterize(pre, projections, isects, opac, colors=rgbs, background=bg_color,

@@ -114,7 +114,7 @@ class HipGSplatRenderer(Renderer):
         def rasterize(feats, background, return_alpha=False, opac=opacities, absgrad=False, channels_first=False):
             nonlocal isects
             if isects is None:
-                isects = ops.bin_gaussians_end(pending)
+                isects = ops.bin_gaussians_end(pending, lazy=True)      # the list length stays on the device until compositing is enqueued
             return ops.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, feats, opac, img_height=H, img_width=W,
                                            block_width=implementation_tile_size(self.block_size), background=background, return_alpha=return_alpha,
                                            absgrad=absgrad, isects=isects if opac is opacities else None,

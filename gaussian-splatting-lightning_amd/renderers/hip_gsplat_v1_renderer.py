@@ -134,7 +134,10 @@ class HipGSplatV1RendererModule(Renderer):
         opacities = opacities.unsqueeze(0)
         if self.config.anti_aliased:
             opacities = opacities * compensations
-        isects = self.isect_encode(preprocessed_camera, projections, opacities, tile_size=implementation_tile_size(self.config.block_size))
+        # lists-only binning of this package: the list length stays on the device until the first compositing launch is enqueued
+        lazy = {"lazy": True} if getattr(self.isect_encode, "__func__", None) in (GSplatV1.isect_encode_lists_only.__func__,
+                                                                                   GSplatV1.isect_encode_tile_based_culling.__func__) else {}
+        isects = self.isect_encode(preprocessed_camera, projections, opacities, tile_size=implementation_tile_size(self.config.block_size), **lazy)
 
         means2d = means2d.squeeze(0)
         projection_for_rasterization = radii, means2d, depths, conics, compensations
@@ -210,6 +213,7 @@ class HipGSplatV1RendererModule(Renderer):
             inverse_depth = 1. / (depths[0].clamp_min(0.) + 1e-8).unsqueeze(-1)
             im = rasterize(inverse_depth, zero1, opac=opacities + (1 - opacities.detach()), absgrad=False).permute(2, 0, 1)
             outputs["hard_inverse_depth"] = outputs["inv_depth_alt"] = im
+        outputs["isects"] = GSplatV1.settled_isects(isects)
         return outputs
 
     def setup_web_viewer_tabs(self, viewer, server, tabs):
@@ -301,30 +305,42 @@ class GSplatV1:
         return cls.isect_encode(preprocessed_camera, projection_results, tile_size)
 
     @classmethod
-    def isect_encode_lists_only(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16):
+    def isect_encode_lists_only(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16, lazy: bool = False):
         """Same per-tile lists as `isect_encode` (bit-identical flatten_ids / isect_offsets, tests/test_hip_parity.py), without
         the 64-bit keys: -> (None, None, flatten_ids [I], isect_offsets [1,th,tw])."""
         img_width, img_height = preprocessed_camera[-1]
         radii, means2d, depths, _, _ = projection_results
         tile_width = math.ceil(int(img_width) / float(tile_size))
         tile_height = math.ceil(int(img_height) / float(tile_size))
-        flatten_ids, offsets = ops.bin_gaussians(means2d.reshape(-1, 2), depths.reshape(-1), radii.reshape(-1), int(img_height), int(img_width), tile_size)
+        flatten_ids, offsets = ops.bin_gaussians(means2d.reshape(-1, 2), depths.reshape(-1), radii.reshape(-1), int(img_height), int(img_width), tile_size,
+                                                 lazy=lazy)
         return None, None, flatten_ids, offsets.reshape(1, tile_height, tile_width)
 
     @classmethod
-    def isect_encode_tile_based_culling(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16):
+    def isect_encode_tile_based_culling(cls, preprocessed_camera: Tuple, projection_results, opacities, tile_size: int = 16, lazy: bool = False):
         """Tile-based culling (StopThePop; reference: gsplat_v1_renderer.py:477-522): a (tile, Gaussian) pair is listed only
         if the Gaussian can reach alpha >= 1/255 somewhere in the tile.  Here that is the list-only two-level binning with
         its exact ellipse-vs-tile test (`ops.bin_gaussians`), so the 64-bit keys are never materialised:
         -> (tiles_per_gauss = None, isect_ids = None, flatten_ids [I'], isect_offsets [1,th,tw]); the reference consumes only
-        the last two (`rasterize`, gsplat_v1_renderer.py:588-601).  `opacities` [1,N]: the ones compositing will use."""
+        the last two (`rasterize`, gsplat_v1_renderer.py:588-601).  `opacities` [1,N]: the ones compositing will use.
+        lazy=True (the plugins' own forward): `flatten_ids` may come back as an `ops.LazyLists` — lists whose length the host has not
+        read yet, which `rasterize` accepts; `settled_isects` turns the tuple into tensors afterwards."""
         img_width, img_height = preprocessed_camera[-1]
         radii, means2d, depths, conics, _ = projection_results
         tile_width = math.ceil(int(img_width) / float(tile_size))
         tile_height = math.ceil(int(img_height) / float(tile_size))
         flatten_ids, offsets = ops.bin_gaussians(means2d.reshape(-1, 2), depths.reshape(-1), radii.reshape(-1), int(img_height), int(img_width),
-                                                 tile_size, conics=conics.reshape(-1, 3), opacities=opacities.reshape(-1))
+                                                 tile_size, conics=conics.reshape(-1, 3), opacities=opacities.reshape(-1), lazy=lazy)
         return None, None, flatten_ids, offsets.reshape(1, tile_height, tile_width)
+
+    @staticmethod
+    def settled_isects(isects):
+        """The `isects` tuple with tensors only: an `ops.LazyLists` in the flatten_ids slot is replaced by the exact-length tensor
+        (by then the compositing launches it fed are enqueued, so the wait for the count costs nothing)."""
+        if isinstance(isects[2], ops.LazyLists):
+            flat, _ = isects[2].resolve()
+            return isects[0], isects[1], flat, isects[3]
+        return isects
 
     @classmethod
     def preprocess(cls, preprocessed_camera: Tuple, means3d, scales, quats, eps2d: float = 0.3, anti_aliased: bool = True,

@@ -79,7 +79,7 @@ def _install_oracle_ops():
             cols.append(rgb)
         return torch.stack(cols)
 
-    def bin_gaussians(xys, depths, radii, img_height, img_width, block_width=16, mode=0, conics=None, opacities=None):
+    def bin_gaussians(xys, depths, radii, img_height, img_width, block_width=16, mode=0, conics=None, opacities=None, lazy=False):
         _, _, flat, offs = O.isect_tiles(O.MODE_GSPLAT, xys.detach(), radii, depths.detach(), img_width, img_height)
         return torch.from_numpy(np.asarray(flat)), torch.from_numpy(np.asarray(offs))
 

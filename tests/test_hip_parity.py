@@ -279,6 +279,58 @@ def test_speculative_emission_recovers_from_a_low_guess(hip):
         assert hip._LAST_ISECTS[(torch.device(d).index, tw, th)] == flat_ref.shape[0]
 
 
+def test_lazy_lists_composite_before_the_host_has_the_list_length(hip):
+    """`bin_gaussians(..., lazy=True)` hands compositing an `ops.LazyLists`: the compositing launch goes out on the capacity-sized
+    buffer with the device-side list end BEFORE the host looks at the count (no blocking wait in the frame); a guess that was too
+    low repeats emission, sort and that launch.  Frames whose guess is far too low, about right and far too high must equal the
+    eager path bit for bit — image, alpha, the lists the object settles to — and their gradients within the atomics' spread; the
+    v0 entry point (which bins by itself, lazily) and the hit flags as well."""
+    d = _dev()
+    W, H, D = 640, 480, 3
+    cases = []
+    for n, seed, mul in ((400, 31, 1.0), (30000, 32, 8.0), (400, 31, 1.0), (30000, 32, 8.0), (30000, 33, 8.0)):
+        res, opac, _, _ = _projected_scene(n, W, H, 600.0, seed=seed, scale_mul=mul)
+        g = torch.Generator().manual_seed(seed)
+        cases.append(dict(xys=res[0].float().to(d), depths=res[1].float().to(d), radii=res[2].to(d), conics=res[3].float().to(d),
+                          op=(opac.reshape(-1) * res[4]).float().to(d), col=torch.rand(n, D, generator=g).to(d)))
+    bg = torch.tensor([0.2, 0.4, 0.1], device=d)
+    w = torch.randn(H, W, D, generator=torch.Generator().manual_seed(3)).to(d)
+    frames0, misses0 = hip.SPECULATION["frames"], hip.SPECULATION["misses"]
+    key = (torch.device(d).index, (W + 15) // 16, (H + 15) // 16)
+    n_lazy, lazy_misses, prev_len = 0, 0, 1
+    for c in cases:
+        def run(lazy):
+            leaves = [c[k].clone().requires_grad_(True) for k in ("xys", "conics", "col", "op")]
+            m2, con, col, op = leaves
+            flat, offs = hip.bin_gaussians(c["xys"], c["depths"], c["radii"], H, W, 16, conics=c["conics"], opacities=c["op"], lazy=lazy)
+            was_lazy = isinstance(flat, hip.LazyLists)
+            out, alphas = hip.rasterize_to_pixels(m2, con[None], col[None], op[None], W, H, 16, offs.reshape(1, (H + 15) // 16, (W + 15) // 16), flat,
+                                                  backgrounds=bg[None], track_hits=True)
+            if was_lazy:
+                assert flat.settled
+                flat = flat.resolve()[0]
+            (out[0] * w).sum().backward()
+            return out.detach(), alphas.detach(), flat, offs, [t.grad for t in leaves], m2.has_hit_any_pixels, was_lazy
+        o0, a0, f0, of0, g0, h0, _ = run(False)
+        # the lazy run starts from the guess the PREVIOUS case left (far too low for a big frame after a small one, far too high the
+        # other way round), not from the one the eager run of the same scene has just stored
+        hip._LAST_ISECTS[key] = prev_len
+        lazy_misses += f0.shape[0] > int(prev_len * 1.25) + 65536
+        prev_len = f0.shape[0]
+        o1, a1, f1, of1, g1, h1, was_lazy = run(True)
+        n_lazy += was_lazy
+        assert torch.equal(o0, o1) and torch.equal(a0, a1) and torch.equal(f0, f1) and torch.equal(of0, of1) and torch.equal(h0, h1)
+        for x, y in zip(g0, g1):
+            assert_close_scaled(y.cpu().numpy(), x.cpu().numpy(), 2e-5, "lazy vs eager gradients")
+        # v0: bins by itself (lazily) inside the call
+        img = hip.rasterize_gaussians(c["xys"], c["depths"], c["radii"], c["conics"], None, c["col"], c["op"][:, None], H, W, 16, bg)
+        assert torch.equal(img, o0[0])
+    assert n_lazy == len(cases), "the speculative path must have been taken"
+    assert lazy_misses >= 2, f"the big frames after the small ones must overflow their guesses (last list length {prev_len})"
+    assert hip.SPECULATION["misses"] - misses0 >= lazy_misses
+    assert hip.SPECULATION["frames"] - frames0 == 3 * len(cases)
+
+
 @pytest.mark.parametrize("mode", [O.MODE_GSPLAT, O.MODE_INRIA])
 def test_binning_big_splats(hip, mode):
     """Splats taller than 16 tile rows (radius > 128 px) are ranked by the scan of the counts and dealt out to the workgroups
