@@ -702,8 +702,8 @@ class _side_stream:
 
 def colour_stream(dev):
     """(raw handle, torch stream) of the stream the fused rasterizer launches its colour (SH) kernel on, next to the binning on the
-    caller's stream: the library's lowest-priority stream when there is one (torch cannot create a stream below the default
-    priority), else the package's side stream; (None, None) with GSPL_SIDE_STREAM=0."""
+    caller's stream: the package's torch side stream (default priority), or with GSPL_SIDE_LOW_PRIORITY=1 the library's
+    lowest-priority stream (torch cannot create one below the default); (None, None) with GSPL_SIDE_STREAM=0."""
     side = _side_stream(dev)
     if not side.enabled:
         return None, None
@@ -1375,8 +1375,8 @@ class _InriaFusedFn(torch.autograd.Function):
             low = False
             raw = None
             if side.enabled:
-                # a stream of the device's LOWEST priority from the library: the colour kernel yields to the key pass and the depth
-                # sort it runs next to
+                # the colour stream (default priority; GSPL_SIDE_LOW_PRIORITY=1: the library's lowest-priority stream, on which the
+                # colour kernel yields to the key pass and the depth sort it runs next to)
                 raw, _ = colour_stream(dev)
                 low = _side_stream._low.get((dev.type, dev.index), False)
                 side_handle = ctypes.c_void_p(raw)
