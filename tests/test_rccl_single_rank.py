@@ -99,9 +99,14 @@ WORKER = textwrap.dedent("""
     img_a, grads_a = render(True)
     img_b, grads_b = render(False)
     assert torch.equal(img_a, img_b)
-    for ga, gb in zip(grads_a, grads_b):
-        # (the compositing backward accumulates with atomics: last-bit differences between two runs)
-        assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max()) + 1e-12
+    for k, (ga, gb) in enumerate(zip(grads_a, grads_b)):
+        # The compositing backward accumulates with fp32 atomics: the order of the additions differs between two launches, most of all
+        # between a process's FIRST launch of the kernel (code being loaded, workgroups start one after the other) and the later ones.
+        # Measured over fresh processes (tools/diag/r03rccl2.py): opacities / SH coefficients agree to 8e-8 of the tensor's maximum,
+        # means / scales / rotations — behind the conic -> cov2D -> cov3D chain, which amplifies a last-bit difference of one
+        # near-degenerate splat — to 1e-6 / 5e-6 / 1.1e-5 for the first frame and 3e-7 between later frames.
+        tol = 1e-4 if k < 3 else 1e-5                     # leaves: means, scales, rotations | opacities, shs_dc, shs_rest
+        assert float((ga - gb).abs().max()) <= tol * float(ga.abs().max()) + 1e-12, (k, float((ga - gb).abs().max()), float(ga.abs().max()))
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL-SINGLE-RANK-OK")
