@@ -82,6 +82,8 @@ def parse():
                         "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
     p.add_argument("--no-overlap-sh-update", action="store_true",
                    help="keep the whole optimizer step on the caller's stream (default on one GPU: the shs_rest update overlaps the next frame's binning)")
+    p.add_argument("--staged-sharded-step", action="store_true",
+                   help="--parallelism sharded: the stage-by-stage formulation of the step (eleven autograd nodes) instead of the three-node one")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
     p.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg and print it (no GPU needed)")
     p.add_argument("--stage-times", action="store_true",
@@ -417,7 +419,7 @@ def main():
         N = hi - lo
         cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
         # tile_based_culling as in the reference's configs/distributed-accel.yaml (lossless here: same images and gradients)
-        renderer = HipGSplatDistributedRenderer(tile_based_culling=True).instantiate()
+        renderer = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step).instantiate()
         renderer.world_size, renderer.global_rank = world, rank
         renderer.camera_lookup = lambda idx, training: cams[idx]
         renderer.train()
@@ -712,7 +714,9 @@ def main():
                                  "chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step")
                               + f", all-reduce of the densification stats every {DENSIFY_INTERVAL} steps"),
                "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of splat records (configs/distributed.yaml); "
-                          + (f"exchange format of the last step: {renderer.last_exchange}" if mode == "sharded" else "")}[mode]
+                          + (f"exchange format of the last step: {renderer.last_exchange}; step as "
+                             + ("eleven stage-by-stage autograd nodes" if args.staged_sharded_step else "three autograd nodes (front / exchange / back)")
+                             if mode == "sharded" else "")}[mode]
         line = {
             "metric": "training images/sec + fwd/bwd ms @1080p, 1M Gaussians, 1/2/4/8 MI355X",
             "value": round(world * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "gspl_low_priority_stream": (c_void_p, []),
     "gspl_records_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gspl_records_pack_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gspl_records_count_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gspl_records_scatter_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_pack_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_unpack_fwd": (c_int, [ctypes.c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_unpack_bwd": (c_int, [ctypes.c_int64, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),

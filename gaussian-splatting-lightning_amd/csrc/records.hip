@@ -48,6 +48,42 @@ __global__ __launch_bounds__(256) void records_pack_kernel(
     dst[2] = make_float4(colors[idx * 3 + 0], colors[idx * 3 + 1], colors[idx * 3 + 2], __int_as_float(r));
 }
 
+// Two-phase form of the pack: the COUNT phase needs the radii only (flag -> scan -> slots and per-camera ends, the ends also into
+// pinned host memory), so the sizes of the exchange are on their way to the host before the colour kernel has run; the SCATTER phase
+// writes the records to the slots.  Same slots, ends and records as records_pack_kernel.
+__global__ __launch_bounds__(256) void records_slots_kernel(
+    int C, int N, const int32_t* __restrict__ radii, const uint32_t* __restrict__ scan, int32_t* __restrict__ slots,
+    int64_t* __restrict__ ends, int64_t* __restrict__ host_ends) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)C * N) return;
+    const int cam = (int)(idx / N);
+    const int g = (int)(idx - (int64_t)cam * N);
+    const uint32_t pos = scan[idx];
+    const bool vis = radii[idx] > 0;
+    slots[idx] = vis ? (int32_t)pos : -1;
+    if (g == N - 1) {                                 // one past the camera's last record
+        const int64_t e = (int64_t)pos + (vis ? 1 : 0);
+        ends[cam] = e;
+        if (host_ends) { host_ends[cam] = e; __threadfence_system(); }
+    }
+}
+
+__global__ __launch_bounds__(256) void records_scatter_kernel(
+    int C, int N, const int32_t* __restrict__ radii, const int32_t* __restrict__ slots, const float* __restrict__ means2d,
+    const float* __restrict__ depths, const float* __restrict__ conics, const float* __restrict__ comps, const float* __restrict__ opacities,
+    const float* __restrict__ colors, float* __restrict__ records) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)C * N) return;
+    const int32_t pos = slots[idx];
+    if (pos < 0) return;
+    const int cam = (int)(idx / N);
+    const int g = (int)(idx - (int64_t)cam * N);
+    float4* dst = reinterpret_cast<float4*>(records + (size_t)pos * REC);
+    dst[0] = make_float4(means2d[idx * 2 + 0], means2d[idx * 2 + 1], depths[idx], conics[idx * 3 + 0]);
+    dst[1] = make_float4(conics[idx * 3 + 1], conics[idx * 3 + 2], comps ? comps[idx] : 1.f, opacities[g]);
+    dst[2] = make_float4(colors[idx * 3 + 0], colors[idx * 3 + 1], colors[idx * 3 + 2], __int_as_float(radii[idx]));
+}
+
 // Every (camera, splat) row of every gradient tensor is written (zeros for the invisible ones): no memset, and the torch ops
 // between the projection and the pack (compensation product, activations) never see uninitialised values.
 template <bool ATOMIC_OPACITY>
@@ -148,6 +184,44 @@ extern "C" int gspl_records_pack_fwd(int C, int N, const int32_t* radii, const f
     hipLaunchKernelGGL(records_pack_kernel, dim3(grid), dim3(256), 0, s, C, N, radii, means2d, depths, conics, compensations, opacities, colors,
                        (const uint32_t*)scan, records, slots, ends, host_ends);
     return check_launch("records_pack_fwd");
+}
+
+extern "C" int gspl_records_count_fwd(int C, int N, const int32_t* radii, int32_t* slots, int64_t* ends, int64_t* host_ends,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace gspl;
+    if (C < 0 || N < 0) return fail_arg("records_count_fwd: bad sizes");
+    const int64_t total = (int64_t)C * N;
+    if (total == 0) return GSPL_OK;
+    if (total >= (1ll << 32)) { set_error("records_count_fwd", "more than 2^32-1 (camera, splat) pairs"); return GSPL_ERR_UNSUPPORTED; }
+    if (!radii || !slots || !ends || !workspace) return fail_arg("records_count_fwd: NULL required pointer");
+    RecordsWorkspace w;
+    plan_records(total, w);
+    if (workspace_bytes < w.total) return fail_ws("records_count_fwd");
+    char* ws = (char*)workspace;
+    uint32_t* flags = (uint32_t*)(ws + w.flags_off);
+    uint32_t* scan = (uint32_t*)(ws + w.scan_off);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(records_flag_kernel, dim3(grid), dim3(256), 0, s, total, radii, flags);
+    int rc = exclusive_scan_u32(flags, scan, (size_t)total, ws + w.tmp_off, s);
+    if (rc != GSPL_OK) return rc;
+    hipLaunchKernelGGL(records_slots_kernel, dim3(grid), dim3(256), 0, s, C, N, radii, (const uint32_t*)scan, slots, ends, host_ends);
+    return check_launch("records_count_fwd");
+}
+
+extern "C" int gspl_records_scatter_fwd(int C, int N, const int32_t* radii, const int32_t* slots, const float* means2d, const float* depths,
+                                        const float* conics, const float* compensations, const float* opacities, const float* colors,
+                                        float* records, void* stream) {
+    using namespace gspl;
+    if (C < 0 || N < 0) return fail_arg("records_scatter_fwd: bad sizes");
+    const int64_t total = (int64_t)C * N;
+    if (total == 0) return GSPL_OK;
+    if (!radii || !slots || !means2d || !depths || !conics || !opacities || !colors || !records)
+        return fail_arg("records_scatter_fwd: NULL required pointer");
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(records_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, radii, slots, means2d, depths, conics,
+                       compensations, opacities, colors, records);
+    return check_launch("records_scatter_fwd");
 }
 
 extern "C" int gspl_records_pack_bwd(int C, int N, const int32_t* slots, const float* v_records,

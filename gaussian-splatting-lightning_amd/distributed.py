@@ -115,6 +115,14 @@ def all_to_all_rows(send: torch.Tensor, send_counts: Sequence[int], recv_counts:
     return _AllToAllRows.apply(send, list(send_counts), list(recv_counts), group)
 
 
+def all_to_all_route(send_counts: Sequence[int], recv_counts: Sequence[int], group=None):
+    """(forward, backward) callables of the same exchange for `ops.sharded_exchange`: rows grouped by destination -> rows grouped
+    by source, and the gradients of the received rows back to the rows that were sent."""
+    send_counts, recv_counts = list(send_counts), list(recv_counts)
+    return (lambda rows: _all_to_all_rows_raw(rows, send_counts, recv_counts, group),
+            lambda v_rows: _all_to_all_rows_raw(v_rows, recv_counts, send_counts, group))
+
+
 def pack_visible(radii, means2d, depths, conics, compensations, opacities, rgbs, visibility) -> torch.Tensor:
     """[n_vis, 12] fp32 records of the splats `visibility` selects (one camera)."""
     rbits = radii.to(torch.int32).view(torch.float32)

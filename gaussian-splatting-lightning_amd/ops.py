@@ -1168,6 +1168,220 @@ def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tens
 
 
 # =============================================================================================
+# The Gaussian-sharded renderer's step as THREE autograd nodes instead of eleven
+# (internal/renderers/gsplat_distributed_renderer.py:252-311 project + colours, :127-211 exchange, :356-389 rasterize)
+# =============================================================================================
+# The staged formulation of that step (fully_fused_projection -> 5 x unbind_cameras -> sh_view_colors_batched ->
+# pack_visible_records -> all_to_all_rows -> unpack_visible_records -> bin_gaussians -> rasterize_to_pixels) costs the host 1.3-1.5 ms
+# per step at 1 M Gaussians for 1.25-1.38 ms of kernels (tools/micro/host_sharded_profile.py): eleven autograd nodes, each with its
+# Python forward, its engine dispatch in the backward and its per-camera tuples.  The three nodes below run the SAME stage bodies —
+# the forward / backward static methods of the stage wrappers above, called with a stand-in context, so there is one copy of every
+# launch sequence — and hand batched [C, N, ...] buffers from stage to stage:
+#
+#   sharded_front     project (C cameras, one launch) -> SH colours (C cameras, one launch) -> pack the visible splats' records
+#   sharded_exchange  the all-to-all of the records (a callable of the caller: this module knows no process groups) AND the tap that
+#                     gives every camera's screen-space positions their gradient (`xys[c].grad` is what the reference's
+#                     DistributedVanillaDensityControllerImpl reads): its backward turns the record gradients into per-(camera, splat)
+#                     gradients once (gspl_records_pack_bwd), returns the means2d part as the gradient of `xys` and leaves the rest
+#                     in the step's `stash` for the front node's backward
+#   sharded_back      unpack -> bin (lists whose length stays on the device) -> composite
+class _StageCtx:
+    """Stand-in for the autograd context of one stage wrapper."""
+    __slots__ = ("saved_tensors", "needs_input_grad", "cfg", "fold", "means2d_ref")
+
+    def __init__(self, needs_input_grad=()):
+        self.saved_tensors = ()
+        self.needs_input_grad = needs_input_grad
+        self.means2d_ref = None
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+class _Ref:
+    """Something attributes can be attached to (the stage wrappers attach side-channel results to the caller's tensor)."""
+
+
+def _save_stages(ctx, stages):
+    """Keep the tensors the stage bodies saved through the REAL context (no attribute references to output tensors: those would
+    be reference cycles through grad_fn), with the split points to rebuild the stand-in contexts in the backward."""
+    flat, cuts = [], []
+    for s in stages:
+        flat.extend(s.saved_tensors)
+        cuts.append(len(flat))
+        s.saved_tensors = ()
+    ctx.save_for_backward(*flat)
+    ctx.cuts = cuts
+
+
+def _load_stages(ctx, stages):
+    saved, lo = ctx.saved_tensors, 0
+    for s, hi in zip(stages, ctx.cuts):
+        s.saved_tensors = saved[lo:hi]
+        lo = hi
+
+
+class _ShardFrontFn(torch.autograd.Function):
+    @staticmethod
+    @_guarded(1)
+    def forward(ctx, means, scales, quats, opacities, dc, rest, viewmats, Ks, centers, width, height, eps2d, degree, stash):
+        C = viewmats.shape[0]
+        proj, sh, pack = _StageCtx(), _StageCtx(), _StageCtx()
+        radii, means2d, depths, conics, comps, _, _ = _ProjectFn.forward(
+            proj, means, scales, quats, viewmats, Ks, width, height, 16, 1.0, eps2d, 0.01, 1e10, 0.0, True, False, L.GSPL_CAMERA_PINHOLE, False)
+        # The pack in two phases (csrc/records.hip): the record COUNTS need the radii only, so they are on their way to the host
+        # (pinned memory, an event behind them) before the colour kernel is even launched; the host waits for them with the colour
+        # kernel and the scatter still queued on the device — the wait of the counted exchange (the reference's
+        # gsplat_distributed_renderer.py:141-160 reads the counts back after everything) no longer drains the stream.
+        lib = L.lib()
+        N, dev = means.shape[0], radii.device
+        opac = _f32c(opacities.detach()).reshape(-1)
+        assert opac.shape[0] == N
+        slots = torch.empty((C, N), dtype=torch.int32, device=dev)
+        ends_dev = torch.empty((C,), dtype=torch.int64, device=dev)
+        pool = _PINNED_ENDS.setdefault(C, [])
+        host_ends = pool.pop() if pool else torch.empty((C,), dtype=torch.int64).pin_memory()
+        ws_bytes = lib.gspl_records_workspace_bytes(C, N)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        L.call("gspl_records_count_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(ends_dev), host_ends.data_ptr(), L.ptr(ws), ws_bytes, L.stream())
+        ev = _take_event(dev)
+        ev.record()
+        colors = _SHBatchedFn.forward(sh, degree, means, centers, dc, rest, radii)
+        records = torch.empty((max(C * N, 1), L.GSPL_RECORD_FLOATS), dtype=torch.float32, device=dev)
+        L.call("gspl_records_scatter_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps),
+               L.ptr(opac), L.ptr(colors), L.ptr(records), L.stream())
+        ev.synchronize()                 # the split sizes of the all-to-all are needed on the host (as in the reference)
+        _EVENTS[dev.index].append(ev)
+        ends = host_ends.clone() if C * N > 0 else torch.zeros((C,), dtype=torch.int64)
+        pool.append(host_ends)
+        records = records[:int(ends[-1]) if C > 0 else 0]
+        pack.save_for_backward(slots)
+        pack.cfg = (C, N, True, tuple(opacities.shape))
+        # the pack stage's state travels in the stash: the exchange node's backward runs that stage's backward
+        stash["pack"] = pack
+        ctx.stash = stash
+        ctx.stages = (proj, sh)
+        _save_stages(ctx, ctx.stages)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(ends, radii, depths, conics, comps)
+        return records, ends, radii, means2d, depths, conics, comps
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, v_records, _v_ends, _v_radii, v_means2d, _v_depths, _v_conics, _v_comps):
+        if v_records is not None:
+            raise RuntimeError("the records of ops.sharded_front must reach their consumer through ops.sharded_exchange")
+        proj, sh = ctx.stages
+        _load_stages(ctx, ctx.stages)
+        rest_of = ctx.stash.pop("grads", None)      # left by _ShardExchangeFn.backward, which the engine runs before this node
+        v_depths = v_conics = v_comps = v_opac = v_colors = None
+        if rest_of is not None:
+            v_depths, v_conics, v_comps, v_opac, v_colors = rest_of
+        v_dc = v_rest = None
+        if v_colors is not None:
+            _, _, _, v_dc, v_rest, _ = _SHBatchedFn.backward(sh, v_colors)
+        v_means = v_scales = v_quats = None
+        if v_means2d is not None or v_conics is not None:
+            v_means, v_scales, v_quats = _ProjectFn.backward(proj, None, v_means2d, v_depths, v_conics, v_comps, None, None)[:3]
+        return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 8
+
+
+class _ShardExchangeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, records, stash, route, *xys):
+        ctx.stash, ctx.route, ctx.C = stash, route, len(xys)
+        ctx.set_materialize_grads(False)
+        if route is None:
+            return records.view_as(records)
+        return route[0](records)
+
+    @staticmethod
+    def backward(ctx, v_records):
+        C = ctx.C
+        if v_records is None:
+            return (None,) * (3 + C)
+        if ctx.route is not None:
+            v_records = ctx.route[1](v_records)
+        pack = ctx.stash.pop("pack")
+        grads = _PackRecordsFn.backward(pack, v_records, None)
+        # (None, None, v_opac, C x None (radii), C x v_means2d, C x v_depths, C x v_conics, C x v_comps, C x v_colors): per-camera
+        # slices of one buffer each
+        v_opac = grads[2]
+        per = lambda k: grads[3 + k * C:3 + (k + 1) * C]
+        ctx.stash["grads"] = (_batched(per(2)), _batched(per(3)), _batched(per(4)), v_opac, _batched(per(5)))
+        return (None, None, None) + tuple(per(1))
+
+
+class _ShardBackFn(torch.autograd.Function):
+    @staticmethod
+    @_guarded(1)
+    def forward(ctx, records, backgrounds, width, height, tile_size, fold_compensation, cull):
+        unpack, comp = _StageCtx(), _StageCtx()
+        comp.means2d_ref = _Ref()
+        radii, means2d, depths, conics, opac, colors = _UnpackRecordsFn.forward(unpack, records, fold_compensation)
+        flat, offsets = bin_gaussians(means2d, depths, radii, height, width, tile_size, conics=conics if cull else None,
+                                      opacities=opac if cull else None, lazy=True)
+        out, alphas = _CompositeFn.forward(comp, means2d, conics, colors, opac, backgrounds, width, height, tile_size, offsets, flat,
+                                           False, L.GSPL_MODE_GSPLAT, L.GSPL_LAYOUT_CHW, False)
+        ctx.stages = (unpack, comp)
+        _save_stages(ctx, ctx.stages)
+        ctx.set_materialize_grads(False)
+        return out, alphas
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, v_out, v_alphas):
+        unpack, comp = ctx.stages
+        _load_stages(ctx, ctx.stages)
+        comp.needs_input_grad = (False, False, False, False, ctx.needs_input_grad[1])
+        if comp.means2d_ref is None:
+            comp.means2d_ref = _Ref()
+        v_means2d, v_conics, v_colors, v_opac, v_bg = _CompositeFn.backward(comp, v_out, v_alphas)[:5]
+        v_records, _ = _UnpackRecordsFn.backward(unpack, None, v_means2d, None, v_conics, v_opac, v_colors)
+        return v_records, v_bg, None, None, None, None, None
+
+
+def sharded_front(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, shs_dc: Tensor, shs_rest: Optional[Tensor],
+                  viewmats: Tensor, Ks: Tensor, camera_centers: Tensor, width: int, height: int, eps2d: float, sh_degree: int,
+                  stash: dict):
+    """This rank's shard seen from C cameras, packed for the exchange — `fully_fused_projection(calc_compensations=True)` +
+    `sh_view_colors_batched` + `pack_visible_records` as ONE autograd node (means are detached for the colours, as
+    gsplat_distributed_renderer.py:417 does).  viewmats [C,4,4], Ks [C,3,3], camera_centers [C,3]; `stash`: a dict private to
+    this step, handed to `sharded_exchange` as well.
+    Returns (records [M,12] grouped by camera, counts per camera (python list), radii [C,N] i32, means2d [C,N,2], depths [C,N],
+    conics [C,N,3], compensations [C,N]).  Only `records` and `means2d` carry gradients — means2d through `sharded_exchange`'s
+    `xys` argument; radii / depths / conics / compensations are handed out for inspection (detached)."""
+    records, ends, radii, means2d, depths, conics, comps = _ShardFrontFn.apply(
+        means, scales, quats, opacities, shs_dc, shs_rest, viewmats, Ks, camera_centers, int(width), int(height), float(eps2d),
+        int(sh_degree), stash)
+    e = [0] + [int(v) for v in ends.tolist()]
+    return records, [e[i + 1] - e[i] for i in range(len(e) - 1)], radii, means2d, depths, conics, comps
+
+
+def sharded_exchange(records: Tensor, stash: dict, xys: Sequence[Tensor], route=None) -> Tensor:
+    """The records on their way to the ranks that render them.  `route`: None (one rank: nothing travels) or a pair of callables
+    (forward, backward) mapping the sent rows to the received rows and the received rows' gradients back to the sent rows' (the
+    all-to-all with split sizes and its reverse: `distributed.all_to_all_route`).  `xys`: the per-camera views of `sharded_front`'s
+    means2d (`unbind_cameras`); after a backward pass `xys[c].grad` (with `retain_grad()`) is d loss / d means2d of camera c."""
+    return _ShardExchangeFn.apply(records, stash, route, *xys)
+
+
+def sharded_back(records: Tensor, backgrounds: Optional[Tensor], width: int, height: int, tile_size: int = 16,
+                 fold_compensation: bool = True, tile_based_culling: bool = False):
+    """Received records -> image: `unpack_visible_records` + `bin_gaussians` (list-only, optional tile-based culling, list length on
+    the device) + `rasterize_to_pixels(channels_first=True)` as ONE autograd node.  Returns (image [D,H,W], alphas [H,W])."""
+    if tile_size not in (8, 16, 32):
+        raise NotImplementedError("tile_size must be 8, 16 or 32")
+    return _ShardBackFn.apply(records, backgrounds, int(width), int(height), int(tile_size), bool(fold_compensation), bool(tile_based_culling))
+
+
+# =============================================================================================
 # Inria API  (diff_gaussian_rasterization.GaussianRasterizer)
 # =============================================================================================
 class GaussianRasterizationSettings(NamedTuple):

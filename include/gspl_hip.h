@@ -443,6 +443,15 @@ int gspl_records_pack_fwd(int C, int N, const int32_t* radii, const float* means
                           const float* compensations /*nullable = 1*/, const float* opacities /*[N]*/, const float* colors /*[C,N,3]*/,
                           float* records, int32_t* slots, int64_t* ends, int64_t* host_ends /*nullable*/,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The pack in two phases (same slots, ends and records): COUNT needs the radii only — the per-camera ends are on their way to the
+ * host (`host_ends`, pinned) before the colours of the frame exist, so the exchange of the counts (gsplat_distributed_renderer.py:
+ * 141-160) overlaps the colour kernel —, SCATTER writes the records to their slots.  Workspace as gspl_records_pack_fwd (COUNT only).
+ * Additive entries (no existing signature changed: the ABI version stays). */
+int gspl_records_count_fwd(int C, int N, const int32_t* radii, int32_t* slots, int64_t* ends, int64_t* host_ends /*nullable*/,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int gspl_records_scatter_fwd(int C, int N, const int32_t* radii, const int32_t* slots, const float* means2d, const float* depths,
+                             const float* conics, const float* compensations /*nullable = 1*/, const float* opacities /*[N]*/,
+                             const float* colors /*[C,N,3]*/, float* records, void* stream);
 int gspl_records_pack_bwd(int C, int N, const int32_t* slots, const float* v_records,
                           float* v_means2d, float* v_depths, float* v_conics, float* v_compensations /*nullable*/, float* v_opacities,
                           float* v_colors, void* stream);

@@ -81,3 +81,35 @@ def test_no_visible_splat_at_all():
     assert counts == [0, 0] and records.shape == (0, 12)
     radii, means2d, *_ = ops.unpack_visible_records(records, True)
     assert radii.shape == (0,) and means2d.shape == (0, 2)
+
+
+@pytest.mark.parametrize("C,N", [(1, 5000), (3, 4097), (2, 1)])
+def test_two_phase_pack_is_the_one_phase_pack(C, N):
+    """`gspl_records_count_fwd` + `gspl_records_scatter_fwd` (counts on their way to the host before the colours exist: the
+    three-node sharded step, ops.sharded_front) leave the same slots, ends and records as `gspl_records_pack_fwd`."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import _lib as L, ops
+    results, rgbs, opac, base = _inputs(C, N, seed=C * 11 + N, batched=True)
+    records_ref, counts_ref = ops.pack_visible_records(results, rgbs, opac)
+    radii = torch.stack([r[0] for r in results]).contiguous()
+    t = {k: v.detach().contiguous() for k, v in base.items()}
+    op = opac.detach().reshape(-1).contiguous()
+    slots = torch.empty((C, N), dtype=torch.int32, device=DEV)
+    ends = torch.empty((C,), dtype=torch.int64, device=DEV)
+    host_ends = torch.empty((C,), dtype=torch.int64).pin_memory()
+    ws_bytes = L.lib().gspl_records_workspace_bytes(C, N)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=DEV)
+    records = torch.full((C * N, L.GSPL_RECORD_FLOATS), float("nan"), device=DEV)
+    with torch.cuda.device(0):
+        L.call("gspl_records_count_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(ends), host_ends.data_ptr(), L.ptr(ws), ws_bytes, L.stream())
+        torch.cuda.synchronize()
+        host = [int(v) for v in host_ends.tolist()]                 # known BEFORE the scatter is launched
+        L.call("gspl_records_scatter_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(t["means2d"]), L.ptr(t["depths"]), L.ptr(t["conics"]),
+               L.ptr(t["comps"]), L.ptr(op), L.ptr(t["rgbs"]), L.ptr(records), L.stream())
+    assert host == [int(v) for v in ends.tolist()]
+    e = [0] + host
+    assert [e[i + 1] - e[i] for i in range(C)] == counts_ref
+    assert torch.equal(records[:host[-1]].view(torch.int32), records_ref.detach().view(torch.int32))
+    assert bool(torch.isnan(records[host[-1]:]).all())               # nothing written past the last record
+    vis = radii > 0
+    assert torch.equal(slots >= 0, vis) and torch.equal(slots[vis].long(), torch.arange(host[-1], device=DEV))
