@@ -82,6 +82,8 @@ def parse():
                         "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
     p.add_argument("--no-overlap-sh-update", action="store_true",
                    help="keep the whole optimizer step on the caller's stream (default on one GPU: the shs_rest update overlaps the next frame's binning)")
+    p.add_argument("--exchange", default="counted", choices=["counted", "padded", "auto"],
+                   help="--parallelism sharded: format of the per-step record exchange (renderer option `exchange`)")
     p.add_argument("--staged-sharded-step", action="store_true",
                    help="--parallelism sharded: the stage-by-stage formulation of the step (eleven autograd nodes) instead of the three-node one")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
@@ -419,7 +421,7 @@ def main():
         N = hi - lo
         cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
         # tile_based_culling as in the reference's configs/distributed-accel.yaml (lossless here: same images and gradients)
-        renderer = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step).instantiate()
+        renderer = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step, exchange=args.exchange).instantiate()
         renderer.world_size, renderer.global_rank = world, rank
         renderer.camera_lookup = lambda idx, training: cams[idx]
         renderer.train()

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "gspl_records_pack_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_records_count_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gspl_records_scatter_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_records_pad_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_pack_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_unpack_fwd": (c_int, [ctypes.c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_unpack_bwd": (c_int, [ctypes.c_int64, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),

@@ -84,6 +84,30 @@ __global__ __launch_bounds__(256) void records_scatter_kernel(
     dst[2] = make_float4(colors[idx * 3 + 0], colors[idx * 3 + 1], colors[idx * 3 + 2], __int_as_float(radii[idx]));
 }
 
+// The FIXED-SIZE exchange format: one record per (camera, local splat), camera-major, rows of invisible splats zeroed (radius 0
+// keeps them out of the receiver's lists); slots = the row's own index for the visible ones, -1 otherwise (what
+// records_pack_bwd_kernel takes).  Nothing about it depends on a number the host would have to wait for.
+__global__ __launch_bounds__(256) void records_pad_kernel(
+    int C, int N, const int32_t* __restrict__ radii, const float* __restrict__ means2d, const float* __restrict__ depths,
+    const float* __restrict__ conics, const float* __restrict__ comps, const float* __restrict__ opacities, const float* __restrict__ colors,
+    float* __restrict__ records, int32_t* __restrict__ slots) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)C * N) return;
+    const int cam = (int)(idx / N);
+    const int g = (int)(idx - (int64_t)cam * N);
+    const int r = radii[idx];
+    const bool vis = r > 0;
+    slots[idx] = vis ? (int32_t)idx : -1;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+    if (vis) {
+        a = make_float4(means2d[idx * 2 + 0], means2d[idx * 2 + 1], depths[idx], conics[idx * 3 + 0]);
+        b = make_float4(conics[idx * 3 + 1], conics[idx * 3 + 2], comps ? comps[idx] : 1.f, opacities[g]);
+        c = make_float4(colors[idx * 3 + 0], colors[idx * 3 + 1], colors[idx * 3 + 2], __int_as_float(r));
+    }
+    float4* dst = reinterpret_cast<float4*>(records + (size_t)idx * REC);
+    dst[0] = a; dst[1] = b; dst[2] = c;
+}
+
 // Every (camera, splat) row of every gradient tensor is written (zeros for the invisible ones): no memset, and the torch ops
 // between the projection and the pack (compensation product, activations) never see uninitialised values.
 template <bool ATOMIC_OPACITY>
@@ -222,6 +246,22 @@ extern "C" int gspl_records_scatter_fwd(int C, int N, const int32_t* radii, cons
     hipLaunchKernelGGL(records_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, radii, slots, means2d, depths, conics,
                        compensations, opacities, colors, records);
     return check_launch("records_scatter_fwd");
+}
+
+extern "C" int gspl_records_pad_fwd(int C, int N, const int32_t* radii, const float* means2d, const float* depths, const float* conics,
+                                    const float* compensations, const float* opacities, const float* colors,
+                                    float* records, int32_t* slots, void* stream) {
+    using namespace gspl;
+    if (C < 0 || N < 0) return fail_arg("records_pad_fwd: bad sizes");
+    const int64_t total = (int64_t)C * N;
+    if (total == 0) return GSPL_OK;
+    if (total >= (1ll << 31)) { set_error("records_pad_fwd", "more than 2^31-1 (camera, splat) pairs"); return GSPL_ERR_UNSUPPORTED; }
+    if (!radii || !means2d || !depths || !conics || !opacities || !colors || !records || !slots)
+        return fail_arg("records_pad_fwd: NULL required pointer");
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(records_pad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, radii, means2d, depths, conics, compensations,
+                       opacities, colors, records, slots);
+    return check_launch("records_pad_fwd");
 }
 
 extern "C" int gspl_records_pack_bwd(int C, int N, const int32_t* slots, const float* v_records,

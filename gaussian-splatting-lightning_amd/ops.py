@@ -1230,37 +1230,45 @@ def _load_stages(ctx, stages):
 class _ShardFrontFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)
-    def forward(ctx, means, scales, quats, opacities, dc, rest, viewmats, Ks, centers, width, height, eps2d, degree, stash):
+    def forward(ctx, means, scales, quats, opacities, dc, rest, viewmats, Ks, centers, width, height, eps2d, degree, padded, stash):
         C = viewmats.shape[0]
         proj, sh, pack = _StageCtx(), _StageCtx(), _StageCtx()
         radii, means2d, depths, conics, comps, _, _ = _ProjectFn.forward(
             proj, means, scales, quats, viewmats, Ks, width, height, 16, 1.0, eps2d, 0.01, 1e10, 0.0, True, False, L.GSPL_CAMERA_PINHOLE, False)
-        # The pack in two phases (csrc/records.hip): the record COUNTS need the radii only, so they are on their way to the host
-        # (pinned memory, an event behind them) before the colour kernel is even launched; the host waits for them with the colour
-        # kernel and the scatter still queued on the device — the wait of the counted exchange (the reference's
-        # gsplat_distributed_renderer.py:141-160 reads the counts back after everything) no longer drains the stream.
         lib = L.lib()
         N, dev = means.shape[0], radii.device
         opac = _f32c(opacities.detach()).reshape(-1)
         assert opac.shape[0] == N
         slots = torch.empty((C, N), dtype=torch.int32, device=dev)
-        ends_dev = torch.empty((C,), dtype=torch.int64, device=dev)
-        pool = _PINNED_ENDS.setdefault(C, [])
-        host_ends = pool.pop() if pool else torch.empty((C,), dtype=torch.int64).pin_memory()
-        ws_bytes = lib.gspl_records_workspace_bytes(C, N)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        L.call("gspl_records_count_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(ends_dev), host_ends.data_ptr(), L.ptr(ws), ws_bytes, L.stream())
-        ev = _take_event(dev)
-        ev.record()
-        colors = _SHBatchedFn.forward(sh, degree, means, centers, dc, rest, radii)
         records = torch.empty((max(C * N, 1), L.GSPL_RECORD_FLOATS), dtype=torch.float32, device=dev)
-        L.call("gspl_records_scatter_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps),
-               L.ptr(opac), L.ptr(colors), L.ptr(records), L.stream())
-        ev.synchronize()                 # the split sizes of the all-to-all are needed on the host (as in the reference)
-        _EVENTS[dev.index].append(ev)
-        ends = host_ends.clone() if C * N > 0 else torch.zeros((C,), dtype=torch.int64)
-        pool.append(host_ends)
-        records = records[:int(ends[-1]) if C > 0 else 0]
+        if padded:
+            # the fixed-size format: one record per (camera, local splat), invisible rows zeroed — no count, no wait
+            colors = _SHBatchedFn.forward(sh, degree, means, centers, dc, rest, radii)
+            L.call("gspl_records_pad_fwd", C, N, L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps), L.ptr(opac),
+                   L.ptr(colors), L.ptr(records), L.ptr(slots), L.stream())
+            ends = torch.arange(1, C + 1, dtype=torch.int64) * N
+            records = records[:C * N]
+        else:
+            # The pack in two phases (csrc/records.hip): the record COUNTS need the radii only, so they are on their way to the host
+            # (pinned memory, an event behind them) before the colour kernel is even launched; the host waits for them with the
+            # colour kernel and the scatter still queued on the device — the wait of the counted exchange (the reference's
+            # gsplat_distributed_renderer.py:141-160 reads the counts back after everything) no longer drains the stream.
+            ends_dev = torch.empty((C,), dtype=torch.int64, device=dev)
+            pool = _PINNED_ENDS.setdefault(C, [])
+            host_ends = pool.pop() if pool else torch.empty((C,), dtype=torch.int64).pin_memory()
+            ws_bytes = lib.gspl_records_workspace_bytes(C, N)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            L.call("gspl_records_count_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(ends_dev), host_ends.data_ptr(), L.ptr(ws), ws_bytes, L.stream())
+            ev = _take_event(dev)
+            ev.record()
+            colors = _SHBatchedFn.forward(sh, degree, means, centers, dc, rest, radii)
+            L.call("gspl_records_scatter_fwd", C, N, L.ptr(radii), L.ptr(slots), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(comps),
+                   L.ptr(opac), L.ptr(colors), L.ptr(records), L.stream())
+            ev.synchronize()                 # the split sizes of the all-to-all are needed on the host (as in the reference)
+            _EVENTS[dev.index].append(ev)
+            ends = host_ends.clone() if C * N > 0 else torch.zeros((C,), dtype=torch.int64)
+            pool.append(host_ends)
+            records = records[:int(ends[-1]) if C > 0 else 0]
         pack.save_for_backward(slots)
         pack.cfg = (C, N, True, tuple(opacities.shape))
         # the pack stage's state travels in the stash: the exchange node's backward runs that stage's backward
@@ -1289,7 +1297,7 @@ class _ShardFrontFn(torch.autograd.Function):
         v_means = v_scales = v_quats = None
         if v_means2d is not None or v_conics is not None:
             v_means, v_scales, v_quats = _ProjectFn.backward(proj, None, v_means2d, v_depths, v_conics, v_comps, None, None)[:3]
-        return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 8
+        return (v_means, v_scales, v_quats, v_opac, v_dc, v_rest) + (None,) * 9
 
 
 class _ShardExchangeFn(torch.autograd.Function):
@@ -1349,17 +1357,20 @@ class _ShardBackFn(torch.autograd.Function):
 
 def sharded_front(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, shs_dc: Tensor, shs_rest: Optional[Tensor],
                   viewmats: Tensor, Ks: Tensor, camera_centers: Tensor, width: int, height: int, eps2d: float, sh_degree: int,
-                  stash: dict):
+                  stash: dict, padded: bool = False):
     """This rank's shard seen from C cameras, packed for the exchange — `fully_fused_projection(calc_compensations=True)` +
     `sh_view_colors_batched` + `pack_visible_records` as ONE autograd node (means are detached for the colours, as
     gsplat_distributed_renderer.py:417 does).  viewmats [C,4,4], Ks [C,3,3], camera_centers [C,3]; `stash`: a dict private to
     this step, handed to `sharded_exchange` as well.
+    padded=False: the records of the VISIBLE splats, compacted (counted exchange: the call waits for the per-camera counts — which
+    leave the device before the colour kernel runs); padded=True: one record per (camera, local splat), invisible rows zeroed
+    (fixed-size exchange: no count, no wait).
     Returns (records [M,12] grouped by camera, counts per camera (python list), radii [C,N] i32, means2d [C,N,2], depths [C,N],
     conics [C,N,3], compensations [C,N]).  Only `records` and `means2d` carry gradients — means2d through `sharded_exchange`'s
     `xys` argument; radii / depths / conics / compensations are handed out for inspection (detached)."""
     records, ends, radii, means2d, depths, conics, comps = _ShardFrontFn.apply(
         means, scales, quats, opacities, shs_dc, shs_rest, viewmats, Ks, camera_centers, int(width), int(height), float(eps2d),
-        int(sh_degree), stash)
+        int(sh_degree), bool(padded), stash)
     e = [0] + [int(v) for v in ends.tolist()]
     return records, [e[i + 1] - e[i] for i in range(len(e) - 1)], radii, means2d, depths, conics, comps
 

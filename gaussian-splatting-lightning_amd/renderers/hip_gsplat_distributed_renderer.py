@@ -48,8 +48,8 @@ class HipGSplatDistributedRenderer(RendererConfig):
     exchange: str = "counted"
     padded_min_visible: float = 0.5
     # The step as three autograd nodes (`ops.sharded_front` / `sharded_exchange` / `sharded_back`: project + colours + pack, the
-    # all-to-all, unpack + bin + composite) instead of eleven — same kernels, same numbers, less host work per step.  Taken for the
-    # counted exchange on the GPU when nothing is overridden (`get_rgbs`) and only "rgb" is asked for; that path hands out
+    # all-to-all, unpack + bin + composite) instead of eleven — same kernels, same numbers, less host work per step.  Taken on
+    # the GPU (either exchange format) when nothing is overridden (`get_rgbs`) and only "rgb" is asked for; that path hands out
     # depths / conics / compensations of `projection_results_list` detached.  False: always the stage-by-stage formulation.
     fused_step: bool = True
 
@@ -178,6 +178,23 @@ class HipGSplatDistributedRendererImpl(Renderer):
                 return collective(payload, dev, group)
         return collective(payload, dev, group)
 
+    def _post_visible_count(self, vis: torch.Tensor, pairs: int):
+        """A padded step's visible count, for the next steps' votes: summed on the device, copied to pinned memory, an event
+        behind it — picked up by `_poll_visible` when it has arrived, never waited for."""
+        with torch.no_grad():
+            n_vis = vis.sum(dtype=torch.int64).reshape(1)
+            word = self.__dict__.get("_visible_word")
+            if word is None:
+                word = self.__dict__["_visible_word"] = torch.empty((1,), dtype=torch.int64).pin_memory()
+            stale = self._visible_pending
+            if stale is not None:           # a count nobody picked up: its event goes back to the pool once it has fired
+                stale[0].synchronize()
+                ops._EVENTS.setdefault(stale[3], []).append(stale[0])
+            word.copy_(n_vis, non_blocking=True)
+            ev = ops._take_event(vis.device)
+            ev.record()
+            self._visible_pending = (ev, word, pairs, vis.device.index)
+
     def _exchange_format(self) -> str:
         """Identical on every rank: a function of the configuration and of the gathered rows only."""
         c = self.config
@@ -259,7 +276,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
             peer_counts = [r[1] for r in self._peer_rows]
             pairs = max(len(cameras) * n_local, 1)
             if self._takes_fused_step(opacities, fmt, render_types):
-                return self._forward_fused(cameras, rank, pc, scales, opacities, bg_color, scaling_modifier, exchanging, pairs)
+                return self._forward_fused(cameras, rank, pc, scales, opacities, bg_color, scaling_modifier, exchanging, pairs, fmt, peer_counts)
             with self._span("project"):
                 project = self.batch_project if self.batched else self.non_batch_project
                 projection_results_list, rgb_list = project(cameras, pc, scales, scaling_modifier)
@@ -273,19 +290,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
                     # one record per (camera, local splat): sizes known beforehand, no read-back; the visible count follows through
                     # pinned memory for the next steps' votes
                     records = ops.pack_all_records(projection_results_list, rgb_list, opacities)
-                    with torch.no_grad():
-                        n_vis = torch.stack([r[5] for r in projection_results_list]).sum(dtype=torch.int64).reshape(1)
-                        word = self.__dict__.get("_visible_word")
-                        if word is None:
-                            word = self.__dict__["_visible_word"] = torch.empty((1,), dtype=torch.int64).pin_memory()
-                        stale = self._visible_pending
-                        if stale is not None:           # a count nobody picked up: its event goes back to the pool once it has fired
-                            stale[0].synchronize()
-                            ops._EVENTS.setdefault(stale[3], []).append(stale[0])
-                        word.copy_(n_vis, non_blocking=True)
-                        ev = ops._take_event(opacities.device)
-                        ev.record()
-                        self._visible_pending = (ev, word, pairs, opacities.device.index)
+                    self._post_visible_count(torch.stack([r[5] for r in projection_results_list]), pairs)
                     if exchanging:
                         records = D.all_to_all_rows(records, [n_local] * len(cameras), peer_counts, self.group)
                     radii, means2d, depths, conics, opac, rgbs = ops.unpack_visible_records(records, self.config.anti_aliased)
@@ -345,10 +350,10 @@ class HipGSplatDistributedRendererImpl(Renderer):
         }
 
     def _takes_fused_step(self, opacities, fmt, render_types) -> bool:
-        return (self.config.fused_step and opacities.is_cuda and fmt == "counted" and self.batched and "hard_inverse_depth" not in render_types
+        return (self.config.fused_step and opacities.is_cuda and self.batched and "hard_inverse_depth" not in render_types
                 and type(self).get_rgbs is HipGSplatDistributedRendererImpl.get_rgbs)
 
-    def _forward_fused(self, cameras, rank, pc, scales, opacities, bg_color, scaling_modifier, exchanging, pairs):
+    def _forward_fused(self, cameras, rank, pc, scales, opacities, bg_color, scaling_modifier, exchanging, pairs, fmt, peer_counts):
         """The same step as three autograd nodes (see `fused_step`); called inside the "forward" span."""
         c = self.config
         W, H = camera_hw(cameras[0])
@@ -359,7 +364,7 @@ class HipGSplatDistributedRendererImpl(Renderer):
             stash = {}
             records, send_counts, radii, means2d, depths, conics, comps = ops.sharded_front(
                 pc.get_means(), scales, pc.get_rotations(), opacities, pc.get_shs_dc(), pc.get_shs_rest(), viewmats, Ks, centers,
-                W, H, c.filter_2d_kernel_size, pc.active_sh_degree, stash)
+                W, H, c.filter_2d_kernel_size, pc.active_sh_degree, stash, padded=(fmt == "padded"))
             vis = radii > 0
             xys = ops.unbind_cameras(means2d)
             projection_results_list = [(radii[i], xys[i], depths[i], conics[i], comps[i], vis[i]) for i in range(len(cameras))]
@@ -367,14 +372,21 @@ class HipGSplatDistributedRendererImpl(Renderer):
                 if x.requires_grad:
                     x.retain_grad()                 # per-camera xys: what the distributed density controller reads
         with self._span("rasterizer_required_data_all2all"):
-            self.last_exchange = "counted"
-            self._visible_permille, self._visible_pending = int(1000 * sum(send_counts) // pairs), None
+            self.last_exchange = fmt
             route = None
-            if exchanging:
-                # the counts were on the host before the colour kernel and the scatter had run (two-phase pack): on RCCL their
-                # exchange goes out on the control stream, next to those kernels instead of behind them
-                recv_counts = self._on_control_stream(D.exchange_counts, send_counts, records.device, self.group)
-                route = D.all_to_all_route(send_counts, recv_counts, self.group)
+            if fmt == "padded":
+                # every size was known before the step (the peers' Gaussian counts came with the camera ids): no count exchange,
+                # no read-back; the visible share follows through pinned memory for the next steps' votes
+                self._post_visible_count(vis, pairs)
+                if exchanging:
+                    route = D.all_to_all_route(send_counts, peer_counts, self.group)
+            else:
+                self._visible_permille, self._visible_pending = int(1000 * sum(send_counts) // pairs), None
+                if exchanging:
+                    # the counts were on the host before the colour kernel and the scatter had run (two-phase pack): on RCCL their
+                    # exchange goes out on the control stream, next to those kernels instead of behind them
+                    recv_counts = self._on_control_stream(D.exchange_counts, send_counts, records.device, self.group)
+                    route = D.all_to_all_route(send_counts, recv_counts, self.group)
             records = ops.sharded_exchange(records, stash, xys, route)
         with self._span("rasterize"):
             local = cameras[rank]

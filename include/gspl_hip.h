@@ -452,6 +452,12 @@ int gspl_records_count_fwd(int C, int N, const int32_t* radii, int32_t* slots, i
 int gspl_records_scatter_fwd(int C, int N, const int32_t* radii, const int32_t* slots, const float* means2d, const float* depths,
                              const float* conics, const float* compensations /*nullable = 1*/, const float* opacities /*[N]*/,
                              const float* colors /*[C,N,3]*/, float* records, void* stream);
+/* The fixed-size exchange format: one record per (camera, local splat), camera-major, rows of invisible splats zeroed (radius 0
+ * keeps them out of the receiver's lists); slots[i] = i for the visible rows, -1 otherwise (input of gspl_records_pack_bwd).  No
+ * count, no workspace, nothing the host has to wait for: every size of the exchange is known before the step starts. */
+int gspl_records_pad_fwd(int C, int N, const int32_t* radii, const float* means2d, const float* depths, const float* conics,
+                         const float* compensations /*nullable = 1*/, const float* opacities /*[N]*/, const float* colors /*[C,N,3]*/,
+                         float* records /*[C*N,12]*/, int32_t* slots /*[C,N]*/, void* stream);
 int gspl_records_pack_bwd(int C, int N, const int32_t* slots, const float* v_records,
                           float* v_means2d, float* v_depths, float* v_conics, float* v_compensations /*nullable*/, float* v_opacities,
                           float* v_colors, void* stream);

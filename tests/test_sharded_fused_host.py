@@ -88,16 +88,20 @@ def _scene(n=400):
     return model, FakeCamera(cam, "cpu")
 
 
-def test_three_node_step_launch_order_and_gradient_routes(recorded_abi, monkeypatch):
+@pytest.mark.parametrize("exchange", ["counted", "padded"])
+def test_three_node_step_launch_order_and_gradient_routes(recorded_abi, monkeypatch, exchange):
     from gspl_amd import ops
     from gspl_amd.renderers import HipGSplatDistributedRenderer
     from gspl_amd.renderers.hip_gsplat_distributed_renderer import HipGSplatDistributedRendererImpl
     calls = recorded_abi
     monkeypatch.setattr(HipGSplatDistributedRendererImpl, "_takes_fused_step",
-                        lambda self, opacities, fmt, render_types: self.config.fused_step and fmt == "counted" and "hard_inverse_depth" not in render_types)
+                        lambda self, opacities, fmt, render_types: self.config.fused_step and "hard_inverse_depth" not in render_types)
+    monkeypatch.setattr(HipGSplatDistributedRendererImpl, "_post_visible_count", lambda self, vis, pairs: None)     # (a CUDA event)
     model, cam = _scene()
     N = model.means.shape[0]
-    renderer = HipGSplatDistributedRenderer(tile_based_culling=True).instantiate()
+    renderer = HipGSplatDistributedRenderer(tile_based_culling=True, exchange=exchange).instantiate()
+    # the fixed-size format has no count phase: colours, then one kernel that writes every (camera, splat) row
+    front = FWD[:1] + ["gspl_sh_fwd_batched", "gspl_records_pad_fwd"] + FWD[4:] if exchange == "padded" else FWD
     renderer.camera_lookup = lambda idx, training: cam
     renderer.train()
     bg = torch.zeros(3)
@@ -107,17 +111,17 @@ def test_three_node_step_launch_order_and_gradient_routes(recorded_abi, monkeypa
             t.grad = None
         out = renderer(cam, model, bg)
         assert set(out) == {"render", "hard_inverse_depth", "cameras", "projection_results_list", "visible_mask_list", "xys_grad_scale_required"}
-        assert out["render"].shape == (3, 64, 96) and out["xys_grad_scale_required"] is True and renderer.last_exchange == "counted"
+        assert out["render"].shape == (3, 64, 96) and out["xys_grad_scale_required"] is True and renderer.last_exchange == exchange
         (radii, xys, depths, conics, comps, vis), = out["projection_results_list"]
         assert radii.shape == (N,) and radii.dtype == torch.int32 and xys.shape == (N, 2) and depths.shape == (N,)
         assert conics.shape == (N, 3) and comps.shape == (N,) and vis.dtype == torch.bool and out["visible_mask_list"][0] is vis
         assert xys.requires_grad and not depths.requires_grad and not conics.requires_grad
         if frame == 0:
             # no guess of the list length yet: count, wait, emit, sort, composite
-            assert calls == FWD + ["gspl_bin_emit", "gspl_bin_sort", "gspl_composite_fwd"], calls
+            assert calls == front + ["gspl_bin_emit", "gspl_bin_sort", "gspl_composite_fwd"], calls
         else:
             # speculative emission, the sort reads the length on the device, compositing launched before the host looks at the count
-            assert calls == FWD + ["gspl_bin_emit", "gspl_bin_sort_device_count", "gspl_composite_fwd"], calls
+            assert calls == front + ["gspl_bin_emit", "gspl_bin_sort_device_count", "gspl_composite_fwd"], calls
         del calls[:]
         out["render"].sum().backward()
         assert calls == BWD, calls
