@@ -82,7 +82,7 @@ def parse():
                         "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
     p.add_argument("--no-overlap-sh-update", action="store_true",
                    help="keep the whole optimizer step on the caller's stream (default on one GPU: the shs_rest update overlaps the next frame's binning)")
-    p.add_argument("--exchange", default="counted", choices=["counted", "padded", "auto"],
+    p.add_argument("--exchange", default="auto", choices=["counted", "padded", "auto"],
                    help="--parallelism sharded: format of the per-step record exchange (renderer option `exchange`)")
     p.add_argument("--staged-sharded-step", action="store_true",
                    help="--parallelism sharded: the stage-by-stage formulation of the step (eleven autograd nodes) instead of the three-node one")

@@ -39,13 +39,15 @@ class HipGSplatDistributedRenderer(RendererConfig):
     redistribute_until: int = 15_000
     redistribute_threshold: float = 1.1
     # Format of the per-step exchange of rasterizer inputs.  "counted": the records of the VISIBLE splats, compacted, after an
-    # exchange of their counts (the reference's scheme: two device read-backs per step).  "padded": one record per (camera, local
-    # splat), invisible rows zeroed — every size is known beforehand, so the step has no read-back in the exchange, at
-    # 1 / (visible fraction) times the bytes.  "auto": padded while at least `padded_min_visible` of the (camera, splat) pairs of
-    # EVERY rank were visible in its last step, else counted (the ranks vote in the per-step all-gather of the camera ids).
-    # Default "counted": measured on one MI355X (W = 1, and every collective issued to RCCL in a one-rank group) the step is bound
-    # by the host's launch work either way (1.51 / 1.99 ms padded against 1.50 / 1.93 ms counted), so the smaller messages win.
-    exchange: str = "counted"
+    # exchange of their counts (the reference's scheme; here the counts leave the device before the colour kernel runs and their
+    # exchange rides a control stream, but the host still waits for them and for the peers').  "padded": one record per (camera,
+    # local splat), invisible rows zeroed — every size is known beforehand (the peers' Gaussian counts travel with the camera ids),
+    # so the exchange has no count collective and no read-back, at 1 / (visible fraction) times the bytes.  "auto" (default): padded
+    # while at least `padded_min_visible` of the (camera, splat) pairs of EVERY rank were visible in its last step, else counted (the
+    # ranks vote in the per-step all-gather of the camera ids; the first step is counted).  Measured on one MI355X with the three-node
+    # step (S-1080p-1M, 95 % visible; profiles/r04b_*): 1.42 ms padded against 1.46 ms counted at W = 1, 1.75-1.78 against 1.83-1.85 ms
+    # with every collective issued to RCCL in a one-rank group.
+    exchange: str = "auto"
     padded_min_visible: float = 0.5
     # The step as three autograd nodes (`ops.sharded_front` / `sharded_exchange` / `sharded_back`: project + colours + pack, the
     # all-to-all, unpack + bin + composite) instead of eleven — same kernels, same numbers, less host work per step.  Taken on

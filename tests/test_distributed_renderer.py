@@ -163,6 +163,7 @@ def _close(got, ref, rel, name, tiered=False):
 
 
 def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
+    exchange, _, form = exchange.partition("-")           # "padded-staged": the stage-by-stage formulation of the step
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (HERE, os.path.dirname(HERE)):
@@ -192,7 +193,7 @@ def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
             p = g["params"][0]
             opt.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.ones_like(p), "exp_avg_sq": torch.ones_like(p)}
         module = _Module(model, [opt], world, rank, dev)
-        renderer = HipGSplatDistributedRenderer(exchange=exchange).instantiate()
+        renderer = HipGSplatDistributedRenderer(exchange=exchange, fused_step=(form != "staged")).instantiate()
         assert renderer.training_setup(module) == (None, None)
         assert module.density_changes == 1 and renderer.world_size == world and renderer.global_rank == rank
         assert model.n_gaussians == hi - lo and torch.equal(model.get_property("ids").cpu(), ids[lo:hi])
@@ -366,8 +367,10 @@ def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["auto", "padded"])
+@pytest.mark.parametrize("exchange", ["auto", "padded", "auto-staged"])
 def test_world2_sharded_renderer_shared_gpu(tmp_path, exchange):
+    """On the GPU the step runs as three autograd nodes (ops.sharded_front / sharded_exchange / sharded_back); "auto-staged" keeps
+    the stage-by-stage formulation (what a subclass overriding `get_rgbs` and the extra render types take) under the same checks."""
     _run(tmp_path, True, exchange=exchange)
 
 
@@ -390,7 +393,7 @@ def test_exchange_format_is_a_function_of_the_gathered_rows_only():
             assert r._exchange_format() == fixed
     with pytest.raises(ValueError):
         HipGSplatDistributedRenderer(exchange="compressed").instantiate()
-    assert HipGSplatDistributedRenderer().exchange == "counted"          # the reference's scheme unless asked otherwise
+    assert HipGSplatDistributedRenderer().exchange == "auto"             # counted (the reference's scheme) until every rank has voted
 
 
 def test_camera_batch_cache_is_keyed_on_tensor_identity_and_version():

@@ -113,3 +113,24 @@ def test_two_phase_pack_is_the_one_phase_pack(C, N):
     assert bool(torch.isnan(records[host[-1]:]).all())               # nothing written past the last record
     vis = radii > 0
     assert torch.equal(slots >= 0, vis) and torch.equal(slots[vis].long(), torch.arange(host[-1], device=DEV))
+
+
+@pytest.mark.parametrize("C,N", [(1, 5000), (3, 4097), (2, 1)])
+def test_pad_kernel_is_the_torch_formulation_of_the_fixed_size_format(C, N):
+    """`gspl_records_pad_fwd` (three-node sharded step, padded exchange) writes the rows `ops.pack_all_records` builds with
+    concat + where, bit for bit, and the identity slots its backward takes."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import _lib as L, ops
+    results, rgbs, opac, base = _inputs(C, N, seed=C * 13 + N, batched=True)
+    ref = ops.pack_all_records(results, rgbs, opac).detach()
+    radii = torch.stack([r[0] for r in results]).contiguous()
+    t = {k: v.detach().contiguous() for k, v in base.items()}
+    op = opac.detach().reshape(-1).contiguous()
+    records = torch.full((C * N, L.GSPL_RECORD_FLOATS), float("nan"), device=DEV)
+    slots = torch.empty((C, N), dtype=torch.int32, device=DEV)
+    with torch.cuda.device(0):
+        L.call("gspl_records_pad_fwd", C, N, L.ptr(radii), L.ptr(t["means2d"]), L.ptr(t["depths"]), L.ptr(t["conics"]), L.ptr(t["comps"]),
+               L.ptr(op), L.ptr(t["rgbs"]), L.ptr(records), L.ptr(slots), L.stream())
+    assert torch.equal(records.view(torch.int32), ref.view(torch.int32))
+    ident = torch.arange(C * N, dtype=torch.int32, device=DEV).reshape(C, N)
+    assert torch.equal(slots, torch.where(radii > 0, ident, -1))

@@ -234,8 +234,8 @@ def test_distributed_renderer_world1_matches_v1():
     assert xys.grad is not None and xys.grad.shape == (params[0].shape[0], 2)
 
 
-@pytest.mark.parametrize("culling", [False, True])
-def test_distributed_renderer_three_node_step_equals_the_staged_one(culling):
+@pytest.mark.parametrize("culling,exchange", [(False, "counted"), (True, "counted"), (True, "padded")])
+def test_distributed_renderer_three_node_step_equals_the_staged_one(culling, exchange):
     """`fused_step` (ops.sharded_front / sharded_exchange / sharded_back: three autograd nodes) launches the same kernels on the same
     buffers as the stage-by-stage formulation: the image and every forward output are bit-identical, the gradients differ by the
     run-to-run spread of the compositing backward's atomics only, and the per-camera xys gradient (what the distributed density
@@ -245,7 +245,7 @@ def test_distributed_renderer_three_node_step_equals_the_staged_one(culling):
     params, cam, wimg, bg = _scene(seed=36, n=5000)
     camera = FakeCamera(cam, DEV)
     models = [FakeGaussianModel(*[p.to(DEV) for p in params]) for _ in range(2)]
-    renderers = [HipGSplatDistributedRenderer(tile_based_culling=culling, fused_step=f).instantiate() for f in (True, False)]
+    renderers = [HipGSplatDistributedRenderer(tile_based_culling=culling, fused_step=f, exchange=exchange).instantiate() for f in (True, False)]
     for frame in range(2):
         outs = []
         for model, renderer in zip(models, renderers):
@@ -256,6 +256,7 @@ def test_distributed_renderer_three_node_step_equals_the_staged_one(culling):
             (out["render"] * wimg.to(DEV)).sum().backward()
             outs.append(out)
         fused, staged = outs
+        assert renderers[0].last_exchange == renderers[1].last_exchange == exchange
         assert torch.equal(fused["render"], staged["render"])
         for a, b in zip(fused["projection_results_list"][0], staged["projection_results_list"][0]):
             assert torch.equal(a.detach(), b.detach())
