@@ -1204,10 +1204,6 @@ class _StageCtx:
         pass
 
 
-class _Ref:
-    """Something attributes can be attached to (the stage wrappers attach side-channel results to the caller's tensor)."""
-
-
 def _save_stages(ctx, stages):
     """Keep the tensors the stage bodies saved through the REAL context (no attribute references to output tensors: those would
     be reference cycles through grad_fn), with the split points to rebuild the stand-in contexts in the backward."""
@@ -1331,7 +1327,6 @@ class _ShardBackFn(torch.autograd.Function):
     @_guarded(1)
     def forward(ctx, records, backgrounds, width, height, tile_size, fold_compensation, cull):
         unpack, comp = _StageCtx(), _StageCtx()
-        comp.means2d_ref = _Ref()
         radii, means2d, depths, conics, opac, colors = _UnpackRecordsFn.forward(unpack, records, fold_compensation)
         flat, offsets = bin_gaussians(means2d, depths, radii, height, width, tile_size, conics=conics if cull else None,
                                       opacities=opac if cull else None, lazy=True)
@@ -1348,8 +1343,6 @@ class _ShardBackFn(torch.autograd.Function):
         unpack, comp = ctx.stages
         _load_stages(ctx, ctx.stages)
         comp.needs_input_grad = (False, False, False, False, ctx.needs_input_grad[1])
-        if comp.means2d_ref is None:
-            comp.means2d_ref = _Ref()
         v_means2d, v_conics, v_colors, v_opac, v_bg = _CompositeFn.backward(comp, v_out, v_alphas)[:5]
         v_records, _ = _UnpackRecordsFn.backward(unpack, None, v_means2d, None, v_conics, v_opac, v_colors)
         return v_records, v_bg, None, None, None, None, None
