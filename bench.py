@@ -522,6 +522,8 @@ def main():
         # timed steps is what a training loop never has.
         import gc
         early = min(warmup, 2) if os.environ.get("GSPL_BENCH_GC_LATE") is None else warmup
+        for _ in range(int(os.environ.get("GSPL_BENCH_PREHEAT", "0"))):      # diagnostic: extra untimed steps ahead of the warm-up
+            full_step(force_reduce=True)
         for _ in range(early):
             full_step(force_reduce=True)
         gc.collect()
