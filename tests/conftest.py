@@ -32,7 +32,7 @@ def pytest_configure(config):
 _FIRST = ["test_abi", "test_oracle_golden", "test_oracle_composite", "test_hip_parity", "test_metric_point_parity", "test_locked_parity", "test_renderers_gpu",
           "test_tile_sizes", "test_sort", "test_sh_batched", "test_camera_models", "test_backward_spread", "test_loss", "test_knn", "test_scores",
           "test_records", "test_adam", "test_density", "test_formats", "test_upstream_golden"]
-_LAST = ["test_training_loop", "test_package_shims", "test_bench_contract", "test_distributed_gloo", "test_masked_replica", "test_allreduce_step",
+_LAST = ["test_training_loop", "test_reference_lightning_loop", "test_package_shims", "test_bench_contract", "test_distributed_gloo", "test_masked_replica", "test_allreduce_step",
          "test_rccl_single_rank", "test_distributed_renderer"]
 
 

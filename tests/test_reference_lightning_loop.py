@@ -1,0 +1,79 @@
+"""The reference's UNCHANGED LightningModule trains with this repository's renderers plugged in.
+
+`internal/gaussian_splatting.py` — `GaussianSplatting.setup("fit")`, `configure_optimizers`, `on_train_start`, and per batch
+`on_train_batch_start` / `training_step` (:329-397) / `on_train_batch_end` — is imported from the reference tree and executed as it is,
+with the reference's own `Cameras`, `VanillaGaussian` (its `setup_from_pcd`, optimizers, LR scheduler, SH-degree schedule),
+`VanillaMetrics` (0.8 L1 + 0.2 (1 - SSIM)), `VanillaDensityController` (densify / prune / opacity reset) and `VanillaOptStrategy`.
+`lightning` itself is not installed in this container, so a stand-in of the few Lightning facilities that module touches drives it
+(tests/lightning_standin.py: hparams, optimizer wrappers whose steps the trainer counts, manual backward, logging) — in a process of
+its own (tests/reference_loop_worker.py), so that the stand-in never meets the other tests' imports of the reference tree.
+
+Two selections of the renderer, as a user would make them:
+  * `--model.renderer gspl_amd.renderers.HipVanillaRenderer` — the plugin, which inside the reference subclasses the reference's
+    own `Renderer` (the `isinstance` test of gaussian_splatting.py:75-77 is asserted in the worker);
+  * nothing at all — the reference's own `GSPlatRenderer`, running on the `gsplat` stand-in package of `gspl_amd.compat`.
+No GPU here and no reference tree on the GPU box: the native ops under both are the oracle stages (the HIP-vs-oracle parity of those
+ops is what the `-m gpu` tests establish).  Checked: the loop runs through densifications, opacity reset and SH-degree raises, the
+loss falls, the trainer's step count advances once per batch, the density controller consumed `viewspace_points.grad` / `radii`,
+the LR scheduler ran, and the final PSNR is that of a scene being learnt."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_ROOT = os.environ.get("GSPL_REFERENCE_ROOT", "/root/reference")
+needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF_ROOT, "internal", "gaussian_splatting.py")),
+                                     reason="reference tree not present")
+
+
+def _run(variant, steps):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "reference_loop_worker.py"), REF_ROOT, str(steps), variant],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@needs_reference
+@pytest.mark.parametrize("variant,steps", [("hip-vanilla", 200), ("reference-gsplat-on-shims", 200)])
+def test_unchanged_lightning_module_trains_with_the_renderers_of_this_repository(variant, steps):
+    d = _run(variant, steps)
+    assert d["inside_reference"] is True
+    assert d["renderer"] == ("gspl_amd.renderers.hip_vanilla_renderer.HipVanillaRenderer" if variant == "hip-vanilla"
+                             else "internal.renderers.gsplat_renderer.GSPlatRenderer")
+    losses, counts = d["losses"], d["counts"]
+    assert len(losses) == steps and all(np.isfinite(losses))
+    first, last = float(np.mean(losses[:12])), float(np.mean(losses[-12:]))
+    changes = sum(1 for a, b in zip(counts, counts[1:]) if a != b)
+    print(f"{variant}: loss {first:.4f} -> {last:.4f}, N {counts[0]} -> {counts[-1]} ({changes} changes), SH degree {d['sh_degrees'][-1]}, "
+          f"PSNR {d['psnr']:.2f} dB")
+    assert last < 0.7 * first, (first, last)
+    assert counts[0] == 2000 and changes >= 2 and max(counts) > 2 * counts[0]      # densify_from_iter 40, every 40 steps
+    assert d["sh_degrees"][0] == 0 and d["sh_degrees"][-1] >= 2                      # sh_degree_up_interval 60
+    assert d["accum_max"] > 0.0 and d["radii_max"] >= 1.0                           # update_states saw the plugin's grad and radii
+    assert d["logged_lr_rows"] >= 2 and d["means_lr_last"] < d["means_lr_first"]    # lr logged every 100 steps; the scheduler stepped
+    assert d["psnr"] > 22.0
+
+
+def test_launcher_registers_the_stand_ins_before_the_entry_point_is_imported(tmp_path):
+    """`python -m gspl_amd.launch <script> args...`: on a machine without the CUDA packages the reference's entry points import
+    `diff_gaussian_rasterization` before their CLI has seen `--model.renderer`; the launcher registers the stand-ins first and then
+    runs the script as `python <script> args...` would (argv, `__main__`, the script's directory on sys.path)."""
+    script = tmp_path / "entry.py"
+    (tmp_path / "sibling.py").write_text("VALUE = 41\n")
+    script.write_text(
+        "import sys, json\n"
+        "from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer\n"
+        "from simple_knn._C import distCUDA2\n"
+        "import sibling\n"
+        "print(json.dumps({'argv': sys.argv, 'name': __name__, 'doc': sys.modules['diff_gaussian_rasterization'].__doc__, 'sib': sibling.VALUE}))\n")
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "gspl_amd.launch", str(script), "fit", "--model.renderer", "x"], capture_output=True, text=True,
+                       env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["argv"] == [str(script), "fit", "--model.renderer", "x"] and d["name"] == "__main__" and d["sib"] == 41
+    assert "gspl_amd" in d["doc"]
