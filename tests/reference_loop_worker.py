@@ -13,7 +13,9 @@ There is no GPU in the container that holds the reference tree and no reference 
 executes.  Prints one JSON line: per-step loss and Gaussian count, what the density controller accumulated, final PSNR.
 A second variant swaps nothing at all: the reference's own `GSPlatRenderer` (internal/renderers/gsplat_renderer.py, unedited) on
 the `gsplat` stand-in package of `gspl_amd.compat`, whose ops are routed to the oracle stages the same way.
-usage: python reference_loop_worker.py <reference root> <steps> [hip-vanilla | reference-gsplat-on-shims]
+A third one selects the Gaussian-sharded multi-GPU plugin (`HipGSplatDistributedRenderer`, world size 1: `training_setup`, the
+per-camera `projection_results_list` contract) together with the reference's `DistributedVanillaDensityController`.
+usage: python reference_loop_worker.py <reference root> <steps> [hip-vanilla | reference-gsplat-on-shims | hip-distributed]
 """
 import json
 import math
@@ -95,8 +97,17 @@ def orbit_cameras(n=6):
 
 def main():
     assert gspl_amd.renderers.renderer.INSIDE_REFERENCE, "the plugins must subclass the reference's own Renderer here"
+    density_cls = VanillaDensityController
     if VARIANT == "hip-vanilla":
         plugin = HipVanillaRenderer()
+    elif VARIANT == "hip-distributed":
+        # configs/distributed.yaml: the sharded renderer + its density controller (one rank here; ops of its host path -> oracle stages)
+        from gspl_amd.renderers import HipGSplatDistributedRenderer
+        from internal.density_controllers.distributed_vanilla_density_controller import DistributedVanillaDensityController
+        import test_distributed_renderer
+        test_distributed_renderer._install_oracle_ops()
+        plugin = HipGSplatDistributedRenderer().instantiate()
+        density_cls = DistributedVanillaDensityController
     else:
         # the reference's own class, importable here only because `gsplat` resolves to the stand-in package
         from internal.renderers.gsplat_renderer import GSPlatRenderer
@@ -136,7 +147,7 @@ def main():
     torch.Tensor.cuda = lambda self, *a, **k: self            # `setup_from_pcd` moves the points to "cuda" for distCUDA2 (vanilla_gaussian.py:124)
 
     out_dir = tempfile.mkdtemp(prefix="gspl_ref_loop_")
-    density = VanillaDensityController(percent_dense=0.01, densification_interval=40, opacity_reset_interval=150, densify_from_iter=40,
+    density = density_cls(percent_dense=0.01, densification_interval=40, opacity_reset_interval=150, densify_from_iter=40,
                                        densify_until_iter=260, densify_grad_threshold=0.00012, cull_opacity_threshold=0.005)
     gaussian = VanillaGaussian(sh_degree=3)
     gaussian.optimization.sh_degree_up_interval = 60
@@ -149,7 +160,8 @@ def main():
 
     ns = lambda **kw: type("NS", (), kw)()
     datamodule = ns(point_cloud=ns(xyz=xyz, rgb=rgb), prune_extent=EXTENT,
-                    dataparser_outputs=ns(camera_extent=EXTENT, train_set=ns(cameras=cameras, image_names=[f"{i:03d}" for i in range(len(cameras))])),
+                    dataparser_outputs=ns(camera_extent=EXTENT, train_set=ns(cameras=cameras, image_names=[f"{i:03d}" for i in range(len(cameras))]),
+                                          val_set=ns(cameras=cameras)),
                     set_device=lambda device: None)
     trainer = lightning_standin.Trainer(datamodule, max_steps=STEPS)
     trainer.fit_setup(module)

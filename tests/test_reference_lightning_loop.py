@@ -8,11 +8,14 @@ with the reference's own `Cameras`, `VanillaGaussian` (its `setup_from_pcd`, opt
 (tests/lightning_standin.py: hparams, optimizer wrappers whose steps the trainer counts, manual backward, logging) — in a process of
 its own (tests/reference_loop_worker.py), so that the stand-in never meets the other tests' imports of the reference tree.
 
-Two selections of the renderer, as a user would make them:
+Three selections of the renderer, as a user would make them:
   * `--model.renderer gspl_amd.renderers.HipVanillaRenderer` — the plugin, which inside the reference subclasses the reference's
     own `Renderer` (the `isinstance` test of gaussian_splatting.py:75-77 is asserted in the worker);
-  * nothing at all — the reference's own `GSPlatRenderer`, running on the `gsplat` stand-in package of `gspl_amd.compat`.
-No GPU here and no reference tree on the GPU box: the native ops under both are the oracle stages (the HIP-vs-oracle parity of those
+  * nothing at all — the reference's own `GSPlatRenderer`, running on the `gsplat` stand-in package of `gspl_amd.compat`;
+  * `configs/distributed.yaml` with `gspl_amd.renderers.HipGSplatDistributedRenderer` in place of its renderer line — the
+    Gaussian-sharded plugin (its `training_setup`, per-camera `projection_results_list`) with the reference's own
+    `DistributedVanillaDensityController`, one rank.
+No GPU here and no reference tree on the GPU box: the native ops under all three are the oracle stages (the HIP-vs-oracle parity of those
 ops is what the `-m gpu` tests establish).  Checked: the loop runs through densifications, opacity reset and SH-degree raises, the
 loss falls, the trainer's step count advances once per batch, the density controller consumed `viewspace_points.grad` / `radii`,
 the LR scheduler ran, and the final PSNR is that of a scene being learnt."""
@@ -38,12 +41,13 @@ def _run(variant, steps):
 
 
 @needs_reference
-@pytest.mark.parametrize("variant,steps", [("hip-vanilla", 200), ("reference-gsplat-on-shims", 200)])
+@pytest.mark.parametrize("variant,steps", [("hip-vanilla", 200), ("reference-gsplat-on-shims", 200), ("hip-distributed", 200)])
 def test_unchanged_lightning_module_trains_with_the_renderers_of_this_repository(variant, steps):
     d = _run(variant, steps)
     assert d["inside_reference"] is True
-    assert d["renderer"] == ("gspl_amd.renderers.hip_vanilla_renderer.HipVanillaRenderer" if variant == "hip-vanilla"
-                             else "internal.renderers.gsplat_renderer.GSPlatRenderer")
+    assert d["renderer"] == {"hip-vanilla": "gspl_amd.renderers.hip_vanilla_renderer.HipVanillaRenderer",
+                             "reference-gsplat-on-shims": "internal.renderers.gsplat_renderer.GSPlatRenderer",
+                             "hip-distributed": "gspl_amd.renderers.hip_gsplat_distributed_renderer.HipGSplatDistributedRendererImpl"}[variant]
     losses, counts = d["losses"], d["counts"]
     assert len(losses) == steps and all(np.isfinite(losses))
     first, last = float(np.mean(losses[:12])), float(np.mean(losses[-12:]))
