@@ -19,7 +19,7 @@ import types
 
 import torch
 
-GENERIC = ("torchvision", "wandb", "viser", "plyfile", "splines", "cv2", "torchmetrics", "jsonargparse", "lightning", "tqdm_unused")
+GENERIC = ("torchvision", "wandb", "viser", "plyfile", "splines", "cv2", "torchmetrics", "jsonargparse", "lightning")
 
 
 class _Anything:
