@@ -15,7 +15,7 @@ A second variant swaps nothing at all: the reference's own `GSPlatRenderer` (int
 the `gsplat` stand-in package of `gspl_amd.compat`, whose ops are routed to the oracle stages the same way.
 A third one selects the Gaussian-sharded multi-GPU plugin (`HipGSplatDistributedRenderer`, world size 1: `training_setup`, the
 per-camera `projection_results_list` contract) together with the reference's `DistributedVanillaDensityController`.
-usage: python reference_loop_worker.py <reference root> <steps> [hip-vanilla | reference-gsplat-on-shims | hip-distributed]
+usage: python reference_loop_worker.py <reference root> <steps> [hip-vanilla | hip-gsplat-v1 | reference-gsplat-on-shims | hip-distributed]
 """
 import json
 import math
@@ -100,6 +100,23 @@ def main():
     density_cls = VanillaDensityController
     if VARIANT == "hip-vanilla":
         plugin = HipVanillaRenderer()
+    elif VARIANT == "hip-gsplat-v1":
+        # configs/gsplat_v1.yaml with the plugin in place of GSplatV1Renderer; its ops -> oracle stages
+        from gspl_amd.renderers import HipGSplatV1Renderer
+        import test_distributed_renderer
+        test_distributed_renderer._install_oracle_ops()          # projection, list-only binning, compositing -> oracle stages
+        composite = ops.rasterize_to_pixels
+
+        def rasterize_to_pixels(means2d, *args, track_hits=False, **kwargs):
+            if track_hits:       # the fork's rasterizer leaves `has_hit_any_pixels` on the screen-space tensor (read as `acc_vis`)
+                means2d.has_hit_any_pixels = torch.ones(means2d.shape[-2], dtype=torch.bool)
+            return composite(means2d, *args, **kwargs)
+
+        def sh_view_colors(degree, means, center, dc, rest, masks=None, detach_means=True):
+            rgb = O.sh_colors(degree, dc if rest is None else torch.cat([dc, rest], dim=1), means, center, detach_dirs=True)
+            return rgb if masks is None else torch.where(masks[:, None], rgb, torch.zeros((), dtype=rgb.dtype))
+        ops.rasterize_to_pixels, ops.sh_view_colors = rasterize_to_pixels, sh_view_colors
+        plugin = HipGSplatV1Renderer().instantiate()
     elif VARIANT == "hip-distributed":
         # configs/distributed.yaml: the sharded renderer + its density controller (one rank here; ops of its host path -> oracle stages)
         from gspl_amd.renderers import HipGSplatDistributedRenderer

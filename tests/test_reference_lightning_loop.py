@@ -8,14 +8,15 @@ with the reference's own `Cameras`, `VanillaGaussian` (its `setup_from_pcd`, opt
 (tests/lightning_standin.py: hparams, optimizer wrappers whose steps the trainer counts, manual backward, logging) — in a process of
 its own (tests/reference_loop_worker.py), so that the stand-in never meets the other tests' imports of the reference tree.
 
-Three selections of the renderer, as a user would make them:
+Four selections of the renderer, as a user would make them:
   * `--model.renderer gspl_amd.renderers.HipVanillaRenderer` — the plugin, which inside the reference subclasses the reference's
     own `Renderer` (the `isinstance` test of gaussian_splatting.py:75-77 is asserted in the worker);
+  * `gspl_amd.renderers.HipGSplatV1Renderer` in place of `configs/gsplat_v1.yaml`'s renderer;
   * nothing at all — the reference's own `GSPlatRenderer`, running on the `gsplat` stand-in package of `gspl_amd.compat`;
   * `configs/distributed.yaml` with `gspl_amd.renderers.HipGSplatDistributedRenderer` in place of its renderer line — the
     Gaussian-sharded plugin (its `training_setup`, per-camera `projection_results_list`) with the reference's own
     `DistributedVanillaDensityController`, one rank.
-No GPU here and no reference tree on the GPU box: the native ops under all three are the oracle stages (the HIP-vs-oracle parity of those
+No GPU here and no reference tree on the GPU box: the native ops under all four are the oracle stages (the HIP-vs-oracle parity of those
 ops is what the `-m gpu` tests establish).  Checked: the loop runs through densifications, opacity reset and SH-degree raises, the
 loss falls, the trainer's step count advances once per batch, the density controller consumed `viewspace_points.grad` / `radii`,
 the LR scheduler ran, and the final PSNR is that of a scene being learnt."""
@@ -33,19 +34,26 @@ needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF_ROOT, "
                                      reason="reference tree not present")
 
 
+_RESULTS = {}
+
+
 def _run(variant, steps):
+    if (variant, steps) in _RESULTS:
+        return _RESULTS[(variant, steps)]
     r = subprocess.run([sys.executable, os.path.join(HERE, "reference_loop_worker.py"), REF_ROOT, str(steps), variant],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-4000:]
-    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    _RESULTS[(variant, steps)] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    return _RESULTS[(variant, steps)]
 
 
 @needs_reference
-@pytest.mark.parametrize("variant,steps", [("hip-vanilla", 200), ("reference-gsplat-on-shims", 200), ("hip-distributed", 200)])
+@pytest.mark.parametrize("variant,steps", [("hip-vanilla", 200), ("hip-gsplat-v1", 200), ("reference-gsplat-on-shims", 200), ("hip-distributed", 200)])
 def test_unchanged_lightning_module_trains_with_the_renderers_of_this_repository(variant, steps):
     d = _run(variant, steps)
     assert d["inside_reference"] is True
     assert d["renderer"] == {"hip-vanilla": "gspl_amd.renderers.hip_vanilla_renderer.HipVanillaRenderer",
+                             "hip-gsplat-v1": "gspl_amd.renderers.hip_gsplat_v1_renderer.HipGSplatV1RendererModule",
                              "reference-gsplat-on-shims": "internal.renderers.gsplat_renderer.GSPlatRenderer",
                              "hip-distributed": "gspl_amd.renderers.hip_gsplat_distributed_renderer.HipGSplatDistributedRendererImpl"}[variant]
     losses, counts = d["losses"], d["counts"]
@@ -60,6 +68,16 @@ def test_unchanged_lightning_module_trains_with_the_renderers_of_this_repository
     assert d["accum_max"] > 0.0 and d["radii_max"] >= 1.0                           # update_states saw the plugin's grad and radii
     assert d["logged_lr_rows"] >= 2 and d["means_lr_last"] < d["means_lr_first"]    # lr logged every 100 steps; the scheduler stepped
     assert d["psnr"] > 22.0
+
+
+@needs_reference
+def test_sharded_plugin_at_one_rank_trains_exactly_like_the_v1_plugin():
+    """One rank of the Gaussian-sharded renderer (project for C = 1 cameras, pack, unpack, bin, composite; per-camera density
+    statistics through `DistributedVanillaDensityController`) IS the v1 renderer with anti-aliasing: inside the unchanged loop the two
+    runs make the same densification decisions and log the same losses."""
+    a, b = _run("hip-gsplat-v1", 200), _run("hip-distributed", 200)
+    assert a["counts"] == b["counts"]
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-5, atol=1e-7)
 
 
 def test_launcher_registers_the_stand_ins_before_the_entry_point_is_imported(tmp_path):
