@@ -15,7 +15,12 @@ A second variant swaps nothing at all: the reference's own `GSPlatRenderer` (int
 the `gsplat` stand-in package of `gspl_amd.compat`, whose ops are routed to the oracle stages the same way.
 A third one selects the Gaussian-sharded multi-GPU plugin (`HipGSplatDistributedRenderer`, world size 1: `training_setup`, the
 per-camera `projection_results_list` contract) together with the reference's `DistributedVanillaDensityController`.
+With `<rank> <world> <port>` appended, `hip-distributed` runs as one rank of a gloo group: `training_setup` shards the model and its
+optimizers, every step exchanges the visible splats' records with the peers (camera (step * world + rank) per rank, the peers'
+cameras found through `trainer.train_dataloader.dataset.image_cameras` as the reference does), densification stays rank-local, and a
+forced `redistribute` moves rows and their Adam moments between the ranks in the middle of the run.
 usage: python reference_loop_worker.py <reference root> <steps> [hip-vanilla | hip-gsplat-v1 | reference-gsplat-on-shims | hip-distributed]
+                                       [<rank> <world> <port>]
 """
 import json
 import math
@@ -27,6 +32,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF_ROOT, STEPS = sys.argv[1], int(sys.argv[2])
 VARIANT = sys.argv[3] if len(sys.argv) > 3 else "hip-vanilla"
+RANK, WORLD, PORT = (int(v) for v in sys.argv[4:7]) if len(sys.argv) > 6 else (0, 1, 0)
 for p in (REF_ROOT, HERE, ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -123,7 +129,12 @@ def main():
         from internal.density_controllers.distributed_vanilla_density_controller import DistributedVanillaDensityController
         import test_distributed_renderer
         test_distributed_renderer._install_oracle_ops()
-        plugin = HipGSplatDistributedRenderer().instantiate()
+        if WORLD > 1:
+            import torch.distributed as dist
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(PORT)
+            dist.init_process_group("gloo", rank=RANK, world_size=WORLD)
+        # a redistribution in the middle of the run (the reference's default interval is 1000 steps; any imbalance triggers it here)
+        plugin = HipGSplatDistributedRenderer(redistribute_interval=90 if WORLD > 1 else 1000, redistribute_threshold=1.0 + 1e-9).instantiate()
         density_cls = DistributedVanillaDensityController
     else:
         # the reference's own class, importable here only because `gsplat` resolves to the stand-in package
@@ -181,13 +192,22 @@ def main():
                                           val_set=ns(cameras=cameras)),
                     set_device=lambda device: None)
     trainer = lightning_standin.Trainer(datamodule, max_steps=STEPS)
+    trainer.global_rank, trainer.world_size = RANK, WORLD
+    loader = ns(dataset=ns(image_cameras=[cameras[i] for i in range(len(cameras))]))
+    trainer.train_dataloader, trainer.val_dataloaders = loader, loader
     trainer.fit_setup(module)
-    assert module.gaussian_model.get_xyz.shape[0] == n0 and len(trainer.raw_optimizers) >= 2
+    from gspl_amd import distributed as gdist
+    lo, hi = gdist.shard_bounds(n0, WORLD, RANK)
+    assert module.gaussian_model.get_xyz.shape[0] == hi - lo and len(trainer.raw_optimizers) >= 2      # (world 1: the whole model)
+    n_redistributions = [0]
+    if WORLD > 1:
+        moved = plugin.random_redistribute
+        plugin.random_redistribute = lambda m, destination=None: (n_redistributions.__setitem__(0, n_redistributions[0] + 1), moved(m, destination))[1]
 
     losses, counts, accum_max, radii_max, sh_degrees = [], [], 0.0, 0.0, []
     for i in range(STEPS):
         torch.manual_seed(1000 + i)                           # the split samples of a densification
-        k = i % len(cameras)
+        k = (i * WORLD + RANK) % len(cameras)
         batch = (cameras[k], (f"{k:03d}", targets[k], None), None)
         trainer.train_batch(module, batch, i)
         assert trainer.global_step == i + 1, (trainer.global_step, i)       # one count per batch, whatever the number of optimizers
@@ -198,13 +218,20 @@ def main():
         radii_max = max(radii_max, float(module.density_controller.max_radii2D.max()))
     module.eval()
     with torch.no_grad():
-        finals = [module(cam)["render"] for cam in cameras]
-    psnr = float(np.mean([T.psnr(f, t) for f, t in zip(finals, targets)]))
+        mine = [(j * WORLD + RANK) % len(cameras) for j in range(len(cameras) // WORLD)]     # every rank renders ITS cameras, in step
+        finals = [module(cameras[k])["render"] for k in mine]
+    psnr = float(np.mean([T.psnr(f, targets[k]) for f, k in zip(finals, mine)]))
     lrs = [m for _, m in trainer.logger.metrics]
     print(json.dumps({"losses": losses, "counts": counts, "sh_degrees": sh_degrees, "accum_max": accum_max, "radii_max": radii_max, "psnr": psnr,
                       "logged_lr_rows": len(lrs), "means_lr_first": lrs[0].get("lr/0_means") if lrs else None,
                       "means_lr_last": float(trainer.raw_optimizers[0].param_groups[0]["lr"]),
-                      "inside_reference": bool(gspl_amd.renderers.renderer.INSIDE_REFERENCE), "renderer": type(plugin).__module__ + "." + type(plugin).__name__}))
+                      "inside_reference": bool(gspl_amd.renderers.renderer.INSIDE_REFERENCE), "renderer": type(plugin).__module__ + "." + type(plugin).__name__,
+                      "rank": RANK, "world": WORLD, "redistributions": n_redistributions[0],
+                      "last_exchange": getattr(plugin, "last_exchange", None)}))
+    if WORLD > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -80,6 +80,43 @@ def test_sharded_plugin_at_one_rank_trains_exactly_like_the_v1_plugin():
     np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-5, atol=1e-7)
 
 
+@needs_reference
+def test_unchanged_lightning_module_trains_on_two_ranks_with_the_sharded_plugin():
+    """`configs/distributed.yaml` at world size 2 (gloo, CPU): two processes run the reference's unchanged LightningModule with
+    `HipGSplatDistributedRenderer` + `DistributedVanillaDensityController`.  `training_setup` cuts the model and its optimizers down
+    to the rank's rows; every step each rank projects its shard for both cameras, the visible splats' records cross in the all-to-all
+    (the peers' cameras looked up through `trainer.train_dataloader.dataset.image_cameras`), each rank composites and back-propagates
+    its own image, densifies its own rows; at step 90 a redistribution moves rows AND their Adam moments between the ranks."""
+    from conftest import free_port
+    port, steps = free_port(), 100
+    threads = str(max(1, (os.cpu_count() or 2) // 2))             # two processes share the host's cores
+    env = dict(os.environ, OMP_NUM_THREADS=threads, MKL_NUM_THREADS=threads)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "reference_loop_worker.py"), REF_ROOT, str(steps), "hip-distributed",
+                               str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=1500))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-4000:]
+    ranks = [json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]) for so, _ in outs]
+    for r, d in enumerate(ranks):
+        first, last = float(np.mean(d["losses"][:12])), float(np.mean(d["losses"][-12:]))
+        print(f"rank {r}: loss {first:.4f} -> {last:.4f}, N {d['counts'][0]} -> {d['counts'][-1]}, PSNR of its cameras {d['psnr']:.2f} dB, "
+              f"exchange {d['last_exchange']}, redistributions {d['redistributions']}")
+        assert d["rank"] == r and d["world"] == 2 and d["inside_reference"] is True
+        assert d["counts"][0] == 1000 and max(d["counts"]) > 1.5 * d["counts"][0]                # 2000 rows sharded 1000 / 1000, then densified
+        assert last < 0.8 * first and all(np.isfinite(d["losses"])) and d["psnr"] > 22.0
+        assert d["redistributions"] == 1 and d["accum_max"] > 0.0 and d["last_exchange"] in ("counted", "padded")
+    total = [a + b for a, b in zip(ranks[0]["counts"], ranks[1]["counts"])]
+    # the redistribution (after step 90; densification at 80) changes who holds the rows, not how many there are
+    assert total[86] == total[95] and (ranks[0]["counts"][86], ranks[1]["counts"][86]) != (ranks[0]["counts"][95], ranks[1]["counts"][95])
+
+
 def test_launcher_registers_the_stand_ins_before_the_entry_point_is_imported(tmp_path):
     """`python -m gspl_amd.launch <script> args...`: on a machine without the CUDA packages the reference's entry points import
     `diff_gaussian_rasterization` before their CLI has seen `--model.renderer`; the launcher registers the stand-ins first and then
