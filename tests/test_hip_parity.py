@@ -813,10 +813,14 @@ def test_inria_rasterizer_reads_shs_dc_and_shs_rest_in_place(hip, fused):
             img1, r1 = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, shs=dc, shs_rest=rest, scales=s, rotations=q)
             assert torch.equal(img0, img1) and torch.equal(r0, r1)
             (img1 * wimg.to(_dev())).sum().backward()
-            # the per-splat colour gradient the SH backward consumes comes out of float atomics (run-to-run order): compare scaled
-            assert_close_scaled(dc.grad.cpu().numpy(), merged.grad[:, :1].cpu().numpy(), 1e-5, f"v_shs_dc deg={deg}")
-            assert_close_scaled(rest.grad.cpu().numpy(), merged.grad[:, 1:].cpu().numpy(), 1e-5, f"v_shs_rest deg={deg}")
-            assert_close_scaled(m.grad.cpu().numpy(), g_means0.cpu().numpy(), 1e-5, f"v_means deg={deg}")
+            # The per-splat gradients the SH / projection backward consume come out of float atomics whose order differs between two
+            # launches: compare scaled, within the spread tests/test_backward_spread.py allows for the compositing gradients (2e-5)
+            # and — for the means, behind the conic -> cov2D -> cov3D chain that amplifies a last-bit difference of a near-degenerate
+            # splat — within 1e-4 (measured over fresh processes: up to 1.1e-5, tools/diag/r03rccl2.py; one element of 18 000 at
+            # 1.04e-5 once in eight runs of this file, profiles/r04_flaky_v_means.txt: a tolerance of 1e-5 was inside the spread).
+            assert_close_scaled(dc.grad.cpu().numpy(), merged.grad[:, :1].cpu().numpy(), 2e-5, f"v_shs_dc deg={deg}")
+            assert_close_scaled(rest.grad.cpu().numpy(), merged.grad[:, 1:].cpu().numpy(), 2e-5, f"v_shs_rest deg={deg}")
+            assert_close_scaled(m.grad.cpu().numpy(), g_means0.cpu().numpy(), 1e-4, f"v_means deg={deg}")
             n_active = (deg + 1) ** 2
             assert float(rest.grad[:, n_active - 1:].abs().max()) == 0.0 if n_active < 16 else True
             # tuple form
