@@ -80,8 +80,10 @@ def parse():
     p.add_argument("--parallelism", default="auto", choices=["auto", "single", "replicated", "sharded"],
                    help="auto: single for one GPU, sharded for several (Gaussian-sharded renderer with the packed all-to-all, "
                         "configs/distributed.yaml); replicated: all Gaussians on every rank, gradient all-reduce + optimizer on every rank")
-    p.add_argument("--no-overlap-sh-update", action="store_true",
-                   help="keep the whole optimizer step on the caller's stream (default on one GPU: the shs_rest update overlaps the next frame's binning)")
+    p.add_argument("--overlap-sh-update", action="store_true",
+                   help="run the shs_rest update on the colour stream, under the next frame's geometry + binning (FusedAdam(deferred=...), "
+                        "HipFusedAdam.overlap_sh_update=True).  Off by default, as in the product: the headline number is the default configuration")
+    p.add_argument("--no-overlap-sh-update", action="store_true", help="(the default; kept for older command lines)")
     p.add_argument("--exchange", default="auto", choices=["counted", "padded", "auto"],
                    help="--parallelism sharded: format of the per-step record exchange (renderer option `exchange`)")
     p.add_argument("--staged-sharded-step", action="store_true",
@@ -407,7 +409,7 @@ def main():
         from gspl_amd import optimizers as gopt
         # single GPU: the update of shs_rest (45 of a Gaussian's 59 floats) runs on the rasterizer's colour stream, under the next
         # frame's geometry and binning kernels (FusedAdam(deferred=...): same kernel, bit-identical parameters)
-        deferred = ("shs_rest",) if (mode == "single" and not args.no_overlap_sh_update) else None
+        deferred = ("shs_rest",) if (mode == "single" and args.overlap_sh_update and not args.no_overlap_sh_update) else None
         return (gopt.FusedAdam if kind == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15, deferred=deferred)
 
     DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
@@ -740,7 +742,7 @@ def main():
                      + (" + gradient all-reduce" if mode == "replicated" and args.optimizer != "none" else "")
                      + ("" if args.optimizer == "none" else " + " + args.optimizer + " step")
                      + (" (shs_rest update on the colour stream, under the next frame's geometry + binning)"
-                        if (mode == "single" and args.optimizer in ("fused-adam", "selective-adam") and not args.no_overlap_sh_update) else "")
+                        if (mode == "single" and args.optimizer in ("fused-adam", "selective-adam") and args.overlap_sh_update and not args.no_overlap_sh_update) else "")
                      + " + densification stats")
         par = {"single": "single GPU",
                "replicated": (f"replicated Gaussians, {world} camera(s)/step, "

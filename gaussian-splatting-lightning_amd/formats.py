@@ -244,14 +244,24 @@ def merge_rank_checkpoints(ckpts: Sequence[dict]) -> dict:
 
     hp = last.get("hyper_parameters")
     renderer = hp.get("renderer") if isinstance(hp, dict) else None
-    if renderer is not None and "Distributed" in type(renderer).__name__:
+    kind = type(renderer).__name__ if renderer is not None else ""
+    if kind in ("GSplatDistributedRenderer", "HipGSplatDistributedRenderer"):
+        # the plain Gaussian-sharded renderers -> the single-process plugin (utils/merge_distributed_ckpts.py:130-141)
         from .renderers import HipGSplatV1Renderer
         hp = dict(hp)
         hp["renderer"] = HipGSplatV1Renderer(
             block_size=getattr(renderer, "block_size", 16), anti_aliased=getattr(renderer, "anti_aliased", True),
             filter_2d_kernel_size=getattr(renderer, "filter_2d_kernel_size", 0.3),
+            separate_sh=getattr(renderer, "separate_sh", False),
             tile_based_culling=getattr(renderer, "tile_based_culling", False))
         merged["hyper_parameters"] = hp
+    elif "Distributed" in kind:
+        # GSplatDistributedAppearanceEmbedding(Mip)Renderer (utils/merge_distributed_ckpts.py:143-170) carry an appearance model
+        # whose weights were renamed `renderer.model.*` above; their single-process counterparts are not part of this package
+        # (appearance models are out of scope), and swapping in a plain renderer would drop the model and leave
+        # orphan keys for a strict load
+        raise NotImplementedError(f"merge_rank_checkpoints: renderer {kind} has an appearance model; merge this checkpoint with the "
+                                  "reference's utils/merge_distributed_ckpts.py (it maps it to GSplatAppearanceEmbedding(Mip)Renderer)")
     return merged
 
 

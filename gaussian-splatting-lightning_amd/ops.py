@@ -56,6 +56,8 @@ def _guarded(pos: int):
 def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
     if t is None:
         return None
+    if PENDING_UPDATES and (t.dtype != torch.float32 or not t.is_contiguous()):
+        join_pending_updates(t.device)      # the copy below is a torch read of what may be a parameter with an update in flight
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
@@ -723,9 +725,27 @@ def colour_stream(dev):
 
 # Parameter updates in flight on another stream (optimizers.FusedAdam(deferred=...): the Adam update of the SH coefficients runs on the
 # colour stream, under the next frame's geometry / binning kernels): data_ptr -> (event recorded after the update, raw handle of the
-# stream it was launched on).  Every kernel of this package that reads a parameter which may be deferred — the SH colour kernels —
+# stream it was launched on, device).  Every kernel of this package that reads a parameter which may be deferred — the SH colour kernels —
 # calls `_await_updates` on the stream it launches on; the optimizer retires its entries at its next step.
 PENDING_UPDATES: dict = {}
+
+
+def join_pending_updates(device=None):
+    """Make the current stream of `device` (default: every device with an entry) wait for ALL parameter updates in flight
+    (`FusedAdam(deferred=...)`).  `_await_updates` recognises a parameter by its data pointer, which covers the kernels of this
+    package reading it in place; a TORCH read — `torch.cat` inside `get_features`, a dtype / layout copy, user code in
+    `on_train_batch_end` — produces a new tensor that no pointer table can tie to the update, so every place of this package that
+    reads a possibly-deferred parameter through torch calls this first (renderers/renderer.py: `model_sh_pair`, `_f32c` above)."""
+    if not PENDING_UPDATES:
+        return
+    seen = set()
+    for done, _raw, dev in list(PENDING_UPDATES.values()):
+        if id(done) in seen:
+            continue
+        seen.add(id(done))
+        if device is not None and torch.device(dev) != torch.device(device):
+            continue
+        torch.cuda.current_stream(dev).wait_event(done)
 
 
 def _await_updates(*tensors, on_raw_stream=None):
@@ -1312,7 +1332,10 @@ class _ShardExchangeFn(torch.autograd.Function):
             return (None,) * (3 + C)
         if ctx.route is not None:
             v_records = ctx.route[1](v_records)
-        pack = ctx.stash.pop("pack")
+        pack = ctx.stash.pop("pack", None)      # (released here: the pack stage's buffers are dead after this backward)
+        if pack is None:
+            raise RuntimeError("sharded_exchange: the backward of this step has already run and released its pack state; the three-node "
+                               "step is single-use (fused_step=False gives the stage-by-stage step, which supports retain_graph)")
         grads = _PackRecordsFn.backward(pack, v_records, None)
         # (None, None, v_opac, C x None (radii), C x v_means2d, C x v_depths, C x v_conics, C x v_comps, C x v_colors): per-camera
         # slices of one buffer each

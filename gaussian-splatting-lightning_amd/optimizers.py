@@ -135,7 +135,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
                 for (p, g, m, v, _lr, _row) in items:
                     keep.append(g)                             # alive until the caller's stream has waited for the update: the
                     p.grad = None                              # allocator must not hand the block to later work on that stream
-                    ops.PENDING_UPDATES[p.data_ptr()] = (done, raw)
+                    ops.PENDING_UPDATES[p.data_ptr()] = (done, raw, dev)
                     ptrs.append(p.data_ptr())
             self._inflight.append((done, keep, ptrs, dev))
 

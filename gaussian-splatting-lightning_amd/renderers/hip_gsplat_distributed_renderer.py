@@ -42,13 +42,14 @@ class HipGSplatDistributedRenderer(RendererConfig):
     # exchange of their counts (the reference's scheme; here the counts leave the device before the colour kernel runs and their
     # exchange rides a control stream, but the host still waits for them and for the peers').  "padded": one record per (camera,
     # local splat), invisible rows zeroed — every size is known beforehand (the peers' Gaussian counts travel with the camera ids),
-    # so the exchange has no count collective and no read-back, at 1 / (visible fraction) times the bytes.  "auto" (default): padded
-    # while at least `padded_min_visible` of the (camera, splat) pairs of EVERY rank were visible in its last step, else counted (the
-    # ranks vote in the per-step all-gather of the camera ids; the first step is counted).  Measured on one MI355X with the three-node
+    # so the exchange has no count collective and no read-back, at 1 / (visible fraction) times the bytes.  "auto" (default): with ONE
+    # rank (nothing travels) padded while at least `padded_min_visible` of the (camera, splat) pairs were visible in the last step,
+    # else counted; with peers always counted — the padded bytes on a real interconnect are unmeasured.  Measured on one MI355X with the three-node
     # step (S-1080p-1M, 95 % visible; profiles/r04b_*): 1.42 ms padded against 1.46 ms counted at W = 1, 1.75-1.78 against 1.83-1.85 ms
     # with every collective issued to RCCL in a one-rank group.
     exchange: str = "auto"
     padded_min_visible: float = 0.5
+    auto_padded_with_peers: bool = False      # let "auto" vote for the padded format with more than one rank too
     # The step as three autograd nodes (`ops.sharded_front` / `sharded_exchange` / `sharded_back`: project + colours + pack, the
     # all-to-all, unpack + bin + composite) instead of eleven — same kernels, same numbers, less host work per step.  Taken on
     # the GPU (either exchange format) when nothing is overridden (`get_rgbs`) and only "rgb" is asked for; that path hands out
@@ -202,6 +203,11 @@ class HipGSplatDistributedRendererImpl(Renderer):
         c = self.config
         if c.exchange != "auto":
             return c.exchange
+        if self._world() > 1 and not c.auto_padded_with_peers:
+            # Every measurement behind "padded" was taken with ONE rank (nothing on the wire, profiles/r04b_*); with peers, padding
+            # sends up to 1 / (visible fraction) times the bytes over xGMI, which nobody has measured: the reference's counted
+            # scheme stays the default there until a multi-rank run says otherwise (exchange="padded" / auto_padded_with_peers=True opt in).
+            return "counted"
         votes = [r[2] for r in self._peer_rows]
         return "padded" if min(votes) >= int(1000 * c.padded_min_visible) else "counted"
 

@@ -110,6 +110,7 @@ class HipGSplatV1RendererModule(Renderer):
     def get_rgbs(self, camera, gaussian_model, projections: Tuple, visibility_filter, status: Any, **kwargs):
         pre_activated = getattr(gaussian_model, "is_pre_activated", False)
         if pre_activated or not self.config.separate_sh:
+            ops.join_pending_updates(gaussian_model.get_xyz.device)      # `get_features` is a torch read of the SH parameters
             return ops.sh_view_colors(gaussian_model.active_sh_degree, gaussian_model.get_xyz, camera.camera_center,
                                       gaussian_model.get_features, None, visibility_filter)
         return ops.sh_view_colors(gaussian_model.active_sh_degree, gaussian_model.get_xyz, camera.camera_center,

@@ -141,6 +141,10 @@ def model_sh_pair(pc):
             return pc.get_shs_dc(), pc.get_shs_rest()
         except KeyError:
             pass
+    # `get_features` reads the parameters through torch (a cat, or the stored tensor of a pre-activated model): an update of the
+    # coefficients still in flight on the colour stream (FusedAdam(deferred=...)) has to land first
+    from .. import ops
+    ops.join_pending_updates(pc.get_xyz.device)
     return pc.get_features, None
 
 

@@ -219,3 +219,54 @@ def test_readers_of_a_deferred_parameter_see_the_finished_update(consumer):
     finally:
         ops.FUSED_INRIA = fused
         opt.join()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reader", ["v1_merged_features", "v0_pre_activated"])
+def test_torch_reads_of_a_deferred_parameter_wait_for_its_update(reader):
+    """`_await_updates` ties an in-flight update to a parameter by its data pointer, which a TORCH read cannot
+    carry — `get_features` is a `torch.cat` on the caller's stream, a dtype / layout copy makes a new tensor.  Those paths join every
+    update in flight first (`ops.join_pending_updates`): HipGSplatV1Renderer with separate_sh=False and a renderer handed a
+    pre-activated model (one merged `get_features`) must give the image of the settled state."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gspl_amd  # noqa: F401
+    from fakes import FakeCamera, FakeGaussianModel
+    from gspl_amd import ops, synthetic
+    from gspl_amd.optimizers import FusedAdam
+    from gspl_amd.renderers import HipGSplatRenderer, HipGSplatV1Renderer
+    from oracle import gsplat_oracle as O
+    dev = torch.device("cuda:0")
+    W, H, n = 320, 208, 400000
+    params = O.synthetic_scene(n, seed=3)
+    cam = FakeCamera(O.synthetic_camera(W, H, 300.0), dev)
+    model = FakeGaussianModel(*[p.to(dev) for p in params])
+    names = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+    opt = FusedAdam([{"params": [p], "lr": 1e-2, "name": nm} for p, nm in zip(model.leaves(), names)], eps=1e-15, deferred=("shs_rest",))
+    bg = torch.zeros(3, device=dev)
+    if reader == "v1_merged_features":
+        renderer = HipGSplatV1Renderer(separate_sh=False).instantiate()
+    elif reader == "v0_pre_activated":
+        renderer = HipGSplatRenderer()
+        model.is_pre_activated = True          # `model_sh_pair` then reads `get_features` (one merged tensor)
+
+    def read():
+        with torch.no_grad():
+            return renderer(cam, model, bg)["render"]
+
+    g = torch.Generator().manual_seed(2)
+    before = read()
+    try:
+        for it in range(3):
+            for p in model.leaves():
+                p.grad = torch.randn(p.shape, generator=g).to(dev)
+            torch.cuda.synchronize()
+            opt.step()
+            first = read()                         # the update of shs_rest is in flight on the colour stream
+            torch.cuda.synchronize()
+            settled = read()
+            assert torch.equal(first, settled), f"step {it}: a torch read saw shs_rest before its update had finished"
+            assert not torch.equal(settled, before)
+            before = settled
+    finally:
+        opt.join()

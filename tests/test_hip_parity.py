@@ -60,11 +60,12 @@ def test_projection_vs_reference_golden(hip, golden_dir, cam):
     # cov3d [N,3,3] as the reference returns it (gaussian_projection.py:47,137): (R S)(R S)^T, zeros for culled Gaussians
     assert cov3d.shape == (means.shape[0], 3, 3) and not cov3d.requires_grad
     np.testing.assert_allclose(cov3d.cpu().numpy(), z[p + "cov3d"], rtol=2e-5, atol=1e-9)
-    r_ref = z[p + "radii"]
-    same = radii.cpu().numpy() == r_ref
-    assert same.mean() >= 0.999, "radii (ceil may flip on an fp32 rounding boundary for <0.1 %)"
+    # integer outputs: bit-exact (the reference compares them with torch.equal, tests/gaussian_projection_test.py:185-265).  The
+    # radius of a splat whose fp32 extent sits on a rounding boundary comes from the fp64 value of the chain (csrc/gspl_device.h:
+    # extent_f64); the fixture's radii equal the fp64 oracle's for every splat (tests/test_oracle_golden.py).
+    assert np.array_equal(radii.cpu().numpy(), z[p + "radii"])
     assert np.array_equal((radii > 0).cpu().numpy(), z[p + "mask"])
-    assert np.array_equal(tiles.cpu().numpy()[same], z[p + "tiles"][same])
+    assert np.array_equal(tiles.cpu().numpy(), z[p + "tiles"])
     np.testing.assert_allclose(xys.detach().cpu().numpy(), z[p + "xys"], rtol=1e-5, atol=2e-3)
     np.testing.assert_allclose(depths.detach().cpu().numpy(), z[p + "depths"], rtol=1e-5, atol=1e-6)
     assert_close_scaled(conics.detach().cpu().numpy(), z[p + "conics"], 2e-4, "conics", frac_ok=0.999, rel_all=5e-2)
@@ -73,7 +74,7 @@ def test_projection_vs_reference_golden(hip, golden_dir, cam):
         + (comp * t32(z[p + "w_k"])).sum()
     loss.backward()
     for got, name in ((means.grad, "g_means"), (scales.grad, "g_scales"), (quats.grad, "g_quats")):
-        assert_close_scaled(got.cpu().numpy(), z[p + name], 3e-4, name, frac_ok=0.998, rel_all=5e-2)
+        assert_close_scaled(got.cpu().numpy(), z[p + name], 1e-4, name, frac_ok=0.995, rel_all=5e-2)      # north_star: 1e-4 rel
 
 
 def test_projection_known_answer_vector(hip, golden_dir):
@@ -117,14 +118,14 @@ def test_projection_vs_oracle_fp64_batched_cameras(hip):
         xys, dep, rad, con, cmp_, tiles, _, mask, _, _ = O.project_gaussians(
             md, sd, 1.0, qd, c["world_to_camera"].double(), c["fx"], c["fy"], c["cx"], c["cy"], H, W)
         same = rad.numpy() == radii[ci].cpu().numpy()
-        assert same.mean() > 0.999
+        assert same.all(), f"camera {ci}: {int((~same).sum())} radii differ from the fp64 oracle's"
         np.testing.assert_allclose(means2d[ci].detach().cpu().numpy()[same], xys.detach().numpy()[same], rtol=1e-5, atol=2e-3)
         assert_close_scaled(conics[ci].detach().cpu().numpy()[same], con.detach().numpy()[same], 2e-4, "conics", 0.999, rel_all=5e-2)
         loss = loss + (xys * ws[0][ci].double()).sum() + (dep * ws[1][ci].double()).sum() \
             + (con * ws[2][ci].double()).sum() + (cmp_ * ws[3][ci].double()).sum()
     loss.backward()
     for got, ref, name in ((m.grad, md.grad, "means"), (s.grad, sd.grad, "scales"), (q.grad, qd.grad, "quats")):
-        assert_close_scaled(got.cpu().numpy(), ref.numpy(), 3e-4, name, frac_ok=0.998, rel_all=5e-2)
+        assert_close_scaled(got.cpu().numpy(), ref.numpy(), 1e-4, name, frac_ok=0.995, rel_all=5e-2)      # north_star: 1e-4 rel
 
 
 # ---------------------------------------------------------------------------------------------

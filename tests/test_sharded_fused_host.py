@@ -170,3 +170,18 @@ def test_records_bypassing_the_exchange_node_are_refused(recorded_abi):
                                     torch.eye(4)[None], torch.eye(3)[None], torch.zeros(1, 3), 96, 64, 0.3, 3, stash)
     with pytest.raises(RuntimeError, match="sharded_exchange"):
         records.sum().backward()
+
+
+def test_second_backward_of_the_three_node_step_says_what_happened(recorded_abi):
+    """the exchange node releases the pack stage's state in its backward; a second backward over the same graph
+    (retain_graph=True) must say so instead of raising a bare KeyError."""
+    from gspl_amd import ops
+    model, cam = _scene(100)
+    stash = {}
+    records, counts, radii, means2d, *_ = ops.sharded_front(model.means, model.scales_, model.rotations_, model.opacities_, model.shs_dc, model.shs_rest,
+                                                            torch.eye(4)[None], torch.eye(3)[None], torch.zeros(1, 3), 96, 64, 0.3, 3, stash)
+    received = ops.sharded_exchange(records, stash, ops.unbind_cameras(means2d), None)
+    image, _ = ops.sharded_back(received, torch.zeros(3), 96, 64, 16, True, False)
+    image.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="single-use"):
+        image.sum().backward()
