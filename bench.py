@@ -89,6 +89,11 @@ def parse():
     p.add_argument("--staged-sharded-step", action="store_true",
                    help="--parallelism sharded: the stage-by-stage formulation of the step (eleven autograd nodes) instead of the three-node one")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
+    p.add_argument("--loop", default="reference-shaped", choices=["none", "reference-shaped"],
+                   help="one-GPU runs: after the timed regions, also run the REFERENCE-SHAPED training loop (bench_loop.py: raw parameters "
+                        "behind exp / sigmoid / normalize getters, the restated density controller densifying every 100 steps from the "
+                        "workload's Gaussians, opacity reset, SH-degree raise, the renderer plugin) and report `reference_shaped_loop`")
+    p.add_argument("--loop-steps", type=int, default=450)
     p.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg and print it (no GPU needed)")
     p.add_argument("--stage-times", action="store_true",
                    help="time EVERY C-ABI call with events (stages_ms); default: only the compositing kernels the roofline needs")
@@ -106,6 +111,58 @@ def _mark():
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     return e
+
+
+def reference_shaped_loop(dev, wl, cam_dicts, steps):
+    """`--loop reference-shaped` (images/s of the Lightning loop, not of a static-N step on activated leaves): the
+    consumer side restated in bench_loop.py drives `HipVanillaRenderer` through what `GaussianSplatting.training_step` does
+    (internal/gaussian_splatting.py:329-397) — activations forward and backward every step, densify / prune every 100 steps (N
+    changes: allocator, list-length guesses and optimizer state see new sizes), one opacity reset, the SH degree raised twice."""
+    import bench_loop as BL
+    import gspl_amd  # noqa: F401
+    from gspl_amd import ops, synthetic
+    from gspl_amd.optimizers import FusedAdam
+    from gspl_amd.renderers import HipVanillaRenderer
+    W, H = wl["width"], wl["height"]
+    clean = synthetic.scene(wl["n"], seed=42)
+    cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
+    renderer = HipVanillaRenderer()
+    bg = torch.zeros(3, device=dev)
+    # targets: the clean scene from every camera (degree 3); the trained model starts from a perturbed copy at degree 1
+    truth = synthetic.ModelObject(*[t.to(dev) for t in clean], active_sh_degree=3)
+    with torch.no_grad():
+        targets = [renderer(c, truth, bg)["render"].clone() for c in cams]
+    del truth
+    model = BL.RawGaussians(*[t.to(dev) for t in BL.perturbed(clean)], active_sh_degree=1, max_sh_degree=3)
+    optimizers = model.make_optimizers(1.0, FusedAdam)
+    # the reference's defaults (vanilla_density_controller.py:14-40) except the schedule, compressed so that a few hundred steps see
+    # every kind of event: densification from step 100 every 100 steps (reference: from 500), opacity reset at step 300 (3000),
+    # SH degree up every 150 steps (1000)
+    controller = BL.DensityController(model.n_gaussians, dev, cameras_extent=2.6, densify_from_iter=100, densification_interval=100,
+                                      opacity_reset_interval=300)
+    loss_fn = lambda img, gt: ops.photometric_loss(img, gt, 0.2)
+    frames0, misses0, cold0 = (ops.SPECULATION[k] for k in ("frames", "misses", "cold"))
+    mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    res = BL.run(renderer, model, controller, optimizers, cams, targets, steps, bg, loss_fn, sh_degree_up_interval=150)
+    event_steps = {e["step"] for e in controller.events}
+    quiet = [ms for i, ms in enumerate(res["step_ms"], start=1) if i not in event_steps and (i - 1) not in event_steps and i > 5]
+    loud = [ms for i, ms in enumerate(res["step_ms"], start=1) if i in event_steps]
+    srt = sorted(quiet)
+    return {
+        "what": "bench_loop.py: RawGaussians (exp / sigmoid / normalize getters) + restated VanillaDensityControllerImpl + FusedAdam x 2 "
+                "+ HipVanillaRenderer + fused 0.8 L1 + 0.2 (1 - SSIM), one camera of the set per step, targets = the unperturbed scene",
+        "steps": steps, "images_per_s_densifying": round(steps / res["elapsed_s"], 2), "ms_per_step_mean": round(1e3 * res["elapsed_s"] / steps, 4),
+        "ms_per_step_between_events_p50": round(srt[len(srt) // 2], 4) if srt else None,
+        "ms_per_event_step_mean": round(sum(loud) / len(loud), 3) if loud else None,
+        "n_start": res["n"][0] if res["n"] else None, "n_end": res["n"][-1] if res["n"] else None,
+        "n_trajectory_every_50_steps": res["n"][49::50], "events": controller.events,
+        "sh_degree_end": model.active_sh_degree, "loss_first_last": [round(res["loss"][0], 5), round(res["loss"][-1], 5)],
+        "speculation": {"frames": ops.SPECULATION["frames"] - frames0, "misses": ops.SPECULATION["misses"] - misses0,
+                        "cold": ops.SPECULATION["cold"] - cold0},
+        "device_mallocs": torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0,
+        "schedule": {"densify_from_iter": 100, "densification_interval": 100, "opacity_reset_interval": 300, "sh_degree_up_interval": 150,
+                     "densify_grad_threshold": 0.0002, "reference_defaults": "500 / 100 / 3000 / 1000 / 0.0002"},
+    }
 
 
 def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
@@ -784,6 +841,11 @@ def main():
                                       "one forward + backward per camera of the set, no parameter update (the workload-statistics pass / first pass over the data set)"),
             "cameras": {"count": len(cam_dicts), "per_camera": per_cam if len(per_cam) <= 64 else None},
         }
+        if world == 1 and mode == "single" and args.loop == "reference-shaped":
+            try:
+                line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps)
+            except Exception as e:  # an extra: it must never take the bench line down
+                line["reference_shaped_loop"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             sample = args.workload if args.cpu_sample == "auto" else args.cpu_sample
             try:
