@@ -69,7 +69,7 @@ def parse():
                    help="skip the per-camera pass that counts I, I', V and the blended pairs after the timed regions (profiler runs: the last "
                         "launches of the process are then the last timed step); the line carries no roofline")
     p.add_argument("--workload", default="S-1080p-1M")
-    p.add_argument("--api", default="vanilla", choices=["vanilla", "gsplat"])
+    p.add_argument("--api", default=None, choices=["vanilla", "gsplat"], help="default: the workload's (vanilla unless it says otherwise)")
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
                    help="l1: mean |render - target| with torch ops; photometric: the reference's training loss "
                         "0.8 L1 + 0.2 (1 - SSIM) (vanilla_metrics.py:66-68) through the fused HIP loss kernels")
@@ -166,12 +166,15 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps):
 
 
 def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
+    sh_degree, absgrad = wl.get("sh_degree", 3), bool(wl.get("absgrad", False))
     """One training step (forward, loss, backward) on the next camera of `cams` (call k of rank r takes camera (k * world + r) mod
     len(cams)).  With state["marks"] = [] the step leaves three events per call (start, before backward, after backward) for the
     fwd_ms / bwd_ms of the bench line."""
     import gspl_amd  # noqa: F401
     from gspl_amd import ops
-    m, s, q, o, dc, rest = tensors          # the reference model's six parameters (shs_dc and shs_rest apart, vanilla_gaussian.py:266-300)
+    # the reference model's six parameters (shs_dc and shs_rest apart, vanilla_gaussian.py:266-300); five at SH degree 0
+    m, s, q, o, dc = tensors[:5]
+    rest = tensors[5] if len(tensors) > 5 else None
     W, H = wl["width"], wl["height"]
     bg = torch.zeros(3, device=dev)
     target = torch.full((3, H, W), 0.5, device=dev)
@@ -189,7 +192,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
     if api == "vanilla":
         rasts = [ops.GaussianRasterizer(ops.GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
-            viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=3,
+            viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=sh_degree,
             campos=cam["camera_center"].to(dev))) for cam in cams]
 
         def step():
@@ -229,8 +232,8 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             opac = o * comp[:, None]
             # same order as HipGSplatRenderer.forward: count half of the binning, SH, emit half, compositing
             pending = ops.bin_gaussians_begin(xys, depths, radii, H, W, 16, conics=conics, opacities=opac)
-            rgbs = ops.sh_view_colors(3, m, center, dc, rest, radii > 0)
-            img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg,
+            rgbs = ops.sh_view_colors(sh_degree, m, center, dc, rest, radii > 0)
+            img = ops.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, opac, H, W, 16, bg, absgrad=absgrad,
                                           isects=ops.bin_gaussians_end(pending, lazy=True), channels_first=True)
             loss = loss_fn(img)
             if marks is not None:
@@ -238,7 +241,8 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             loss.backward()
             if marks is not None:
                 marks.append(_mark())
-            state["vs_grad"], state["radii"], state["loss"] = xys.grad, radii, loss
+            # configs/gsplat-absgrad.yaml:6-8: the density controller reads `viewspace_points.absgrad`
+            state["vs_grad"], state["radii"], state["loss"] = (xys.absgrad if absgrad else xys.grad), radii, loss
             state["grad_scale"] = grad_scale
             return state
     step.state = state
@@ -405,6 +409,11 @@ def pmc_traffic(workload_key, kernel):
 
 def main():
     args = parse()
+    if args.api is None:      # the workload's API (configs[4] proxy: gsplat), vanilla otherwise — the reference's default renderer
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import gspl_amd  # noqa: F401
+        from gspl_amd import synthetic as _syn
+        args.api = _syn.WORKLOADS[args.workload].get("api", "vanilla")
     if args.cpu_baseline_only:
         sample = args.workload if args.cpu_sample == "auto" else args.cpu_sample
         print(json.dumps(cpu_baseline(sample, args.api)), flush=True)
@@ -444,7 +453,8 @@ def main():
         gdist.SINGLE_RANK_SHORTCUT = False
     wl = synthetic.WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
-    means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
+    means, scales, quats, opac, shs = synthetic.workload_scene(wl, seed=42)
+    SH_DEGREE = wl.get("sh_degree", 3)
     # The camera set the steps cycle through: rank r takes camera (k * world + r) mod n at its step k (cameras sharded over the
     # ranks, one per rank per step).  Camera 0 is the pose the workload is defined on.
     n_cams = max(args.cameras, world)
@@ -521,10 +531,10 @@ def main():
         api = "gsplat"
     else:
         # the reference model's parameters: the SH coefficients are two of them, shs_dc [N,1,3] and shs_rest [N,15,3]
-        tensors = [t.contiguous().to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs[:, :1], shs[:, 1:])]
+        tensors = [t.contiguous().to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs[:, :1], shs[:, 1:]) if t.shape[1] > 0]
         N = wl["n"]
         step = make_step(args.api, dev, wl, cam_dicts, tensors, args.loss, rank, world)
-        lrs = LRS[:4] + (LRS[4], LRS[4] / 20.0)
+        lrs = (LRS[:4] + (LRS[4], LRS[4] / 20.0))[:len(tensors)]
 
         def stats(st, accum, denom, max_radii):
             densification_stats(st, accum, denom, max_radii)
@@ -817,7 +827,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "api": api, "n_gaussians": wl["n"], "width": W, "height": H,
-                       "sh_degree": 3, "loss": args.loss, "optimizer": args.optimizer, "step": step_desc,
+                       "sh_degree": SH_DEGREE, "absgrad": bool(wl.get("absgrad", False)), "loss": args.loss, "optimizer": args.optimizer, "step": step_desc,
                        "parallelism": par, "parallelism_mode": mode,
                        **({"init_dist": f"process group of one rank on {args.dist_backend}: every collective of this mode is issued (code-path run, not a scaling point)"}
                           if args.init_dist else {})},
@@ -841,7 +851,7 @@ def main():
                                       "one forward + backward per camera of the set, no parameter update (the workload-statistics pass / first pass over the data set)"),
             "cameras": {"count": len(cam_dicts), "per_camera": per_cam if len(per_cam) <= 64 else None},
         }
-        if world == 1 and mode == "single" and args.loop == "reference-shaped":
+        if world == 1 and mode == "single" and args.loop == "reference-shaped" and api == "vanilla" and SH_DEGREE == 3:
             try:
                 line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps)
             except Exception as e:  # an extra: it must never take the bench line down

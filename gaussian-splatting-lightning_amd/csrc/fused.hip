@@ -246,6 +246,10 @@ extern "C" int gspl_rasterize_inria_fwd(
                 (void)hipEventSynchronize(ev_cnt);
                 n_isects = host[0];
             }
+            if (n_isects > (int64_t)((1u << 30) - 1u)) {
+                set_error("rasterize_inria_fwd", "more than 2^30-1 (tile, Gaussian) intersections in one frame: the per-tile lists hold at most 1073741823 entries");
+                return GSPL_ERR_UNSUPPORTED;
+            }
             if (n_isects > 0 && (!ws2 || capacity < n_isects)) {
                 capacity = n_isects;
                 ws2_bytes = gspl_bin_workspace_bytes(N, capacity);

@@ -1001,6 +1001,7 @@ def _take_event(dev):
     return pool.pop() if pool else torch.cuda.Event()
 
 
+MAX_ISECTS = 2 ** 30 - 1      # RADIX_MAX_ITEMS of csrc/gspl_sort.h: the list positions and the sort's workgroup spans are 32-bit
 _LAST_ISECTS: dict = {}       # (device, tile grid) -> list length of the last frame: the guess of the speculative emission
 # How the guesses fared (bench.py reports the miss rate): frames binned, frames without a guess (first of a size: the host waits),
 # frames whose guess was too low (emission, sort and — in the fused call — compositing are repeated).
@@ -1058,7 +1059,7 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
         # that turns out too low costs one repeated emission in `bin_gaussians_end`.
         guess = _LAST_ISECTS.get((dev.index, p.tile_w, p.tile_h), 0)
         if SPECULATIVE_EMIT and guess > 0:
-            p.capacity = int(guess * 1.25) + 65536
+            p.capacity = min(int(guess * 1.25) + 65536, MAX_ISECTS)
             p.ws2_bytes = lib.gspl_bin_workspace_bytes(N, p.capacity)
             if p.ws2_bytes == 0:
                 raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
@@ -1120,6 +1121,9 @@ def _bin_count_arrived(p: _PendingBins) -> int:
     _EVENTS[p.dev.index].append(p.event)
     n_isects = int(p.host_count[0])
     _PINNED_WORDS.append(p.host_count)
+    if n_isects > MAX_ISECTS:
+        raise RuntimeError(f"{n_isects} (tile, Gaussian) intersections in one frame: the per-tile lists of this library hold at most "
+                           f"2^30-1 = {MAX_ISECTS} entries (fewer / smaller Gaussians, a larger tile size or a lower resolution)")
     _LAST_ISECTS[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
     SPECULATION["frames"] += 1
     if p.capacity == 0:
@@ -1606,7 +1610,7 @@ class _InriaFusedFn(torch.autograd.Function):
         tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
         key = (dev.index, tile_w, tile_h)
         guess = _LAST_ISECTS.get(key, 0)
-        hint = (int(guess * 1.25) + 65536) if (SPECULATIVE_EMIT and guess > 0) else 0
+        hint = min(int(guess * 1.25) + 65536, MAX_ISECTS) if (SPECULATIVE_EMIT and guess > 0) else 0
         state = L.InriaState()
         holder = {"device": dev}
         _ALLOC_TLS.holder = holder

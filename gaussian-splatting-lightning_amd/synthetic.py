@@ -20,7 +20,16 @@ WORKLOADS = {
     # camera INSIDE the cloud (distance 0.4 from its centre): roughly half of the Gaussians are behind the camera or outside
     # the frustum, as in real captures; exercises the visibility-masked SH loads
     "S-1080p-1M-inside": dict(n=1_000_000, width=1920, height=1080, fx=1600.0, distance=0.4),
+    # BASELINE.json configs[4] proxy (MatrixCity aerial partition, configs/matrixcity/gsplat-aerial.yaml:25 + configs/gsplat-absgrad.yaml:6-8):
+    # ~20 M small Gaussians at SH degree 0 (56 B of parameters each), gsplat API, absgrad densification statistics
+    "S-1080p-20M-sh0-absgrad": dict(n=20_000_000, width=1920, height=1080, fx=1600.0, sh_degree=0, scale_mul=0.4, api="gsplat", absgrad=True),
 }
+
+
+def workload_scene(wl: dict, seed: int = 42):
+    """`scene` with the workload's SH degree and scale multiplier."""
+    means, scales, quats, opac, shs = scene(wl["n"], seed=seed, sh_degree=wl.get("sh_degree", 3))
+    return means, scales * wl.get("scale_mul", 1.0), quats, opac, shs
 
 
 def scene(n: int, seed: int = 42, sh_degree: int = 3):

@@ -405,3 +405,32 @@ def test_renderers_accept_the_reference_block_size_field(block_size):
                 assert_close_scaled(y.cpu().numpy(), x.cpu().numpy(), 1e-4, "gradient", frac_ok=1.0)
     assert HipGSplatV1Renderer(block_size=block_size).block_size == block_size      # the field itself is kept
     assert any("16 x 16" in str(w.message) for w in caught) or block_size == 16
+
+
+@pytest.mark.parametrize("which", ["gsplat_v0", "vanilla"])
+def test_more_list_entries_than_the_library_holds_is_a_python_exception_naming_the_limit(which):
+    """VERDICT r3 / BASELINE configs[4] scale: every list path of the library indexes its per-tile lists with 32-bit positions and
+    sorts at most 2^30-1 records.  A frame beyond that (here 140 000 screen-filling splats x 8160 tiles = 1.14e9 intersections —
+    only the COUNT half of the binning runs, nothing of that size is allocated) must surface from the renderer's forward as an
+    exception that names the limit, on both plugin families."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipGSplatRenderer, HipVanillaRenderer
+    from gspl_amd import synthetic
+    n, W, H = 140_000, 1920, 1080
+    g = torch.Generator().manual_seed(0)
+    means = (torch.rand(n, 3, generator=g) - 0.5) * 0.02                      # all in front of the camera, near the axis
+    scales = torch.full((n, 3), 8.0)                                          # projected radius far beyond the image
+    quats = torch.tensor([[1.0, 0.0, 0.0, 0.0]]).repeat(n, 1)
+    opac = torch.full((n, 1), 0.5)
+    shs = torch.zeros(n, 16, 3)
+    model = FakeGaussianModel(*[t.to(DEV) for t in (means, scales, quats, opac, shs)])
+    camera = FakeCamera(synthetic.camera(W, H, 1600.0), DEV)
+    renderer = HipGSplatRenderer() if which == "gsplat_v0" else HipVanillaRenderer()
+    with pytest.raises(RuntimeError, match=r"2\^30-1"):
+        with torch.no_grad():
+            renderer(camera, model, torch.zeros(3, device=DEV))
+    # and the next, ordinary frame is unaffected
+    small = FakeGaussianModel(*[t[:2000].to(DEV) for t in (means, scales * 0.001, quats, opac, shs)])
+    with torch.no_grad():
+        out = renderer(camera, small, torch.zeros(3, device=DEV))
+    assert torch.isfinite(out["render"]).all()
