@@ -49,6 +49,12 @@ def test_single_gpu_line():
               "inria_preprocess_bwd_with_sh_bwd", "adam"):
         assert sr[k]["ms"] > 0 and sr[k]["bytes"] > 0 and abs(sr[k]["frac"] - sr[k]["GBps"] / 8000.0) <= 2e-4, k
     assert roof["traffic"] is None or "same ABI and kernel sources" in roof["traffic_source"]      # stale PMC files are refused
+    # round 4: the reference-shaped loop (raw parameters, density controller, N changes) rides in the same line
+    loop = line["reference_shaped_loop"]
+    assert "failed" not in loop, loop
+    assert loop["images_per_s_densifying"] > 0 and loop["steps"] == 450 and loop["sh_degree_end"] == 3
+    assert sum(1 for e in loop["events"] if "n_after" in e) >= 3 and any(e.get("opacity_reset") for e in loop["events"])
+    assert loop["speculation"]["frames"] == 450 and loop["loss_first_last"][1] < loop["loss_first_last"][0]
 
 
 @pytest.mark.gpu
@@ -67,9 +73,13 @@ def test_two_rank_launch_line(mode):
     assert ("masked" in line["config"]["parallelism"]) == (mode == "replicated-masked")
     assert abs(line["value"] - 2e3 / line["ms_per_step"]) <= 1e-3 * line["value"]               # whole-job images/s
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None                           # rank 0, N = 1 only
-    roof = line["roofline"]                          # the byte model counts every tile-rect intersection, in every mode
+    roof = line["roofline"]          # `frac` is priced on the list entries the launch WALKS; the rect intersections beside it
     assert roof["intersections"] >= roof["list_entries"] > 0
-    assert abs(roof["algorithmic_bytes"] - (76.0 * roof["intersections"] + 20.0 * line["config"]["width"] * line["config"]["height"])) < 1.0
+    P = line["config"]["width"] * line["config"]["height"]
+    assert abs(roof["algorithmic_bytes"] - (76.0 * roof["list_entries"] + 20.0 * P)) < 1.0
+    assert abs(roof["frac"] - roof["algorithmic_bytes"] / (roof["avg_ms"] * 1e-3) / 1e9 / roof["peak"]) <= 2e-3 * roof["frac"] + 1e-5
+    on_rects = (76.0 * roof["intersections"] + 20.0 * P) / (roof["avg_ms"] * 1e-3) / 1e9 / roof["peak"]
+    assert abs(roof["frac_on_rect_intersections"] - on_rects) <= 2e-3 * on_rects + 1e-5 and roof["frac_on_rect_intersections"] >= roof["frac"]
 
 
 def test_cpu_baseline_leg_runs_without_a_gpu():
