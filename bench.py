@@ -86,6 +86,9 @@ def parse():
     p.add_argument("--no-overlap-sh-update", action="store_true", help="(the default; kept for older command lines)")
     p.add_argument("--exchange", default="auto", choices=["counted", "padded", "auto"],
                    help="--parallelism sharded: format of the per-step record exchange (renderer option `exchange`)")
+    p.add_argument("--exchange-transport", default="collective", choices=["collective", "peer"],
+                   help="--parallelism sharded: collective = torch.distributed all-to-all (RCCL); peer = direct writes into the peers' IPC-mapped "
+                        "receive buffers + flags (renderer option `exchange_transport`)")
     p.add_argument("--staged-sharded-step", action="store_true",
                    help="--parallelism sharded: the stage-by-stage formulation of the step (eleven autograd nodes) instead of the three-node one")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
@@ -490,7 +493,8 @@ def main():
         N = hi - lo
         cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
         # tile_based_culling as in the reference's configs/distributed-accel.yaml (lossless here: same images and gradients)
-        renderer = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step, exchange=args.exchange).instantiate()
+        renderer = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step, exchange=args.exchange,
+                                                exchange_transport=args.exchange_transport).instantiate()
         renderer.world_size, renderer.global_rank = world, rank
         renderer.camera_lookup = lambda idx, training: cams[idx]
         renderer.train()
@@ -818,7 +822,7 @@ def main():
                                  "chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step")
                               + f", all-reduce of the densification stats every {DENSIFY_INTERVAL} steps"),
                "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of splat records (configs/distributed.yaml); "
-                          + (f"exchange format of the last step: {renderer.last_exchange}; step as "
+                          + (f"exchange format of the last step: {renderer.last_exchange} over {args.exchange_transport}; step as "
                              + ("eleven stage-by-stage autograd nodes" if args.staged_sharded_step else "three autograd nodes (front / exchange / back)")
                              if mode == "sharded" else "")}[mode]
         line = {

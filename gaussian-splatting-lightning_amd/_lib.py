@@ -73,6 +73,13 @@ _SIGNATURES = {
     "gspl_records_pack_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_unpack_fwd": (c_int, [ctypes.c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_records_unpack_bwd": (c_int, [ctypes.c_int64, c_int, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P]),
+    "gspl_peer_alloc": (c_int, [c_size_t, _P, _P]),
+    "gspl_peer_open": (c_int, [_P, _P]),
+    "gspl_peer_close": (c_int, [_P]),
+    "gspl_peer_free": (c_int, [_P]),
+    "gspl_peer_put_rows": (c_int, [c_int, _P, _P, _P, c_int, _P]),
+    "gspl_peer_signal": (c_int, [c_int, _P, ctypes.c_uint64, _P]),
+    "gspl_peer_wait": (c_int, [_P, c_int, ctypes.c_uint64, ctypes.c_uint64, _P, _P]),
     "gspl_sh_fwd": (c_int, [c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),
     "gspl_sh_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P]),
     "gspl_sh_fwd_batched": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, _P]),

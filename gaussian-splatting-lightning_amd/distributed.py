@@ -123,6 +123,149 @@ def all_to_all_route(send_counts: Sequence[int], recv_counts: Sequence[int], gro
             lambda v_rows: _all_to_all_rows_raw(v_rows, recv_counts, send_counts, group))
 
 
+class _DevicePtr:
+    """A region of raw device memory as something `torch.as_tensor` understands (CUDA array interface)."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PeerExchange:
+    """The fixed-size ("padded") record exchange of the Gaussian-sharded renderer WITHOUT a collective: every rank writes its rows
+    straight into the receive buffer of the rank that renders that camera — device memory of the peer PROCESS mapped once through HIP
+    IPC (csrc/peer.hip: fine-grained memory, reached over xGMI or on the same GPU) — and raises a flag word per destination; the
+    receiver's stream waits for the flag words of its sources.  Three small launches per direction, nothing for the host to wait
+    for, no count exchange.  Replaces the per-step `all_to_all` of gsplat_distributed_renderer.py:141-202 (`all_to_all_route` above
+    stays as the route of the gloo / CPU tests and of the variable-size "counted" format).
+
+    Every rank derives the SAME layout from the same `rows_per_rank` (the local Gaussian counts, which the per-step all-gather of the
+    camera ids carries).  One allocation per rank:
+        [flags fwd: W x u64][flags bwd: W x u64][error: i32] | 2 x forward receive (rows of every source for MY camera, by source)
+        | 2 x backward receive (gradients of the rows I sent, by destination)
+    Two copies of each receive area, used alternately (step parity): a source may run one exchange ahead of the slowest reader of
+    the previous one, never two (its next forward needs every peer's backward rows of this step).  Training steps only — a
+    forward without backward has no such bound and takes the collective route.
+    Buffers grow (x 1.5, identically on every rank) when the Gaussian counts outgrow them; the handles are exchanged again then."""
+
+    FLOATS = RECORD_FLOATS
+    MAX_POLLS = 4_000_000          # ~ a few seconds of polling before a wait gives up and raises the error word
+
+    def __init__(self, rank: int, group, device):
+        self.rank, self.group, self.device = int(rank), group, torch.device(device)
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 16:
+            raise NotImplementedError("PeerExchange: up to 16 ranks (one node)")
+        self.step = 0
+        self.cap_total = self.cap_rank = 0
+        self.base: List[int] = []          # base pointer of every rank's buffer in THIS process
+        self._mine = None
+        self._opened: List[int] = []
+        self._layout = None
+
+    # ---- layout (identical on every rank) -----------------------------------------------------------------------------
+    def _plan(self, cap_total: int, cap_rank: int):
+        W, row = self.world, self.FLOATS * 4
+        up = lambda x: (x + 255) // 256 * 256
+        flags_f, flags_b = 0, up(8 * W)
+        err = flags_b + up(8 * W)
+        fwd = err + 256
+        fwd_stride = up(cap_total * row)
+        bwd = fwd + 2 * fwd_stride
+        bwd_stride = up(W * cap_rank * row)
+        return dict(flags_f=flags_f, flags_b=flags_b, err=err, fwd=fwd, fwd_stride=fwd_stride, bwd=bwd, bwd_stride=bwd_stride, total=bwd + 2 * bwd_stride)
+
+    def _ensure(self, rows_per_rank: Sequence[int]):
+        total, biggest = int(sum(rows_per_rank)), int(max(rows_per_rank))
+        if self._mine is not None and total <= self.cap_total and biggest <= self.cap_rank:
+            return
+        import ctypes
+        from . import _lib as L
+        self.close()
+        self.cap_total, self.cap_rank = int(total * 1.5) + 1024, int(biggest * 1.5) + 1024
+        self._layout = lay = self._plan(self.cap_total, self.cap_rank)
+        with torch.cuda.device(self.device):
+            ptr, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+            L.check(L.lib().gspl_peer_alloc(lay["total"], ctypes.byref(ptr), handle), "gspl_peer_alloc")
+            self._mine = int(ptr.value)
+            handles = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(handles, (self.rank, handle.raw), group=self.group)
+            else:
+                handles = [(self.rank, handle.raw)]
+            self.base, self._opened = [0] * self.world, []
+            for r, raw in handles:
+                if r == self.rank:
+                    self.base[r] = self._mine
+                    continue
+                p = ctypes.c_void_p()
+                L.check(L.lib().gspl_peer_open(ctypes.create_string_buffer(raw, 64), ctypes.byref(p)), "gspl_peer_open")
+                self.base[r] = int(p.value)
+                self._opened.append(int(p.value))
+        if self.world > 1:
+            dist.barrier(group=self.group)          # nobody writes into a buffer its owner has not mapped and cleared yet
+
+    def close(self):
+        if self._mine is None:
+            return
+        from . import _lib as L
+        torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.group)          # the peers are done with the old buffers
+        with torch.cuda.device(self.device):
+            for p in self._opened:
+                L.lib().gspl_peer_close(p)
+            L.lib().gspl_peer_free(self._mine)
+        self._mine, self._opened, self.base = None, [], []
+
+    def check(self):
+        """Raises if a wait of this rank gave up (a peer that never signalled).  Synchronises the current stream."""
+        if self._mine is None:
+            return
+        err = int(torch.as_tensor(_DevicePtr(self._mine + self._layout["err"], (1,), "<i4"), device=self.device).item())
+        if err:
+            raise RuntimeError(f"PeerExchange: rank {self.rank} gave up waiting for the records of rank {err - 1} (step {self.step})")
+
+    # ---- one exchange ---------------------------------------------------------------------------------------------------
+    def _send(self, rows: torch.Tensor, begin: List[int], dst: List[int], flag_dst: List[int], my_flags: int, value: int):
+        import ctypes
+        from . import _lib as L
+        W = self.world
+        rows = rows.contiguous()
+        with torch.cuda.device(self.device):
+            L.call("gspl_peer_put_rows", W, L.ptr(rows), (ctypes.c_int64 * (W + 1))(*begin), (ctypes.c_void_p * W)(*dst), self.FLOATS, L.stream())
+            L.call("gspl_peer_signal", W, (ctypes.c_void_p * W)(*flag_dst), value, L.stream())
+            L.call("gspl_peer_wait", ctypes.c_void_p(my_flags), W, value, self.MAX_POLLS, ctypes.c_void_p(self._mine + self._layout["err"]), L.stream())
+
+    def route(self, rows_per_rank: Sequence[int]):
+        """(forward, backward) callables for `ops.sharded_exchange`, as `all_to_all_route` returns them, for ONE training step:
+        forward: rows [W * n_me, 12] grouped by destination -> rows [sum n_s, 12] grouped by source (a view of this rank's receive
+        buffer, valid until the exchange after the next one); backward: gradients of those -> gradients of the rows that were sent."""
+        rows_per_rank = [int(v) for v in rows_per_rank]
+        self._ensure(rows_per_rank)
+        self.step += 1
+        step, par, lay, W, me, row = self.step, self.step & 1, self._layout, self.world, self.rank, self.FLOATS * 4
+        n_me, total = rows_per_rank[me], sum(rows_per_rank)
+        prefix = [0]
+        for v in rows_per_rank:
+            prefix.append(prefix[-1] + v)
+        fwd_of = lambda r: self.base[r] + lay["fwd"] + par * lay["fwd_stride"]
+        bwd_of = lambda r: self.base[r] + lay["bwd"] + par * lay["bwd_stride"]
+        view = lambda ptr, n: torch.as_tensor(_DevicePtr(ptr, (n, self.FLOATS), "<f4"), device=self.device)
+
+        def forward(rows: torch.Tensor) -> torch.Tensor:
+            assert rows.shape == (W * n_me, self.FLOATS) and rows.dtype == torch.float32, (tuple(rows.shape), W, n_me)
+            self._send(rows, [d * n_me for d in range(W + 1)], [fwd_of(d) + prefix[me] * row for d in range(W)],
+                       [self.base[d] + lay["flags_f"] + 8 * me for d in range(W)], self._mine + lay["flags_f"], step)
+            return view(fwd_of(me), total) if total else rows.new_zeros((0, self.FLOATS))
+
+        def backward(v_rows: torch.Tensor) -> torch.Tensor:
+            assert v_rows.shape == (total, self.FLOATS), (tuple(v_rows.shape), total)
+            self._send(v_rows.to(torch.float32), prefix, [bwd_of(s) + me * rows_per_rank[s] * row for s in range(W)],
+                       [self.base[s] + lay["flags_b"] + 8 * me for s in range(W)], self._mine + lay["flags_b"], step)
+            return view(bwd_of(me), W * n_me) if n_me else v_rows.new_zeros((0, self.FLOATS))
+        return forward, backward
+
+
 def pack_visible(radii, means2d, depths, conics, compensations, opacities, rgbs, visibility) -> torch.Tensor:
     """[n_vis, 12] fp32 records of the splats `visibility` selects (one camera)."""
     rbits = radii.to(torch.int32).view(torch.float32)

@@ -50,6 +50,12 @@ class HipGSplatDistributedRenderer(RendererConfig):
     exchange: str = "auto"
     padded_min_visible: float = 0.5
     auto_padded_with_peers: bool = False      # let "auto" vote for the padded format with more than one rank too
+    # How the records of a training step travel.  "collective": torch.distributed all-to-all (RCCL over xGMI; gloo in the tests) —
+    # the reference's transport.  "peer": every rank writes its rows straight into the destination rank's receive buffer (HIP IPC
+    # mapping, fine-grained device memory) and raises a flag the receiver's stream waits for (distributed.PeerExchange, csrc/peer.hip):
+    # no collective and no host round trip in the step.  Implies the fixed-size "padded" format (every size is known before the step);
+    # GPU, three-node step, training steps only — anything else takes the collective route.
+    exchange_transport: str = "collective"
     # The step as three autograd nodes (`ops.sharded_front` / `sharded_exchange` / `sharded_back`: project + colours + pack, the
     # all-to-all, unpack + bin + composite) instead of eleven — same kernels, same numbers, less host work per step.  Taken on
     # the GPU (either exchange format) when nothing is overridden (`get_rgbs`) and only "rgb" is asked for; that path hands out
@@ -98,6 +104,11 @@ class HipGSplatDistributedRendererImpl(Renderer):
         self.profiler = None
         if config.exchange not in ("auto", "counted", "padded"):
             raise ValueError(f"exchange must be auto | counted | padded, got {config.exchange!r}")
+        if config.exchange_transport not in ("collective", "peer"):
+            raise ValueError(f"exchange_transport must be collective | peer, got {config.exchange_transport!r}")
+        if config.exchange_transport == "peer" and config.exchange == "counted":
+            raise ValueError("exchange_transport='peer' sends fixed-size records: exchange must be 'padded' or 'auto'")
+        self._peer = None                         # distributed.PeerExchange, created by the first step that uses it
         self.last_exchange = None                 # format the last forward used ("counted" | "padded"; None: nothing exchanged)
         self._visible_permille = -1               # share of (camera, splat) pairs visible in this rank's last step; -1: unknown
         self._visible_pending = None              # (event, pinned word, total) of a count still on its way to the host
@@ -201,6 +212,8 @@ class HipGSplatDistributedRendererImpl(Renderer):
     def _exchange_format(self) -> str:
         """Identical on every rank: a function of the configuration and of the gathered rows only."""
         c = self.config
+        if c.exchange_transport == "peer":
+            return "padded"
         if c.exchange != "auto":
             return c.exchange
         if self._world() > 1 and not c.auto_padded_with_peers:
@@ -390,7 +403,13 @@ class HipGSplatDistributedRendererImpl(Renderer):
                 n = self.__dict__["_padded_steps"] = self.__dict__.get("_padded_steps", 0) + 1
                 if n % 8 == 1:
                     self._post_visible_count(vis, pairs)
-                if exchanging:
+                if exchanging and c.exchange_transport == "peer" and torch.is_grad_enabled():
+                    if self._peer is None:
+                        self._peer = D.PeerExchange(rank, self.group, records.device)
+                    route = self._peer.route(peer_counts)
+                    if n % 64 == 0:
+                        self._peer.check()          # (a wait that gave up; synchronises, hence seldom)
+                elif exchanging:
                     route = D.all_to_all_route(send_counts, peer_counts, self.group)
             else:
                 self._visible_permille, self._visible_pending = int(1000 * sum(send_counts) // pairs), None

@@ -468,6 +468,28 @@ int gspl_records_unpack_bwd(int64_t M, int fold_compensation, const float* recor
                             const float* v_conics /*nullable*/, int v_conics_stride, const float* v_opacities /*nullable*/, int v_opacities_stride,
                             const float* v_colors /*nullable*/, int v_colors_stride, float* v_records, void* stream);
 
+/*    Direct peer-to-peer transport of the records (csrc/peer.hip): instead of an all-to-all collective, every rank writes its rows
+ *    straight into the receive buffer of the destination rank — device memory of the peer process mapped through HIP IPC, reached
+ *    over xGMI (or the same GPU) — and raises one flag word per destination; the receiver's stream waits for its flag words.
+ *    Replaces torch.distributed.nn.functional.all_to_all of gsplat_distributed_renderer.py:141-202 in the per-step exchange.
+ *      gspl_peer_alloc   fine-grained device memory (remote stores are visible without an L2 invalidation) + its 64-byte IPC handle,
+ *                        which the host sends to the peers once (e.g. torch.distributed.all_gather_object at training_setup)
+ *      gspl_peer_open    maps a peer's buffer from its handle (gspl_peer_close unmaps; gspl_peer_free releases an own buffer)
+ *      gspl_peer_put_rows  one launch: rows [row_begin[d], row_begin[d+1]) of `rows` -> dst[d] (16-byte stores; up to 16 destinations)
+ *      gspl_peer_signal  one launch behind it: system-scope release fence, then `value` into every flag word
+ *      gspl_peer_wait    one launch on the receiver: polls its n_src flag words until all are >= value; gives up after max_polls
+ *                        polls and stores 1 + source into *error (a lost peer must not hang the GPU; the host checks the word)
+ *    Additive entries (no existing signature changed: the ABI version stays). */
+int gspl_peer_alloc(size_t bytes, void** ptr, void* handle_out /* 64 bytes */);
+int gspl_peer_open(const void* handle /* 64 bytes */, void** ptr);
+int gspl_peer_close(void* ptr);
+int gspl_peer_free(void* ptr);
+int gspl_peer_put_rows(int n_dst, const float* rows, const int64_t* row_begin /* host, [n_dst + 1] */,
+                       void* const* dst /* host, [n_dst] device pointers */, int floats_per_row /* multiple of 4 */, void* stream);
+int gspl_peer_signal(int n_dst, void* const* flags /* host, [n_dst] device pointers to 8-byte words */, uint64_t value, void* stream);
+int gspl_peer_wait(const uint64_t* flags /* device, [n_src] */, int n_src, uint64_t value, uint64_t max_polls,
+                   int32_t* error /* device word */, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 7. Mean squared distance to the 3 nearest neighbours ("next" row SURVEY.md §8f rank 1).
  *    Replaces `simple_knn._C.distCUDA2` at its one call site, the initial scales of

@@ -163,7 +163,9 @@ def _close(got, ref, rel, name, tiered=False):
 
 
 def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
-    exchange, _, form = exchange.partition("-")           # "padded-staged": the stage-by-stage formulation of the step
+    parts = exchange.split("-")                           # "padded-staged": the stage-by-stage formulation of the step;
+    exchange, form = parts[0], ("staged" if "staged" in parts else "")      # "padded-peer": direct peer writes instead of the collective
+    transport = "peer" if "peer" in parts else "collective"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     for p in (HERE, os.path.dirname(HERE)):
@@ -193,7 +195,8 @@ def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
             p = g["params"][0]
             opt.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.ones_like(p), "exp_avg_sq": torch.ones_like(p)}
         module = _Module(model, [opt], world, rank, dev)
-        renderer = HipGSplatDistributedRenderer(exchange=exchange, fused_step=(form != "staged"), auto_padded_with_peers=True).instantiate()
+        renderer = HipGSplatDistributedRenderer(exchange=exchange, fused_step=(form != "staged"), auto_padded_with_peers=True,
+                                                exchange_transport=transport).instantiate()
         assert renderer.training_setup(module) == (None, None)
         assert module.density_changes == 1 and renderer.world_size == world and renderer.global_rank == rank
         assert model.n_gaussians == hi - lo and torch.equal(model.get_property("ids").cpu(), ids[lo:hi])
@@ -215,6 +218,16 @@ def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
         # "auto" starts with the counted exchange (no rank has a visible share to vote with yet) and moves to the padded one when
         # every rank saw at least half of its (camera, splat) pairs; the other two settings are fixed
         assert renderer.last_exchange == ("counted" if exchange == "auto" else exchange)      # (auto: nobody has voted yet)
+        if transport == "peer":
+            # the records of this step went through the peers' IPC-mapped buffers, not through a collective: the image must be the
+            # one the collective route composes from the same records, bit for bit (the forward pass is deterministic)
+            assert renderer._peer is not None and renderer._peer.step == 1 and renderer._peer.world == world
+            via_collective = HipGSplatDistributedRenderer(exchange="padded", fused_step=True).instantiate()
+            via_collective.world_size, via_collective.global_rank = world, rank
+            via_collective.camera_lookup = renderer.camera_lookup
+            via_collective.train()
+            other = via_collective(camset[rank], model, bg.to(dev))["render"]
+            assert via_collective._peer is None and torch.equal(other, out["render"])
         assert [r[1] for r in renderer._peer_rows] == [D.shard_bounds(N, world, r)[1] - D.shard_bounds(N, world, r)[0] for r in range(world)]
         for r in out["projection_results_list"]:          # what DistributedVanillaDensityControllerImpl.before_backward does
             r[1].retain_grad()
@@ -367,10 +380,11 @@ def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["auto", "padded", "auto-staged"])
+@pytest.mark.parametrize("exchange", ["auto", "padded", "auto-staged", "padded-peer"])
 def test_world2_sharded_renderer_shared_gpu(tmp_path, exchange):
     """On the GPU the step runs as three autograd nodes (ops.sharded_front / sharded_exchange / sharded_back); "auto-staged" keeps
-    the stage-by-stage formulation (what a subclass overriding `get_rgbs` and the extra render types take) under the same checks."""
+    the stage-by-stage formulation (what a subclass overriding `get_rgbs` and the extra render types take) under the same checks;
+    "padded-peer": the two processes (sharing the GPU) write their records straight into each other's IPC-mapped receive buffers."""
     _run(tmp_path, True, exchange=exchange)
 
 

@@ -1,0 +1,56 @@
+"""distributed.PeerExchange / csrc/peer.hip: the direct peer-write transport of the sharded renderer's records.
+One process (its own and only peer) exercises the three launches — put, signal, wait —, the two receive areas used alternately,
+buffer growth and the give-up path of the wait; two processes on one GPU (IPC mapping of each other's buffers) run in
+tests/test_distributed_renderer.py::test_world2_sharded_renderer_shared_gpu[padded-peer]."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_round_trips_and_growth():
+    import gspl_amd  # noqa: F401
+    from gspl_amd import distributed as D
+    dev = torch.device("cuda:0")
+    px = D.PeerExchange(0, None, dev)
+    g = torch.Generator().manual_seed(0)
+    last = None
+    for n in (1000, 1000, 1000, 777, 5000, 0, 12):          # 5000 outgrows the first allocation (1.5 x 1000 + 1024 rows)
+        capacity_before = px.cap_total
+        fwd, bwd = px.route([n])
+        rows = torch.randn(n, 12, generator=g).to(dev)
+        got = fwd(rows)
+        assert got.shape == (n, 12) and torch.equal(got, rows)
+        if last is not None and last[0].shape[0] and n and px.cap_total == capacity_before:
+            assert torch.equal(last[0], last[1])             # the previous step's rows are still intact (the other receive area)
+        if n == 5000:
+            assert px.cap_total > capacity_before      # (the buffers were re-allocated — possibly at the same address; views of the old ones are dead)
+        v = torch.randn(n, 12, generator=g).to(dev)
+        back = bwd(v)
+        assert back.shape == (n, 12) and torch.equal(back, v)
+        last = (got, rows.clone())
+    px.check()
+    assert px.step == 7 and px.cap_total >= 5000
+    px.close()
+
+
+def test_wait_gives_up_and_reports_the_missing_source():
+    """A flag that never arrives must not hang the GPU: the wait kernel stops after max_polls polls and raises the error word."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import _lib as L
+    dev = torch.device("cuda:0")
+    flags = torch.zeros(2, dtype=torch.int64, device=dev)
+    flags[0] = 5
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.call("gspl_peer_wait", L.ptr(flags), 2, 5, 2000, L.ptr(err), L.stream())
+    torch.cuda.synchronize()
+    assert int(err.item()) == 2          # 1 + the source whose flag stayed below 5
+    err.zero_()
+    flags[1] = 9
+    with torch.cuda.device(dev):
+        L.call("gspl_peer_wait", L.ptr(flags), 2, 5, 2000, L.ptr(err), L.stream())
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0

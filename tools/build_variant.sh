@@ -8,7 +8,7 @@ src=$root/gaussian-splatting-lightning_amd/csrc
 out=$root/gaussian-splatting-lightning_amd/variants
 mkdir -p $out/obj_$name
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function -Wno-unused-variable -Wno-pass-failed"
-all="projection sh binning composite composite_bwd inria knn loss adam sort density fused records"
+all="projection sh binning composite composite_bwd inria knn loss adam sort density fused records peer"
 # ONLY="sort binning" recompiles just those files and takes the other objects from the regular build (csrc/build)
 for f in $all; do
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $f "; then cp $src/build/$f.o $out/obj_$name/$f.o; continue; fi
