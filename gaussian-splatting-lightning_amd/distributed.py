@@ -123,6 +123,63 @@ def all_to_all_route(send_counts: Sequence[int], recv_counts: Sequence[int], gro
             lambda v_rows: _all_to_all_rows_raw(v_rows, recv_counts, send_counts, group))
 
 
+class HostMailbox:
+    """What the ranks of ONE node have to agree on before a step — camera id, local Gaussian count, vote on the exchange format:
+    a short row of integers per rank — through POSIX shared memory instead of a collective: every rank stores its row and a sequence
+    number into its slot and polls the other slots.  Host to host, a few microseconds, no stream, no kernel, no device
+    synchronisation (the all-gather this replaces, `gather_int_rows`, is an RCCL launch, a copy back and a stream wait: 0.1-0.2 ms of
+    host time per step on the critical path — profiles/r05d_*).  Created once (the name travels through one collective)."""
+
+    def __init__(self, rank: int, group, width: int = 4):
+        import numpy as np
+        from multiprocessing import shared_memory
+        self.rank, self.group = int(rank), group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.width, self.seq = int(width), 0
+        # two copies of the table, used alternately: a rank can be one call ahead of the slowest reader of the previous call (never
+        # two: the call after the next needs everybody's rows of the next), so its new row must not land where that reader looks
+        nbytes = 8 * 2 * self.world * (self.width + 1)
+        names = [None]
+        if self.rank == 0:
+            self._shm = shared_memory.SharedMemory(create=True, size=nbytes)
+            self._shm.buf[:nbytes] = bytes(nbytes)
+            names = [self._shm.name]
+        if self.world > 1:
+            dist.broadcast_object_list(names, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if self.rank != 0:
+            self._shm = shared_memory.SharedMemory(name=names[0])
+        self._rows = np.ndarray((2, self.world, self.width + 1), dtype=np.int64, buffer=self._shm.buf)      # [..., -1] = sequence number
+        if self.world > 1:
+            dist.barrier(group=group)
+
+    def exchange(self, values: Sequence[int], timeout_s: float = 120.0) -> List[List[int]]:
+        """My row in, everybody's rows out (rank order); blocks until every rank has posted its row of this call."""
+        import time
+        self.seq += 1
+        table = self._rows[self.seq & 1]
+        table[self.rank, :self.width] = [int(v) for v in values]
+        table[self.rank, self.width] = self.seq          # (x86: stores become visible in program order)
+        deadline = None
+        while not bool((table[:, self.width] == self.seq).all()):
+            if deadline is None:
+                deadline = time.monotonic() + timeout_s
+            elif time.monotonic() > deadline:
+                raise RuntimeError(f"HostMailbox: rank {self.rank} waited {timeout_s} s for the rows of call {self.seq} "
+                                   f"(have {table[:, self.width].tolist()})")
+        return [[int(v) for v in table[r, :self.width]] for r in range(self.world)]
+
+    def close(self):
+        shm, self._shm = getattr(self, "_shm", None), None
+        if shm is not None:
+            self._rows = None
+            shm.close()
+            if self.rank == 0:
+                try:
+                    shm.unlink()
+                except FileNotFoundError:
+                    pass
+
+
 class _DevicePtr:
     """A region of raw device memory as something `torch.as_tensor` understands (CUDA array interface)."""
 

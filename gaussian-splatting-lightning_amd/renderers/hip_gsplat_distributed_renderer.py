@@ -171,7 +171,13 @@ class HipGSplatDistributedRendererImpl(Renderer):
         # The ids travel on a stream of their own: the collective and the read-back of its result then wait for nothing but
         # each other — on the current stream they would sit behind the previous step's backward and optimizer, and the host
         # could not start enqueueing this step before the device had drained.
-        rows = self._on_control_stream(D.gather_int_rows, mine, dev, self.group)
+        if self.config.exchange_transport == "peer" and dev.type == "cuda":
+            # one node, one process per GPU: the rows go through shared host memory (a few microseconds, no stream involved)
+            if self.__dict__.get("_mailbox") is None:
+                self._mailbox = D.HostMailbox(dist.get_rank(self.group), self.group, width=len(mine))
+            rows = self._mailbox.exchange(mine)
+        else:
+            rows = self._on_control_stream(D.gather_int_rows, mine, dev, self.group)
         self._peer_rows = rows
         for i in (r[0] for r in rows):
             cam = self.camera_lookup(i, self.training)

@@ -91,3 +91,36 @@ def test_world2_gloo(tmp_path):
     port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _mailbox_worker(rank, world, port, tmpdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    for p in (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        import gspl_amd  # noqa: F401
+        from gspl_amd import distributed as D
+        box = D.HostMailbox(rank, None, width=3)
+        for call in range(1, 400):
+            if rank == call % world and call % 7 == 0:
+                time.sleep(0.002)                  # ranks drift: a fast rank posts its next row while a slow one still reads
+            rows = box.exchange([call * 10 + rank, 1000 + rank, -call])
+            assert rows == [[call * 10 + r, 1000 + r, -call] for r in range(world)], (call, rows)
+        box.close()
+        open(os.path.join(tmpdir, f"mb{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_mailbox_rows_agree_under_drift(tmp_path, world):
+    """distributed.HostMailbox (the per-step camera ids / Gaussian counts / votes of the peer transport, through shared host memory):
+    every rank sees every rank's row of the SAME call, also when the ranks drift by a call."""
+    from conftest import free_port
+    mp.spawn(_mailbox_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"mb{r}").exists() for r in range(world))
