@@ -1,0 +1,62 @@
+"""The mutable run-time state of the operator layer, in ONE object instead of module-level globals scattered over the wrappers:
+the process-wide switches (tests and bench flip them), and everything that is kept between frames — keyed by DEVICE (and tile grid
+where it matters), so that several devices in one process and the viewer's threads (one renderer call per client thread,
+internal/viewer/client.py:114) never share a slot that belongs to another device.
+
+    STATE.fused_inria, .device_side_list_length, .speculative_emit, .track_hit_pixels, .keep_last_raster, .side_low_priority
+    STATE.last_isects[(device index, tiles x, tiles y)]    list length of the last frame = the guess of the next speculative emission
+    STATE.speculation                                       how the guesses fared (frames / cold / misses; bench.py reports them)
+    STATE.events[device index], .pinned_words, .pinned_ends[C]    free lists (an event / a pinned word costs ~15 us to construct)
+    STATE.pending_updates[data_ptr]                         parameter updates in flight on the colour stream (optimizers.FusedAdam)
+    STATE.last_raster                                       introspection: the last compositing forward's inputs (keep_last_raster)
+    STATE.consts, .identity_slots, .zero_scalars            small per-device constant tensors
+
+`gspl_amd.ops` keeps the historical module-level spellings (ops.FUSED_INRIA, ops._LAST_ISECTS, ...) as properties of the package
+that read and write this object.  Container operations used on the hot path (dict get / set, list pop / append) are atomic under
+the GIL; the statistics counters are advisory."""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+
+class RuntimeState:
+    __slots__ = ("fused_inria", "device_side_list_length", "speculative_emit", "track_hit_pixels", "keep_last_raster", "side_low_priority",
+                 "last_isects", "speculation", "events", "pinned_words", "pinned_ends", "pending_updates", "last_raster", "consts",
+                 "identity_slots", "zero_scalars", "new_event")
+
+    def __init__(self):
+        env = os.environ.get
+        # one C-ABI call per direction for the Inria rasterizer (csrc/fused.hip); GSPL_FUSED_INRIA=0: the stage-by-stage calls
+        self.fused_inria: bool = env("GSPL_FUSED_INRIA", "1") != "0"
+        # staged binning: with a speculative emission in flight the tile sort is enqueued before the host has read the list length
+        # (False: wait for the count first, then sort — the round-1 order; kept for A/B runs and the tests of both orders)
+        self.device_side_list_length: bool = True
+        self.speculative_emit: bool = env("GSPL_SPECULATIVE_EMIT", "1") != "0"
+        # the compositing backward also reports which splats some pixel actually composited and attaches the mask as
+        # `has_hit_any_pixels` to the caller's screen-space tensor (the fork-only side channel gsplat's SelectiveAdam adapter reads,
+        # internal/optimizers.py:39); off by default: one more byte store per (tile, splat) in the hot kernel
+        self.track_hit_pixels: bool = False
+        # introspection for bench.py / tools: the last compositing forward leaves its per-splat inputs and tile lists in `last_raster`
+        self.keep_last_raster: bool = False
+        # the colour kernel on the library's lowest-priority stream instead of a default-priority torch stream (measured: no gain)
+        self.side_low_priority: bool = env("GSPL_SIDE_LOW_PRIORITY", "0") != "0"
+        self.last_isects: dict = {}
+        self.speculation: dict = {"frames": 0, "cold": 0, "misses": 0}
+        self.events: dict = {}
+        self.pinned_words: list = []
+        self.pinned_ends: dict = {}
+        self.pending_updates: dict = {}
+        self.last_raster: Optional[dict] = None
+        self.consts: dict = {}
+        self.identity_slots: dict = {}
+        self.zero_scalars: dict = {}
+        self.new_event = _new_event      # (constructor of the events the free lists hand out; the host-only tests put a stand-in here)
+
+
+def _new_event():
+    import torch
+    return torch.cuda.Event()
+
+
+STATE = RuntimeState()

@@ -1,0 +1,329 @@
+"""The Inria API: `GaussianRasterizationSettings`, `GaussianRasterizer` (one fused C call per direction, or the staged calls)."""
+from __future__ import annotations
+
+import os
+from typing import NamedTuple, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _lib as L
+from ._state import STATE as S
+from ._common import (_SUPPORTED_D, _packed_row_stride, _guarded, _f32c, _rows, _raw_ptr, _grad_or_zeros, _side_stream, colour_stream,
+                      join_pending_updates, _await_updates, _take_event)
+from .binning import MAX_ISECTS, bin_gaussians_begin, bin_gaussians_end
+from .compositing import _CompositeFn, _composite
+
+# =============================================================================================
+# Inria API  (diff_gaussian_rasterization.GaussianRasterizer)
+# =============================================================================================
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool = False
+    debug: bool = False
+
+
+def _split_sh(sh, sh_rest):
+    """(sh, sh_rest, n_coeffs) of the rasterizer's colour input: `sh` [N, K, 3] alone, or the reference model's two parameters
+    `shs_dc` [N, 1, 3] and `shs_rest` [N, K - 1, 3] (internal/models/vanilla_gaussian.py:266-300), which the kernels then read — and
+    whose gradients they write — in place: `get_shs()`'s per-step `torch.cat` (and its backward's two slice copies) never run."""
+    if sh is None:
+        if sh_rest is not None:
+            raise ValueError("shs_rest without shs")
+        return None, None, 0
+    if sh_rest is None:
+        return sh, None, sh.shape[1]
+    sh_rest = _f32c(sh_rest)
+    if sh.dim() != 3 or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != sh.shape[0] or sh_rest.shape[2] != 3:
+        raise ValueError(f"shs / shs_rest must be [N,1,3] and [N,K-1,3], got {tuple(sh.shape)} and {tuple(sh_rest.shape)}")
+    if sh_rest.shape[1] == 0:
+        return sh, None, 1
+    return sh, sh_rest, 1 + sh_rest.shape[1]
+
+
+class _InriaRasterizeFn(torch.autograd.Function):
+    @staticmethod
+    @_guarded(1)
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest=None):
+        lib = L.lib()
+        s: GaussianRasterizationSettings = settings
+        dev = means3D.device
+        means3D = _f32c(means3D)
+        N = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        sh, colors_precomp, scales, rotations, cov3D_precomp = map(_f32c, (sh, colors_precomp, scales, rotations, cov3D_precomp))
+        opac = _f32c(opacities).reshape(-1)
+        viewm, projm, campos = _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos)
+        bg = _f32c(s.bg)
+        sh, sh_rest, n_coeffs = _split_sh(sh, sh_rest)
+        radii = torch.empty((N,), dtype=torch.int32, device=dev)
+        means2d = torch.empty((N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((N,), dtype=torch.float32, device=dev)
+        conics = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        colors = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        clamped = torch.empty((N, 3), dtype=torch.uint8, device=dev)
+        cov3d = torch.empty((N, 6), dtype=torch.float32, device=dev)
+        # d colour / d view direction, left by the colour kernel for the backward (which then reads no coefficients for v_means)
+        sh_jac = torch.empty((N, 9), dtype=torch.float32, device=dev) if (sh is not None and ctx.needs_input_grad[0]) else None
+        tile = 16
+        tile_w, tile_h = (W + tile - 1) // tile, (H + tile - 1) // tile
+        def preprocess(phases):
+            if N > 0:
+                if phases & L.GSPL_INRIA_COLOURS:
+                    _await_updates(sh, sh_rest)
+                L.call("gspl_inria_preprocess_fwd",
+                       N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3D_precomp),
+                       L.ptr(sh), L.ptr(sh_rest), L.ptr(colors_precomp), L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tile,
+                       float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier),
+                       L.ptr(radii), L.ptr(means2d), L.ptr(depths), L.ptr(conics), L.ptr(colors), L.ptr(clamped), L.ptr(cov3d),
+                       L.ptr(sh_jac) if (phases & L.GSPL_INRIA_COLOURS) else None, phases, L.stream())
+        # geometry, then two independent chains: the SH kernel (HBM-bound, one launch) on a side stream, and the count /
+        # depth-sort half of the binning (a dozen small latency-bound launches) on the caller's stream; the host meanwhile
+        # waits for the one number that sizes the tile sort.
+        preprocess(L.GSPL_INRIA_GEOMETRY)
+        with _side_stream(dev) as side:
+            preprocess(L.GSPL_INRIA_COLOURS)
+        pending = bin_gaussians_begin(means2d, depths, radii, H, W, tile, mode=L.GSPL_MODE_INRIA, conics=conics, opacities=opac)
+        flat, offsets = bin_gaussians_end(pending)
+        side.join()
+        n_isects = flat.shape[0]
+        out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        alphas = torch.empty((H, W), dtype=torch.float32, device=dev)
+        final_Ts = torch.empty((H, W), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((H, W), dtype=torch.int32, device=dev)
+        L.call("gspl_composite_fwd", 
+            N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
+            L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat) if n_isects else None,
+            L.ptr(out), L.ptr(alphas), L.ptr(final_Ts), L.ptr(last_ids), None, L.stream())
+        ctx.save_for_backward(means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
+                              radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac, sh_rest)
+        if S.keep_last_raster:
+            S.last_raster = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=means2d, conics=conics, opacities=opac,
+                               colors=colors, flatten_ids=flat, offsets=offsets, radii=radii, depths=depths)
+        ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
+                   float(s.scale_modifier), colors_precomp is not None, opacities.shape)
+        ctx.set_materialize_grads(False)      # the integer `radii` output would otherwise get a zero "gradient" tensor per step
+        ctx.mark_non_differentiable(radii)
+        ctx.means2D_ref = means2D       # the caller's screen-space tensor: `.has_hit_any_pixels` is attached to it in backward
+        return out, radii
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, v_out, _v_radii):
+        lib = L.lib()
+        (means3D, scales, rotations, cov3D_precomp, sh, opac, viewm, projm, campos, bg,
+         radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac, sh_rest) = ctx.saved_tensors
+        H, W, tile, tile_w, tile_h, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, opac_shape = ctx.cfg
+        N = means3D.shape[0]
+        dev = means3D.device
+        n_isects = flat.shape[0]
+        v_out = _grad_or_zeros(v_out, (3, H, W), dev)
+        RS = _packed_row_stride(9)
+        packed = torch.zeros((N, RS), dtype=torch.float32, device=dev)       # x y | a b c | opacity | r g b | pad
+        if n_isects > 0:
+            hit = torch.zeros((N,), dtype=torch.uint8, device=dev) if S.track_hit_pixels else None
+            L.call("gspl_composite_bwd_packed",
+                N, n_isects, 3, L.GSPL_MODE_INRIA, L.GSPL_LAYOUT_CHW, L.ptr(means2d), L.ptr(conics), L.ptr(colors), L.ptr(opac),
+                L.ptr(bg), W, H, tile, tile_w, tile_h, L.ptr(offsets), L.ptr(flat), L.ptr(final_Ts), L.ptr(last_ids),
+                L.ptr(v_out), None, L.ptr(packed), RS, 0, L.ptr(hit), L.stream())
+            if hit is not None and ctx.means2D_ref is not None:
+                ctx.means2D_ref.has_hit_any_pixels = hit.bool()
+        v_opac = torch.empty((N,), dtype=torch.float32, device=dev)      # dense copy of the packed column (written below)
+        v_means = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_ndc = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        use_cov = cov3D_precomp is not None
+        v_scales = None if use_cov else torch.empty((N, 3), dtype=torch.float32, device=dev)
+        v_quats = None if use_cov else torch.empty((N, 4), dtype=torch.float32, device=dev)
+        v_cov = torch.empty((N, 6), dtype=torch.float32, device=dev) if use_cov else None
+        v_sh = None if has_precomp_colors else torch.empty_like(sh)
+        v_sh_rest = None if sh_rest is None else torch.empty_like(sh_rest)
+        v_cp = torch.empty((N, 3), dtype=torch.float32, device=dev) if has_precomp_colors else None
+        if N > 0:
+            L.call("gspl_inria_preprocess_bwd", 
+                N, degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(cov3d), L.ptr(sh), L.ptr(sh_rest),
+                L.ptr(viewm), L.ptr(projm), L.ptr(campos), W, H, tanfovx, tanfovy, scale_modifier,
+                L.ptr(radii), L.ptr(clamped), L.ptr(packed), L.ptr(packed, offset_bytes=8), L.ptr(packed, offset_bytes=24), RS,
+                L.ptr(v_means), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.ptr(v_sh), L.ptr(v_sh_rest), L.ptr(v_cp), L.ptr(v_ndc),
+                L.ptr(packed, offset_bytes=20), L.ptr(v_opac), L.ptr(sh_jac), L.stream())
+        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest
+
+
+# ---- the same rasterizer through ONE C-ABI call per direction (gspl_rasterize_inria_fwd/bwd, csrc/fused.hip) -----------------
+# The colour stream at the device's lowest priority (a stream from the library; torch cannot create one below the default) or at the
+# default priority (the package's torch side stream).  Round 3, 16 rotating cameras, two runs each on one box: no difference for the
+# colour kernel alone (1.280 / 1.280 vs 1.292 / 1.273 ms per step), and with the deferred shs_rest update on the same stream the
+# default priority is the faster one (1.251 / 1.257 vs 1.266 / 1.264) — and the only two runs with 6-9 ms stalls of single steps had
+# the low-priority stream carrying the update.  Default: the default priority.
+_ALLOC_TLS = __import__("threading").local()
+
+
+def _alloc_trampoline(_ctx, tag, nbytes):
+    """`gspl_alloc_fn`: hand the library a block of torch-owned device memory; the tensors stay with the caller's holder."""
+    holder = _ALLOC_TLS.holder
+    try:
+        t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=holder["device"])
+        holder.setdefault(tag, []).append(t)
+        return t.data_ptr()
+    except Exception as e:      # an exception must not cross the C boundary: NULL = failure, re-raised by the caller
+        holder["error"] = e
+        return 0
+
+
+_ALLOC_CB = L.ALLOC_FN(_alloc_trampoline)
+
+
+def _view(buf: Tensor, ptr: int, shape, dtype) -> Tensor:
+    """Typed view of a region of a byte buffer the library carved up (ptr = device address inside `buf`)."""
+    import math
+    off = ptr - buf.data_ptr()
+    nbytes = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype).view(shape)
+
+
+class _InriaFusedFn(torch.autograd.Function):
+    @staticmethod
+    @_guarded(1)
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest=None):
+        import ctypes
+        s: GaussianRasterizationSettings = settings
+        dev = means3D.device
+        means3D = _f32c(means3D)
+        N = means3D.shape[0]
+        H, W = int(s.image_height), int(s.image_width)
+        sh, colors_precomp, scales, rotations, cov3D_precomp = map(_f32c, (sh, colors_precomp, scales, rotations, cov3D_precomp))
+        opac = _f32c(opacities).reshape(-1)
+        viewm, projm, campos, bg = _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos), _f32c(s.bg)
+        sh, sh_rest, n_coeffs = _split_sh(sh, sh_rest)
+        out = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((N,), dtype=torch.int32, device=dev)
+        tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
+        key = (dev.index, tile_w, tile_h)
+        guess = S.last_isects.get(key, 0)
+        hint = min(int(guess * 1.25) + 65536, MAX_ISECTS) if (S.speculative_emit and guess > 0) else 0
+        state = L.InriaState()
+        holder = {"device": dev}
+        _ALLOC_TLS.holder = holder
+        side = _side_stream(dev)
+        with torch.cuda.device(dev):
+            side_handle = None
+            low = False
+            raw = None
+            if side.enabled:
+                # the colour stream (default priority; GSPL_SIDE_LOW_PRIORITY=1: the library's lowest-priority stream, on which the
+                # colour kernel yields to the key pass and the depth sort it runs next to)
+                raw, _ = colour_stream(dev)
+                low = _side_stream._low.get((dev.type, dev.index), False)
+                side_handle = ctypes.c_void_p(raw)
+            # coefficient updates still in flight (FusedAdam(deferred=...)): on the colour stream itself stream order covers them
+            _await_updates(sh, sh_rest, on_raw_stream=raw)
+            try:
+                L.call("gspl_rasterize_inria_fwd", N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
+                       L.ptr(cov3D_precomp), L.ptr(sh), L.ptr(sh_rest), L.ptr(colors_precomp), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg),
+                       W, H, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), _ALLOC_CB, None, hint,
+                       L.ptr(out), L.ptr(radii), ctypes.byref(state), L.stream(), side_handle)
+            except RuntimeError:
+                if "error" in holder:
+                    raise holder["error"]
+                raise
+            finally:
+                _ALLOC_TLS.holder = None
+        if side.enabled and not low:
+            # blocks the colour kernel used on the side stream are freed by the caller's stream: tell the allocator
+            # (the library's own low-priority stream is joined inside the call: stream order on the caller's stream covers it)
+            for t in holder.get(L.GSPL_BUF_GEOMETRY, []):
+                t.record_stream(side.stream)
+        S.last_isects[key] = int(state.n_isects)
+        S.speculation["frames"] += 1
+        if hint == 0:
+            S.speculation["cold"] += 1
+        elif int(state.n_isects) > hint:
+            S.speculation["misses"] += 1
+        holder.pop(L.GSPL_BUF_BINNING, None)           # scratch of the count half and of the tile sort: not needed again
+        holder.pop(L.GSPL_BUF_LISTS_WORK, None)
+        ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest)
+        ctx.holder, ctx.state = holder, state
+        ctx.cfg = (H, W, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), colors_precomp is not None,
+                   cov3D_precomp is not None, opacities.shape)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        ctx.means2D_ref = means2D
+        if S.keep_last_raster:
+            geom, lists = holder[L.GSPL_BUF_GEOMETRY][0], holder.get(L.GSPL_BUF_LISTS, [None])[-1]
+            img = holder[L.GSPL_BUF_IMAGE][0]
+            nI = int(state.n_isects)
+            S.last_raster = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=_view(geom, state.means2d, (N, 2), torch.float32),
+                               conics=_view(geom, state.conics, (N, 3), torch.float32), opacities=opac,
+                               colors=_view(geom, state.colors, (N, 3), torch.float32),
+                               flatten_ids=(lists[:4 * nI].view(torch.int32) if lists is not None else torch.empty(0, dtype=torch.int32, device=dev)),
+                               offsets=_view(img, state.offsets, (tile_w * tile_h,), torch.int32), radii=radii,
+                               depths=_view(geom, state.depths, (N,), torch.float32))
+        return out, radii
+
+    @staticmethod
+    @_guarded(0)
+    def backward(ctx, v_out, _v_radii):
+        import ctypes
+        means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest = ctx.saved_tensors
+        H, W, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, use_cov, opac_shape = ctx.cfg
+        N = means3D.shape[0]
+        dev = means3D.device
+        v_out = _grad_or_zeros(v_out, (3, H, W), dev)
+        E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        packed = E(N, 9)
+        hit = torch.empty((N,), dtype=torch.uint8, device=dev) if S.track_hit_pixels else None
+        v_means, v_ndc, v_opac = E(N, 3), E(N, 3), E(N)
+        v_scales = None if use_cov else E(N, 3)
+        v_quats = None if use_cov else E(N, 4)
+        v_cov = E(N, 6) if use_cov else None
+        v_sh = None if has_precomp_colors else torch.empty_like(sh)
+        v_sh_rest = None if sh_rest is None else torch.empty_like(sh_rest)
+        v_cp = E(N, 3) if has_precomp_colors else None
+        if N > 0:
+            with torch.cuda.device(dev):
+                L.call("gspl_rasterize_inria_bwd", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh), L.ptr(sh_rest),
+                       L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
+                       ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_sh_rest),
+                       L.ptr(v_cp), L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
+            if hit is not None and ctx.means2D_ref is not None:
+                ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
+        else:
+            for t in (v_means, v_ndc, v_opac):
+                t.zero_()
+        ctx.holder = None
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """Drop-in for `diff_gaussian_rasterization.GaussianRasterizer` as the reference uses it
+    (internal/renderers/vanilla_renderer.py:79,111-120): returns (color [3,H,W], radii [N] i32);
+    `means2D.grad` receives the screen-space gradient in the Inria (NDC-scaled) units."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, shs_rest=None):
+        """`shs_rest` (extension; also accepted as `shs=(shs_dc, shs_rest)`): the model's two SH parameters as they are stored."""
+        if isinstance(shs, (tuple, list)):
+            shs, shs_rest = shs
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        # one C-ABI call per direction (csrc/fused.hip) unless GSPL_FUSED_INRIA=0 selects the stage-by-stage orchestration
+        fn = _InriaFusedFn if S.fused_inria else _InriaRasterizeFn
+        if shs_rest is not None and shs_rest.shape[1] == 0:
+            shs_rest = None
+        return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings, shs_rest)

@@ -366,9 +366,9 @@ def test_binning_big_splats(hip, mode):
 
 
 def test_binning_above_one_million_splats(hip):
-    """Above ~1 M splats the depth sort and the scan of the counts run on the library path (binning.hip: plan_bin); big splats
-    are then listed by their own small kernel.  The two-level lists must equal those of the independent 64-bit (tile | depth)
-    sort behind `isect_tiles` (itself checked against the oracle at small sizes)."""
+    """1.2 M splats (several sort workgroups per pass, multi-block scans) with a few screen-filling ones dealt out to the emit
+    kernel's workgroups: the two-level lists must equal those of the independent 64-bit (tile | depth) sort behind `isect_tiles`
+    (itself checked against the oracle at small sizes)."""
     d = _dev()
     W, H = 640, 400
     n = 1_200_000

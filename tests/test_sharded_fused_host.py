@@ -56,9 +56,6 @@ def recorded_abi(monkeypatch):
         assert t.is_contiguous(), "gspl ops need contiguous tensors"
         return ctypes.c_void_p(t.data_ptr() + offset_bytes)
 
-    def take_event(dev):
-        ops._EVENTS.setdefault(dev.index, [])
-        return _Event()
 
     monkeypatch.setattr(L, "call", call)
     monkeypatch.setattr(L, "ptr", ptr)
@@ -66,7 +63,8 @@ def recorded_abi(monkeypatch):
     monkeypatch.setattr(L, "device_guard", lambda t: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
     monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self, *a, **k: self)
-    monkeypatch.setattr(ops, "_take_event", take_event)
+    monkeypatch.setattr(ops.STATE, "new_event", _Event)
+    monkeypatch.setattr(ops, "_EVENTS", {})
     monkeypatch.setattr(ops, "_LAST_ISECTS", {})
     monkeypatch.setattr(ops, "_PINNED_ENDS", {})
     monkeypatch.setattr(ops, "_PINNED_WORDS", [])
