@@ -7,7 +7,7 @@ registers this directory as that package).  Layout:
 
     csrc/        hand-written HIP kernels + the C-ABI (include/gspl_hip.h)  -> libgspl_hip.so
     _lib.py      ctypes binding (no fallback: raises when the library is missing)
-    ops.py       autograd.Function wrappers with the reference's operator signatures
+    ops/         autograd.Function wrappers with the reference's operator signatures (one module per concern; ops._state.STATE = the run-time state)
     renderers/   Renderer plugins (vanilla / gsplat-v0 / gsplat-v1 / distributed)
 """
 from . import _lib  # noqa: F401

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "gspl_abi_version": (c_int, []),
     "gspl_last_error": (ctypes.c_char_p, []),
     "gspl_composite_bwd_kernel_name": (ctypes.c_char_p, []),
+    "gspl_set_deterministic": (c_int, [c_int]),
+    "gspl_get_deterministic": (c_int, []),
     "gspl_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int,
                                  c_float, c_float, c_float, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int,

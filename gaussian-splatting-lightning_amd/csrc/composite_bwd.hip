@@ -294,11 +294,17 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         __syncthreads();
         if constexpr (PACKED) {
             float* __restrict__ v_packed = v_means2d;
+            // packed_stride < 0 (gspl_set_deterministic): one row per LIST ENTRY instead of one per splat — the staged slot `row` is
+            // list position hi - 1 - row, a single (tile, splat) pair, so every row has one writer and a later pass adds a splat's
+            // rows in list order (ordered_reduce_kernel below)
+            const bool by_entry = packed_stride < 0;
+            const int ps = by_entry ? -packed_stride : packed_stride;
             for (int e = t; e < cnt * NV; e += B2_NT) {
                 const float v = s_acc[e];
                 s_acc[e] = 0.f;
                 const int row = e / NV;
-                if (v != 0.f) atomicAdd(&v_packed[(int64_t)(s_id[row] & 0x7fffffff) * packed_stride + (e - row * NV)], v);
+                const int64_t dst_row = by_entry ? (int64_t)(hi - 1 - row) : (int64_t)(s_id[row] & 0x7fffffff);
+                if (v != 0.f) atomicAdd(&v_packed[dst_row * ps + (e - row * NV)], v);
             }
         } else if (t < cnt) {
             const int g = s_id[t] & 0x7fffffff;
@@ -520,6 +526,46 @@ extern "C" int gspl_composite_bwd(int N, int64_t n_isects, int D, int mode, int 
     return rc;
 }
 
+// ---- deterministic (debug) mode ----------------------------------------------------------------------------------------------
+// gspl_set_deterministic(1): gspl_composite_bwd_packed delivers bit-reproducible gradients.  The regular launch adds every
+// (tile, splat) total to the splat's row with an fp32 L2 atomic, so the ORDER of a splat's additions follows the dispatch order of
+// its tiles: run-to-run differences of 1e-7 relative, which tests of HIP against HIP could only bound (1e-4 after the projection
+// chain, profiles/r04_flaky_v_means.txt).  In this mode the kernel writes one row per list entry (single writer), the entries
+// are sorted by splat id (stable: ties in list order) and one thread per splat adds its rows in that order.  Three extra passes over
+// the entries and scratch from hipMallocAsync: a mode for tests and debugging, not for the timed path.
+#include "gspl_sort.h"
+namespace gspl {
+static int g_deterministic = 0;
+
+__global__ __launch_bounds__(256) void iota_ids_kernel(int64_t n, const int32_t* __restrict__ ids, uint32_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { keys[i] = (uint32_t)ids[i]; pos[i] = (uint32_t)i; }
+}
+// thread i = the first entry of a run of equal ids (sorted, stable): adds the run's rows in list order into the splat's row
+__global__ __launch_bounds__(256) void ordered_reduce_kernel(int64_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pos,
+                                                             const float* __restrict__ entries, int nv, int entry_stride,
+                                                             float* __restrict__ v_packed, int packed_stride) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = keys[i];
+    if (i > 0 && keys[i - 1] == g) return;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int64_t j = i; j < n && keys[j] == g; ++j) {
+        const float* row = entries + (int64_t)pos[j] * entry_stride;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < nv) acc[k] += row[k];
+    }
+    float* out = v_packed + (int64_t)g * packed_stride;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (k < nv) out[k] += acc[k];      // (the row was zero, or holds what the caller put there: one writer)
+}
+}  // namespace gspl
+
+extern "C" int gspl_set_deterministic(int on) { const int was = gspl::g_deterministic; gspl::g_deterministic = on ? 1 : 0; return was; }
+extern "C" int gspl_get_deterministic(void) { return gspl::g_deterministic; }
+
 // Same backward, gradients delivered as ONE packed row per splat: v_packed [N, packed_stride >= 6 + D (+2 with absgrad)] =
 // (dL/dx, dL/dy, dL/da, dL/db, dL/dc, dL/dopacity, dL/dcolour[D], [sum|dL/dx|, sum|dL/dy|]); must be zero-initialised.
 // The flush then issues atomics whose 64 lanes cover contiguous components of a few rows instead of 64 scattered
@@ -544,6 +590,29 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
     const int ctw = (width + TILE - 1) / TILE, n_tiles = ctw * ((height + TILE - 1) / TILE);      // 16x16 compute tiles
     hipStream_t s = (hipStream_t)stream;
     const bool ag = absgrad != 0;
+    // deterministic mode (see gspl_set_deterministic below): rows per list entry, then an ordered reduction per splat
+    const int nv = 6 + D + (ag ? 2 : 0);
+    const bool ordered = gspl_get_deterministic() != 0 && lt.log2 == 4 && n_isects > 0;
+    float* entries = nullptr;
+    uint32_t *k0 = nullptr, *k1 = nullptr, *p0 = nullptr, *p1 = nullptr;
+    void* sort_ws = nullptr;
+    size_t sort_ws_bytes = 0;
+    int id_bits = 1;
+    float* const v_packed_out = v_packed;
+    const int packed_stride_out = packed_stride;
+    if (ordered) {
+        if (n_isects < 0) return fail_arg("composite_bwd_packed: the deterministic mode needs the list length on the host (n_isects >= 0)");
+        while (id_bits < 32 && (1ll << id_bits) < (long long)N) ++id_bits;
+        sort_ws_bytes = gspl_radix_sort_workspace_bytes(n_isects, 4, 0, id_bits);
+        hipError_t e = hipMallocAsync((void**)&entries, (size_t)n_isects * nv * sizeof(float), s);
+        if (e == hipSuccess) e = hipMallocAsync((void**)&k0, (size_t)n_isects * 4 * sizeof(uint32_t), s);
+        if (e == hipSuccess) e = hipMallocAsync(&sort_ws, sort_ws_bytes ? sort_ws_bytes : 16, s);
+        if (e == hipSuccess) e = hipMemsetAsync(entries, 0, (size_t)n_isects * nv * sizeof(float), s);
+        if (e != hipSuccess) return check_hip(e, "composite_bwd_packed(deterministic): scratch");
+        k1 = k0 + n_isects; p0 = k1 + n_isects; p1 = p0 + n_isects;
+        v_packed = entries;
+        packed_stride = -nv;
+    }
     rc = GSPL_ERR_UNSUPPORTED;
 #define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride, hit_flags, lt)
     if (mode == GSPL_MODE_GSPLAT) {
@@ -554,6 +623,19 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
         else { GSPL_DISPATCH_D(D, GSPL_MODE_INRIA, true, CALL_BWDP) }
     }
 #undef CALL_BWDP
+    if (ordered) {
+        if (rc == GSPL_OK) {
+            hipLaunchKernelGGL(iota_ids_kernel, dim3((unsigned)((n_isects + 255) / 256)), dim3(256), 0, s, n_isects, flatten_ids, k0, p0);
+            int which = 0;
+            rc = gspl_radix_sort_pairs_u32(n_isects, k0, k1, p0, p1, 0, id_bits, &which, sort_ws, sort_ws_bytes, s);
+            if (rc == GSPL_OK) {
+                hipLaunchKernelGGL(ordered_reduce_kernel, dim3((unsigned)((n_isects + 255) / 256)), dim3(256), 0, s, n_isects, which ? k1 : k0, which ? p1 : p0,
+                                   entries, nv, nv, v_packed_out, packed_stride_out);
+                rc = check_launch("composite_bwd_packed(ordered reduce)");
+            }
+        }
+        (void)hipFreeAsync(entries, s); (void)hipFreeAsync(k0, s); (void)hipFreeAsync(sort_ws, s);
+    }
     return rc;
 }
 

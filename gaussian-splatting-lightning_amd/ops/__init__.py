@@ -24,7 +24,7 @@ import types as _types
 
 from ._state import STATE, RuntimeState
 from ._common import (_SUPPORTED_D, _packed_row_stride, _guarded, _f32c, _rows, _raw_ptr, _grad_or_zeros, _side_stream, colour_stream,
-                      join_pending_updates, _await_updates, _take_event)
+                      join_pending_updates, _await_updates, _take_event, set_deterministic)
 from .projection import (_ProjectFn, fully_fused_projection, project_gaussians, _SHFn, spherical_harmonics, spherical_harmonics_decomposed,
                          sh_view_colors, _SHBatchedFn, sh_view_colors_batched)
 from .binning import (isect_tiles, isect_offset_encode, _PendingBins, MAX_ISECTS, bin_gaussians_begin, bin_gaussians_end, bin_gaussians, LazyLists,

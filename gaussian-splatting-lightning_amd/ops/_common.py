@@ -179,3 +179,10 @@ def _await_updates(*tensors, on_raw_stream=None):
 def _take_event(dev):
     pool = S.events.setdefault(dev.index, [])
     return pool.pop() if pool else S.new_event()
+
+
+def set_deterministic(on: bool = True) -> bool:
+    """Bit-reproducible gradients from the compositing backward (`gspl_set_deterministic`: per-splat rows added in list order instead
+    of by atomics in dispatch order) — for tests that compare two runs and for debugging; slower (three extra passes over the list
+    entries).  Process-wide; returns the previous setting."""
+    return bool(L.lib().gspl_set_deterministic(1 if on else 0))

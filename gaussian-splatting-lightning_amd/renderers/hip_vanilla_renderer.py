@@ -1,5 +1,5 @@
 """HipVanillaRenderer — drop-in for the reference's default `VanillaRenderer`
-(internal/renderers/vanilla_renderer.py:17-213), backed by the HIP `GaussianRasterizer` of ops.py
+(internal/renderers/vanilla_renderer.py:17-213), backed by the HIP `GaussianRasterizer` of ops/inria.py
 instead of `diff_gaussian_rasterization`.
 
 Select with   --model.renderer gspl_amd.renderers.HipVanillaRenderer   (INTEGRATION.md).

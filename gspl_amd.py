@@ -1,7 +1,7 @@
 """Import shim: exposes the hyphen-named directory `gaussian-splatting-lightning_amd/` as package `gspl_amd`.
 
     import gspl_amd                      # -> gaussian-splatting-lightning_amd/__init__.py
-    from gspl_amd import ops             # -> gaussian-splatting-lightning_amd/ops.py
+    from gspl_amd import ops             # -> gaussian-splatting-lightning_amd/ops/
     --model.renderer gspl_amd.renderers.HipGSplatRenderer   (reference CLI)
 """
 import importlib.util

@@ -4,7 +4,7 @@
  * This is the drop-in boundary: every entry point takes raw device
  * pointers + sizes + a hipStream_t passed as void*, returns an int status
  * (GSPL_OK == 0) and never throws.  No torch types cross this line; the Python
- * host side (gaussian-splatting-lightning_amd/ops.py) binds it with ctypes and
+ * host side (gaussian-splatting-lightning_amd/ops/) binds it with ctypes and
  * allocates every buffer through torch's caching allocator.
  *
  * Each function names the reference interface it replaces.  Paths are relative to
@@ -306,6 +306,12 @@ int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mode, int layo
                               float* v_packed, int packed_stride /* floats per row, >= 6+D(+2) */, int absgrad,
                               uint8_t* hit_flags /*nullable*/, void* stream);
 
+/* Deterministic (debug) mode of gspl_composite_bwd_packed (and of everything built on it: the fused Inria backward, the staged
+ * rasterizers): the per-splat gradient rows are added up in list order instead of by fp32 atomics in dispatch order, so two runs give
+ * the same bits.  Costs three extra passes over the list entries and stream-ordered scratch (hipMallocAsync); needs the list length
+ * on the host (n_isects >= 0) and 16-pixel list tiles.  Returns the previous setting.  Process-wide.  Additive entries. */
+int gspl_set_deterministic(int on);
+int gspl_get_deterministic(void);
 /* Name of the kernel template the two backward entry points launch in this build (profile look-ups in bench.py). */
 const char* gspl_composite_bwd_kernel_name(void);
 

@@ -43,3 +43,44 @@ def test_backward_run_to_run_spread_is_fp32_reassociation_only(mode):
         assert spread.max() <= 2e-5, (k, float(spread.max()))
     print(f"[spread] worst run-to-run spread over 6 launches: {worst:.2e} (relative to |g| + rms)")
     assert all(torch.equal(runs[0]["hit"], r["hit"]) for r in runs)
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_is_bit_reproducible_and_within_the_spread():
+    """`ops.set_deterministic(True)` (gspl_set_deterministic): the compositing backward's per-splat rows are added in list order, not by
+    atomics in dispatch order — two runs give identical bits, with and without absgrad, and the result sits inside the spread of the
+    regular (atomics) mode."""
+    import numpy as np
+    import gspl_amd  # noqa: F401
+    from gspl_amd import ops
+    from oracle import gsplat_oracle as O
+    dev = torch.device("cuda:0")
+    W, H, n = 480, 320, 30000
+    means, scales, quats, opac, shs = O.synthetic_scene(n, seed=21)
+    cam = O.synthetic_camera(W, H, 400.0)
+    res = O.project_gaussians(means, scales * 4, 1.0, quats, cam["world_to_camera"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W)
+    xys, depths, radii, conics, comp = [r.float().to(dev) if r.dtype != torch.int32 else r.to(dev) for r in res[:5]]
+    g = torch.Generator().manual_seed(4)
+    colors = torch.rand(n, 3, generator=g).to(dev)
+    op = (opac.reshape(-1).float().to(dev) * comp)
+    w = torch.randn(H, W, 3, generator=g).to(dev)
+    flat, offs = ops.bin_gaussians(xys, depths, radii, H, W, 16, conics=conics, opacities=op)
+
+    def run(absgrad):
+        leaves = [t.clone().requires_grad_(True) for t in (xys, conics, colors, op)]
+        out, _ = ops.rasterize_to_pixels(leaves[0], leaves[1][None], leaves[2][None], leaves[3][None], W, H, 16,
+                                         offs.reshape(1, (H + 15) // 16, (W + 15) // 16), flat, absgrad=absgrad)
+        (out[0] * w).sum().backward()
+        return [t.grad.clone() for t in leaves] + ([leaves[0].absgrad.clone()] if absgrad else [])
+
+    for absgrad in (False, True):
+        loose = run(absgrad)
+        was = ops.set_deterministic(True)
+        try:
+            a, b = run(absgrad), run(absgrad)
+        finally:
+            ops.set_deterministic(was)
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        for x, y in zip(a, loose):
+            scale = float(y.abs().max()) + 1e-30
+            assert float((x - y).abs().max()) <= 2e-5 * scale

@@ -822,6 +822,23 @@ def test_inria_rasterizer_reads_shs_dc_and_shs_rest_in_place(hip, fused):
             assert_close_scaled(dc.grad.cpu().numpy(), merged.grad[:, :1].cpu().numpy(), 2e-5, f"v_shs_dc deg={deg}")
             assert_close_scaled(rest.grad.cpu().numpy(), merged.grad[:, 1:].cpu().numpy(), 2e-5, f"v_shs_rest deg={deg}")
             assert_close_scaled(m.grad.cpu().numpy(), g_means0.cpu().numpy(), 1e-4, f"v_means deg={deg}")
+            # ... and with the compositing backward's rows added in list order (`set_deterministic`: no atomics-ordered sum left on
+            # this path) the two forms give the SAME BITS, for every gradient
+            was = hip.set_deterministic(True)
+            try:
+                grads = []
+                for form in ("merged", "split"):
+                    for t in (m, s, q, o, merged, dc, rest):
+                        t.grad = None
+                    kw = dict(shs=merged) if form == "merged" else dict(shs=dc, shs_rest=rest)
+                    img, _ = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, scales=s, rotations=q, **kw)
+                    (img * wimg.to(_dev())).sum().backward()
+                    sh_grad = merged.grad if form == "merged" else torch.cat((dc.grad, rest.grad), 1)
+                    grads.append([m.grad.clone(), s.grad.clone(), q.grad.clone(), o.grad.clone(), sh_grad.clone()])
+                for a, b, name in zip(grads[0], grads[1], ("means", "scales", "quats", "opacities", "shs")):
+                    assert torch.equal(a, b), f"deterministic mode, deg={deg}: {name} differs between the merged and the split form"
+            finally:
+                hip.set_deterministic(was)
             n_active = (deg + 1) ** 2
             assert float(rest.grad[:, n_active - 1:].abs().max()) == 0.0 if n_active < 16 else True
             # tuple form
@@ -863,6 +880,18 @@ def test_fused_inria_device_side_list_length_and_guesses(hip):
         assert torch.equal(img, r_img) and torch.equal(radii, r_radii)
         for g, rg in zip(grads, r_grads):
             assert float((g - rg).abs().max()) <= 2e-5 * max(1.0, float(rg.abs().max()))
+    # the same with the backward's sums in list order: fused and staged, whatever the guess, give the same bits
+    was = hip.set_deterministic(True)
+    try:
+        ref = {id(sc): render(sc, False) for sc in (small, big)}
+        for sc in (big, small, big):
+            img, radii, grads = render(sc, True)
+            r_img, r_radii, r_grads = ref[id(sc)]
+            assert torch.equal(img, r_img) and all(torch.equal(g, rg) for g, rg in zip(grads, r_grads))
+            again = render(sc, True)[2]
+            assert all(torch.equal(g, rg) for g, rg in zip(grads, again)), "two runs of the deterministic mode differ"
+    finally:
+        hip.set_deterministic(was)
 
 
 def test_degenerate_inputs(hip):
