@@ -310,7 +310,12 @@ def cpu_baseline(workload_name, api):
     torch.autograd.backward([xys, conics, rgbs, op],
                             [torch.from_numpy(g_xy), torch.from_numpy(g_con), torch.from_numpy(g_col), torch.from_numpy(g_op)])
     t5 = time.perf_counter()
-    total = t5 - t0
+    # `value`: the legs a CPU implementation of this path would spend its time in — projection + SH (torch, all cores) and the
+    # compositing pair (C, OpenMP).  The binning leg between them is the ORACLE's numpy restatement of the key sort (test
+    # infrastructure, single-threaded sort of 13.8 M 64-bit keys): timed and listed, but nobody would ship it, so it stays out of
+    # `value` and `value_with_numpy_binning` carries the figure rounds 1-3 reported.
+    binning_s = t2 - t1
+    total = (t5 - t0) - binning_s
     ref = None
     try:
         ref = reference_projection_sh(workload_name, cores)
@@ -318,6 +323,8 @@ def cpu_baseline(workload_name, api):
         ref = {"kind": "reference", "failed": repr(e)}
     return {
         "value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port", "reference_projection_sh": ref,
+        "value_with_numpy_binning": 1.0 / (total + binning_s),
+        "binning_note": "ms.binning is the oracle's numpy restatement of the (tile | depth) key sort — test infrastructure, not a baseline; excluded from value",
         "sample": f"one fwd+bwd pass of {workload_name} (N={wl['n']}, {W}x{H}, I={int(flat.shape[0])}), fp32, "
                   f"torch CPU projection+SH (restating the reference's gaussian_projection.py/sh_utils.py) + OpenMP C compositing",
         "ms": {"project_sh_fwd": (t1 - t0) * 1e3, "binning": (t2 - t1) * 1e3, "composite_fwd": (t3 - t2) * 1e3,
