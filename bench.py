@@ -86,9 +86,11 @@ def parse():
     p.add_argument("--no-overlap-sh-update", action="store_true", help="(the default; kept for older command lines)")
     p.add_argument("--exchange", default="auto", choices=["counted", "padded", "auto"],
                    help="--parallelism sharded: format of the per-step record exchange (renderer option `exchange`)")
-    p.add_argument("--exchange-transport", default="collective", choices=["collective", "peer"],
+    p.add_argument("--exchange-transport", default="auto", choices=["auto", "collective", "peer"],
                    help="--parallelism sharded: collective = torch.distributed all-to-all (RCCL); peer = direct writes into the peers' IPC-mapped "
-                        "receive buffers + flags (renderer option `exchange_transport`)")
+                        "receive buffers + flags (renderer option `exchange_transport`).  auto (default): collective with one rank; with several, "
+                        "peer IF it sets up on every rank and one validation frame equals the collective route's image bit for bit on every "
+                        "rank, else collective")
     p.add_argument("--staged-sharded-step", action="store_true",
                    help="--parallelism sharded: the stage-by-stage formulation of the step (eleven autograd nodes) instead of the three-node one")
     p.add_argument("--no-renderer-only", action="store_true", help="skip the second timed region (no optimizer) of a one-GPU run")
@@ -491,6 +493,7 @@ def main():
 
     DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
     counter = {"n": 0}
+    transport_note = None
 
     if mode == "sharded":
         # ---- the reference's configs/distributed.yaml: Gaussians sharded, one packed all-to-all per step ------------------
@@ -500,12 +503,41 @@ def main():
         N = hi - lo
         cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
         # tile_based_culling as in the reference's configs/distributed-accel.yaml (lossless here: same images and gradients)
-        renderer = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step, exchange=args.exchange,
-                                                exchange_transport=args.exchange_transport).instantiate()
-        renderer.world_size, renderer.global_rank = world, rank
-        renderer.camera_lookup = lambda idx, training: cams[idx]
-        renderer.train()
+        def make_renderer(transport):
+            r = HipGSplatDistributedRenderer(tile_based_culling=True, fused_step=not args.staged_sharded_step,
+                                             exchange=("auto" if (transport == "peer" and args.exchange == "counted") else args.exchange),
+                                             exchange_transport=transport).instantiate()
+            r.world_size, r.global_rank = world, rank
+            r.camera_lookup = lambda idx, training: cams[idx]
+            r.train()
+            return r
         bg = torch.zeros(3, device=dev)
+        transport, transport_note = args.exchange_transport, None
+        if transport == "auto":
+            transport = "collective"
+            if world > 1 and not args.staged_sharded_step:
+                # one validation frame over each transport: the forward is deterministic, so the peer route must reproduce the
+                # collective route's image bit for bit on EVERY rank; a set-up failure or a mismatch anywhere keeps the collective
+                ok, why = 1, "validated: one frame over the peer transport equals the collective route's image bit for bit on every rank"
+                try:
+                    ref_img = make_renderer("collective")(cams[rank % len(cams)], model, bg)["render"].detach()
+                    candidate = make_renderer("peer")
+                    img = candidate(cams[rank % len(cams)], model, bg)["render"].detach()
+                    if candidate._peer is None or not torch.equal(img, ref_img):
+                        ok, why = 0, "the peer route's validation frame differed from the collective route's (or the route was not taken)"
+                    if candidate._peer is not None:
+                        candidate._peer.check()
+                except Exception as e:      # IPC mapping refused, shared memory unavailable, ...
+                    ok, why = 0, f"peer transport set-up failed on rank {rank}: {e!r}"
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    transport = "peer"
+                elif ok == 1:
+                    why = "another rank could not use the peer transport"
+                transport_note = why
+        renderer = candidate if (transport == "peer" and args.exchange_transport == "auto") else make_renderer(transport)
+        args.exchange_transport = transport
         target = torch.full((3, H, W), 0.5, device=dev)
         loss_fn = (lambda img: ops.photometric_loss(img, target, 0.2)) if args.loss == "photometric" else (lambda img: (img - target).abs().mean())
         tensors = model.leaves()
@@ -829,7 +861,8 @@ def main():
                                  "chunked all-reduce of the parameter gradients overlapped with the chunk-wise fused Adam every step")
                               + f", all-reduce of the densification stats every {DENSIFY_INTERVAL} steps"),
                "sharded": f"Gaussians sharded over {world} rank(s), {world} camera(s)/step, packed all-to-all of splat records (configs/distributed.yaml); "
-                          + (f"exchange format of the last step: {renderer.last_exchange} over {args.exchange_transport}; step as "
+                          + (f"exchange format of the last step: {renderer.last_exchange} over the {args.exchange_transport} transport"
+                             + (f" ({transport_note})" if transport_note else "") + "; step as "
                              + ("eleven stage-by-stage autograd nodes" if args.staged_sharded_step else "three autograd nodes (front / exchange / back)")
                              if mode == "sharded" else "")}[mode]
         line = {

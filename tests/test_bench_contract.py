@@ -71,6 +71,11 @@ def test_two_rank_launch_line(mode):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["config"]["parallelism_mode"] == ("sharded" if mode == "default" else "replicated")      # sharded unless told otherwise
     assert ("masked" in line["config"]["parallelism"]) == (mode == "replicated-masked")
+    if mode == "default":
+        # --exchange-transport auto: the peer transport (records written straight into the other process's IPC-mapped buffer) is taken
+        # only after a validation frame reproduced the collective route's image bit for bit on every rank — which two processes on one
+        # GPU can do — and the line says which transport the numbers come from
+        assert "over the peer transport (validated" in line["config"]["parallelism"], line["config"]["parallelism"]
     assert abs(line["value"] - 2e3 / line["ms_per_step"]) <= 1e-3 * line["value"]               # whole-job images/s
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None                           # rank 0, N = 1 only
     roof = line["roofline"]          # `frac` is priced on the list entries the launch WALKS; the rect intersections beside it
