@@ -188,7 +188,8 @@ class _DevicePtr:
 
 
 class PeerExchange:
-    """The fixed-size ("padded") record exchange of the Gaussian-sharded renderer WITHOUT a collective: every rank writes its rows
+    """The record exchange of the Gaussian-sharded renderer (fixed-size "padded" format, or "counted" with the count matrix the ranks
+    post through a `HostMailbox`) WITHOUT a collective: every rank writes its rows
     straight into the receive buffer of the rank that renders that camera — device memory of the peer PROCESS mapped once through HIP
     IPC (csrc/peer.hip: fine-grained memory, reached over xGMI or on the same GPU) — and raises a flag word per destination; the
     receiver's stream waits for the flag words of its sources.  Three small launches per direction, nothing for the host to wait
@@ -293,33 +294,45 @@ class PeerExchange:
             L.call("gspl_peer_signal", W, (ctypes.c_void_p * W)(*flag_dst), value, L.stream())
             L.call("gspl_peer_wait", ctypes.c_void_p(my_flags), W, value, self.MAX_POLLS, ctypes.c_void_p(self._mine + self._layout["err"]), L.stream())
 
-    def route(self, rows_per_rank: Sequence[int]):
-        """(forward, backward) callables for `ops.sharded_exchange`, as `all_to_all_route` returns them, for ONE training step:
-        forward: rows [W * n_me, 12] grouped by destination -> rows [sum n_s, 12] grouped by source (a view of this rank's receive
-        buffer, valid until the exchange after the next one); backward: gradients of those -> gradients of the rows that were sent."""
+    def route(self, rows_per_rank: Sequence[int], matrix: Optional[Sequence[Sequence[int]]] = None):
+        """(forward, backward) callables for `ops.sharded_exchange`, as `all_to_all_route` returns them, for ONE training step.
+        matrix[s][d] = rows rank s sends to rank d, identical on every rank (None: the fixed-size format, n_s rows to everybody; the
+        counted format passes the per-destination visible counts every rank posted through a `HostMailbox`).
+        forward: my rows grouped by destination -> the rows of every source for my camera, grouped by source (a view of this rank's
+        receive buffer, valid until the exchange after the next one); backward: gradients of those -> gradients of the rows I sent."""
         rows_per_rank = [int(v) for v in rows_per_rank]
+        W, me, row = self.world, self.rank, self.FLOATS * 4
+        if matrix is None:
+            matrix = [[n] * W for n in rows_per_rank]
+        matrix = [[int(v) for v in r] for r in matrix]
+        if len(matrix) != W or any(len(r) != W for r in matrix) or any(v < 0 or v > rows_per_rank[s] for s, r in enumerate(matrix) for v in r):
+            raise ValueError("PeerExchange.route: matrix must be W x W with 0 <= matrix[s][d] <= rows_per_rank[s]")
         self._ensure(rows_per_rank)
         self.step += 1
-        step, par, lay, W, me, row = self.step, self.step & 1, self._layout, self.world, self.rank, self.FLOATS * 4
-        n_me, total = rows_per_rank[me], sum(rows_per_rank)
-        prefix = [0]
-        for v in rows_per_rank:
-            prefix.append(prefix[-1] + v)
+        step, par, lay = self.step, self.step & 1, self._layout
+        sent = [0]                      # my rows, grouped by destination
+        for d in range(W):
+            sent.append(sent[-1] + matrix[me][d])
+        got = [0]                       # the rows I receive, grouped by source
+        for s_ in range(W):
+            got.append(got[-1] + matrix[s_][me])
+        before_me_at = [sum(matrix[s_][d] for s_ in range(me)) for d in range(W)]       # my slot in destination d's forward area
+        my_block_at = [sum(matrix[s_][d] for d in range(me)) for s_ in range(W)]        # my slot in source s's backward area
         fwd_of = lambda r: self.base[r] + lay["fwd"] + par * lay["fwd_stride"]
         bwd_of = lambda r: self.base[r] + lay["bwd"] + par * lay["bwd_stride"]
         view = lambda ptr, n: torch.as_tensor(_DevicePtr(ptr, (n, self.FLOATS), "<f4"), device=self.device)
 
         def forward(rows: torch.Tensor) -> torch.Tensor:
-            assert rows.shape == (W * n_me, self.FLOATS) and rows.dtype == torch.float32, (tuple(rows.shape), W, n_me)
-            self._send(rows, [d * n_me for d in range(W + 1)], [fwd_of(d) + prefix[me] * row for d in range(W)],
+            assert rows.shape == (sent[-1], self.FLOATS) and rows.dtype == torch.float32, (tuple(rows.shape), sent[-1])
+            self._send(rows, sent, [fwd_of(d) + before_me_at[d] * row for d in range(W)],
                        [self.base[d] + lay["flags_f"] + 8 * me for d in range(W)], self._mine + lay["flags_f"], step)
-            return view(fwd_of(me), total) if total else rows.new_zeros((0, self.FLOATS))
+            return view(fwd_of(me), got[-1]) if got[-1] else rows.new_zeros((0, self.FLOATS))
 
         def backward(v_rows: torch.Tensor) -> torch.Tensor:
-            assert v_rows.shape == (total, self.FLOATS), (tuple(v_rows.shape), total)
-            self._send(v_rows.to(torch.float32), prefix, [bwd_of(s) + me * rows_per_rank[s] * row for s in range(W)],
-                       [self.base[s] + lay["flags_b"] + 8 * me for s in range(W)], self._mine + lay["flags_b"], step)
-            return view(bwd_of(me), W * n_me) if n_me else v_rows.new_zeros((0, self.FLOATS))
+            assert v_rows.shape == (got[-1], self.FLOATS), (tuple(v_rows.shape), got[-1])
+            self._send(v_rows.to(torch.float32), got, [bwd_of(s_) + my_block_at[s_] * row for s_ in range(W)],
+                       [self.base[s_] + lay["flags_b"] + 8 * me for s_ in range(W)], self._mine + lay["flags_b"], step)
+            return view(bwd_of(me), sent[-1]) if sent[-1] else v_rows.new_zeros((0, self.FLOATS))
         return forward, backward
 
 

@@ -53,7 +53,8 @@ class HipGSplatDistributedRenderer(RendererConfig):
     # How the records of a training step travel.  "collective": torch.distributed all-to-all (RCCL over xGMI; gloo in the tests) —
     # the reference's transport.  "peer": every rank writes its rows straight into the destination rank's receive buffer (HIP IPC
     # mapping, fine-grained device memory) and raises a flag the receiver's stream waits for (distributed.PeerExchange, csrc/peer.hip):
-    # no collective and no host round trip in the step.  Implies the fixed-size "padded" format (every size is known before the step);
+    # no collective and no host round trip in the step.  With exchange="auto" it uses the fixed-size "padded" format (every size is
+    # known before the step); with "counted" the W x W matrix of visible counts travels through shared host memory first.
     # GPU, three-node step, training steps only — anything else takes the collective route.
     exchange_transport: str = "collective"
     # The step as three autograd nodes (`ops.sharded_front` / `sharded_exchange` / `sharded_back`: project + colours + pack, the
@@ -106,8 +107,6 @@ class HipGSplatDistributedRendererImpl(Renderer):
             raise ValueError(f"exchange must be auto | counted | padded, got {config.exchange!r}")
         if config.exchange_transport not in ("collective", "peer"):
             raise ValueError(f"exchange_transport must be collective | peer, got {config.exchange_transport!r}")
-        if config.exchange_transport == "peer" and config.exchange == "counted":
-            raise ValueError("exchange_transport='peer' sends fixed-size records: exchange must be 'padded' or 'auto'")
         self._peer = None                         # distributed.PeerExchange, created by the first step that uses it
         self.last_exchange = None                 # format the last forward used ("counted" | "padded"; None: nothing exchanged)
         self._visible_permille = -1               # share of (camera, splat) pairs visible in this rank's last step; -1: unknown
@@ -218,8 +217,8 @@ class HipGSplatDistributedRendererImpl(Renderer):
     def _exchange_format(self) -> str:
         """Identical on every rank: a function of the configuration and of the gathered rows only."""
         c = self.config
-        if c.exchange_transport == "peer":
-            return "padded"
+        if c.exchange_transport == "peer" and c.exchange == "auto":
+            return "padded"             # (every size known before the step: not even the counts have to travel)
         if c.exchange != "auto":
             return c.exchange
         if self._world() > 1 and not c.auto_padded_with_peers:
@@ -419,7 +418,15 @@ class HipGSplatDistributedRendererImpl(Renderer):
                     route = D.all_to_all_route(send_counts, peer_counts, self.group)
             else:
                 self._visible_permille, self._visible_pending = int(1000 * sum(send_counts) // pairs), None
-                if exchanging:
+                if exchanging and c.exchange_transport == "peer" and torch.is_grad_enabled():
+                    # the whole W x W count matrix through shared host memory (every rank posts its row), then direct peer writes
+                    if self.__dict__.get("_count_mailbox") is None:
+                        self._count_mailbox = D.HostMailbox(rank, self.group, width=len(cameras))
+                    matrix = self._count_mailbox.exchange(send_counts)
+                    if self._peer is None:
+                        self._peer = D.PeerExchange(rank, self.group, records.device)
+                    route = self._peer.route(peer_counts, matrix)
+                elif exchanging:
                     # the counts were on the host before the colour kernel and the scatter had run (two-phase pack): on RCCL their
                     # exchange goes out on the control stream, next to those kernels instead of behind them
                     recv_counts = self._on_control_stream(D.exchange_counts, send_counts, records.device, self.group)

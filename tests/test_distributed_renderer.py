@@ -222,7 +222,7 @@ def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
             # the records of this step went through the peers' IPC-mapped buffers, not through a collective: the image must be the
             # one the collective route composes from the same records, bit for bit (the forward pass is deterministic)
             assert renderer._peer is not None and renderer._peer.step == 1 and renderer._peer.world == world
-            via_collective = HipGSplatDistributedRenderer(exchange="padded", fused_step=True).instantiate()
+            via_collective = HipGSplatDistributedRenderer(exchange=exchange, fused_step=True).instantiate()
             via_collective.world_size, via_collective.global_rank = world, rank
             via_collective.camera_lookup = renderer.camera_lookup
             via_collective.train()
@@ -380,7 +380,7 @@ def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["auto", "padded", "auto-staged", "padded-peer"])
+@pytest.mark.parametrize("exchange", ["auto", "padded", "auto-staged", "padded-peer", "counted-peer"])
 def test_world2_sharded_renderer_shared_gpu(tmp_path, exchange):
     """On the GPU the step runs as three autograd nodes (ops.sharded_front / sharded_exchange / sharded_back); "auto-staged" keeps
     the stage-by-stage formulation (what a subclass overriding `get_rgbs` and the extra render types take) under the same checks;

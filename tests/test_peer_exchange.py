@@ -54,3 +54,23 @@ def test_wait_gives_up_and_reports_the_missing_source():
         L.call("gspl_peer_wait", L.ptr(flags), 2, 5, 2000, L.ptr(err), L.stream())
     torch.cuda.synchronize()
     assert int(err.item()) == 0
+
+
+def test_single_rank_counted_matrix():
+    """The counted format: fewer rows than the shard holds, as the count matrix says."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import distributed as D
+    dev = torch.device("cuda:0")
+    px = D.PeerExchange(0, None, dev)
+    g = torch.Generator().manual_seed(1)
+    for n, c in ((1000, 640), (1000, 0), (1000, 1000)):
+        fwd, bwd = px.route([n], [[c]])
+        rows = torch.randn(c, 12, generator=g).to(dev)
+        got = fwd(rows)
+        assert got.shape == (c, 12) and torch.equal(got, rows)
+        v = torch.randn(c, 12, generator=g).to(dev)
+        assert torch.equal(bwd(v), v)
+    with pytest.raises(ValueError):
+        px.route([10], [[11]])
+    px.check()
+    px.close()
