@@ -118,20 +118,23 @@ def _mark():
     return e
 
 
-def reference_shaped_loop(dev, wl, cam_dicts, steps):
+def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True):
     """`--loop reference-shaped` (images/s of the Lightning loop, not of a static-N step on activated leaves): the
     consumer side restated in bench_loop.py drives `HipVanillaRenderer` through what `GaussianSplatting.training_step` does
-    (internal/gaussian_splatting.py:329-397) — activations forward and backward every step, densify / prune every 100 steps (N
-    changes: allocator, list-length guesses and optimizer state see new sizes), one opacity reset, the SH degree raised twice."""
+    (internal/gaussian_splatting.py:329-397) — raw parameters behind exp / normalize / sigmoid getters (fuse_activations: evaluated
+    inside the renderer's preprocess kernels, the plugin's default for such a model; False: by torch around it, forward and backward
+    every step, as the reference's renderer has them), densify / prune every 100 steps (N changes: allocator, list-length guesses
+    and optimizer state see new sizes), one opacity reset, the SH degree raised twice."""
     import bench_loop as BL
     import gspl_amd  # noqa: F401
     from gspl_amd import ops, synthetic
     from gspl_amd.optimizers import FusedAdam
     from gspl_amd.renderers import HipVanillaRenderer
     W, H = wl["width"], wl["height"]
+    torch.cuda.empty_cache()          # every run of the loop starts with a cold caching allocator (the event steps' device mallocs are part of it)
     clean = synthetic.scene(wl["n"], seed=42)
     cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
-    renderer = HipVanillaRenderer()
+    renderer = HipVanillaRenderer(fuse_activations=fuse_activations)
     bg = torch.zeros(3, device=dev)
     # targets: the clean scene from every camera (degree 3); the trained model starts from a perturbed copy at degree 1
     truth = synthetic.ModelObject(*[t.to(dev) for t in clean], active_sh_degree=3)
@@ -156,6 +159,8 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps):
     return {
         "what": "bench_loop.py: RawGaussians (exp / sigmoid / normalize getters) + restated VanillaDensityControllerImpl + FusedAdam x 2 "
                 "+ HipVanillaRenderer + fused 0.8 L1 + 0.2 (1 - SSIM), one camera of the set per step, targets = the unperturbed scene",
+        "activations": ("inside the preprocess kernels (HipVanillaRenderer.fuse_activations, renderer.model_raw_parameters)" if fuse_activations
+                        else "torch getters around the renderer, forward and backward (fuse_activations=False)"),
         "steps": steps, "images_per_s_densifying": round(steps / res["elapsed_s"], 2), "ms_per_step_mean": round(1e3 * res["elapsed_s"] / steps, 4),
         "ms_per_step_between_events_p50": round(srt[len(srt) // 2], 4) if srt else None,
         "ms_per_event_step_mean": round(sum(loud) / len(loud), 3) if loud else None,
@@ -898,6 +903,10 @@ def main():
         if world == 1 and mode == "single" and args.loop == "reference-shaped" and api == "vanilla" and SH_DEGREE == 3:
             try:
                 line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps)
+                # the same loop with the activations left to torch (what the reference's renderer does with the same model)
+                other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False)
+                line["reference_shaped_loop"]["with_torch_activations"] = {
+                    k: other[k] for k in ("activations", "images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end")}
             except Exception as e:  # an extra: it must never take the bench line down
                 line["reference_shaped_loop"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -6,8 +6,10 @@ are not on the GPU box (no reference tree there), so this module restates just e
 what that loop does to it — and times that:
 
   * `RawGaussians`        raw parameters (log scales, logit opacities, unnormalised quaternions, shs_dc / shs_rest) behind the
-                          activated getters of `VanillaGaussianModel` (internal/models/vanilla_gaussian.py:341-364): every step pays
-                          exp / sigmoid / normalize forward and backward, as the reference does;
+                          activated getters of `VanillaGaussianModel` (internal/models/vanilla_gaussian.py:341-364): exp / sigmoid /
+                          normalize forward and backward every step — by torch around the renderer, as the reference has them
+                          (`HipVanillaRenderer(fuse_activations=False)`), or inside its preprocess kernels (the plugin's default
+                          for a model whose getters are exactly these: `renderer.model_raw_parameters`);
   * `DensityController`   `VanillaDensityControllerImpl` (internal/density_controllers/vanilla_density_controller.py:69-286):
                           `retain_grad` on the screen-space means, statistics after every backward (the package's fused kernel, as
                           `HipDensityStatsMixin` wires it), clone / split / prune every `densification_interval` steps with the
@@ -43,6 +45,8 @@ class RawGaussians(nn.Module):
         self.active_sh_degree, self.max_sh_degree = active_sh_degree, max_sh_degree
         self.is_pre_activated = False
 
+    # what the reference's VanillaGaussianModel is recognised by (renderer.model_raw_parameters): getters = exp / normalize / sigmoid
+    fused_activations = {"scales": "exp", "rotations": "normalize", "opacities": "sigmoid"}
     properties = property(lambda s: s.gaussians)
     n_gaussians = property(lambda s: s.gaussians["means"].shape[0])
 

@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -27,6 +27,7 @@ GSPL_LAYOUT_HWC = 0
 GSPL_LAYOUT_CHW = 1
 GSPL_SH_ADD_HALF_CLAMP = 1
 GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
+GSPL_INRIA_RAW_PARAMS = 1      # gspl_inria_state.flags: scales / rotations / opacities are the model's raw parameters
 GSPL_BIN_SPAN_BYTES = 64
 GSPL_ADAM_MAX_TENSORS = 16
 
@@ -51,7 +52,7 @@ class InriaState(ctypes.Structure):
                 ("means2d", ctypes.c_void_p), ("depths", ctypes.c_void_p), ("conics", ctypes.c_void_p), ("colors", ctypes.c_void_p),
                 ("clamped", ctypes.c_void_p), ("cov3d", ctypes.c_void_p), ("sh_jac", ctypes.c_void_p),
                 ("alphas", ctypes.c_void_p), ("final_Ts", ctypes.c_void_p), ("last_ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p),
-                ("flatten_ids", ctypes.c_void_p)]
+                ("flatten_ids", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("flags", ctypes.c_int)]
 
 
 _P = c_void_p

@@ -23,7 +23,7 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // per-splat intermediates of one frame, carved out of ONE allocation (tag GSPL_BUF_GEOMETRY)
 struct GeomLayout {
-    size_t radii, means2d, depths, conics, colors, clamped, cov3d, sh_jac, order, cum, big_list, spans, total;
+    size_t radii, means2d, depths, conics, colors, clamped, cov3d, sh_jac, order, cum, big_list, spans, opac, total;
 };
 static GeomLayout geom_layout(size_t n) {
     GeomLayout g;
@@ -32,6 +32,7 @@ static GeomLayout geom_layout(size_t n) {
     g.means2d = take(8 * n); g.depths = take(4 * n); g.conics = take(12 * n); g.colors = take(12 * n);
     g.clamped = take(3 * n); g.cov3d = take(24 * n); g.sh_jac = take(36 * n);
     g.order = take(4 * n); g.cum = take(8 * (n + 1)); g.big_list = take(4 * n); g.spans = take((size_t)GSPL_BIN_SPAN_BYTES * n);
+    g.opac = take(4 * n);
     g.radii = 0;       // radii are an OUTPUT tensor of the call, not part of the block
     g.total = off;
     return g;
@@ -155,7 +156,12 @@ extern "C" int gspl_rasterize_inria_fwd(
     if (N > 0 && (!means3D || !opacities || !radii || !viewmatrix || !projmatrix || !campos)) return fail_arg("rasterize_inria_fwd: NULL required pointer");
     const int tile = 16, tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream, ss = (hipStream_t)side_stream;
+    const int flags = st->flags;
+    if (flags & ~GSPL_INRIA_RAW_PARAMS) return fail_arg("rasterize_inria_fwd: unknown state->flags (zero the struct before the call)");
+    const bool raw = (flags & GSPL_INRIA_RAW_PARAMS) != 0;
+    if (raw && (cov3D_precomp || (N > 0 && (!scales || !rotations)))) return fail_arg("rasterize_inria_fwd: raw parameters need scales and rotations");
     memset(st, 0, sizeof(*st));
+    st->flags = flags;
     st->N = N; st->width = width; st->height = height;
     const size_t n = (size_t)(N > 0 ? N : 1);
     const GeomLayout g = geom_layout(n);
@@ -166,6 +172,9 @@ extern "C" int gspl_rasterize_inria_fwd(
     st->means2d = (float*)(geom + g.means2d); st->depths = (float*)(geom + g.depths); st->conics = (float*)(geom + g.conics);
     st->colors = (float*)(geom + g.colors); st->clamped = (uint8_t*)(geom + g.clamped); st->cov3d = (float*)(geom + g.cov3d);
     st->sh_jac = (float*)(geom + g.sh_jac);
+    const float* raw_opacities = raw ? opacities : nullptr;
+    if (raw) opacities = (float*)(geom + g.opac);          // from here on: what binning and compositing read
+    st->opacities = const_cast<float*>(opacities);
     st->alphas = (float*)(img + im.alphas); st->final_Ts = (float*)(img + im.final_Ts); st->last_ids = (int32_t*)(img + im.last_ids);
     st->offsets = (int32_t*)(img + im.offsets);
     int32_t* order = (int32_t*)(geom + g.order);
@@ -193,9 +202,10 @@ extern "C" int gspl_rasterize_inria_fwd(
         if (!host) return fail_arg("rasterize_inria_fwd: no pinned host word");
         // geometry; then two independent chains: the colour (SH) kernel on the side stream, the count / depth-sort half of the
         // binning on the caller's stream; the host meanwhile waits for the one number that sizes the tile sort
-        rc = gspl_inria_preprocess_fwd(N, degree, n_coeffs, means3D, scales, rotations, cov3D_precomp, shs, shs_rest, colors_precomp, viewmatrix, projmatrix,
-                                       campos, width, height, tile, tanfovx, tanfovy, scale_modifier, radii, st->means2d, st->depths, st->conics,
-                                       st->colors, st->clamped, st->cov3d, nullptr, GSPL_INRIA_GEOMETRY, s);
+        if (!viewmatrix || !projmatrix) return fail_arg("rasterize_inria_fwd: NULL required pointer");
+        if (!cov3D_precomp && (!scales || !rotations)) return fail_arg("rasterize_inria_fwd: need scales+rotations or cov3D_precomp");
+        rc = inria_geometry_launch(N, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, width, height, tile, tanfovx, tanfovy, scale_modifier,
+                                   radii, st->means2d, st->depths, st->conics, st->cov3d, raw_opacities, st->opacities, s);
         if (rc != GSPL_OK) return rc;
         FrameEvents& fe = frame_events();
         if (!fe.ok) return check_hip(hipGetLastError(), "rasterize_inria_fwd: event");
@@ -298,6 +308,11 @@ extern "C" int gspl_rasterize_inria_bwd(
         if (e != hipSuccess) return check_hip(e, "rasterize_inria_bwd: clear");
     }
     int rc = GSPL_OK;
+    const bool raw = (st->flags & GSPL_INRIA_RAW_PARAMS) != 0;
+    if (raw) {
+        if (!st->opacities || !v_scales || !v_rotations) return fail_arg("rasterize_inria_bwd: raw parameters need the forward's state, v_scales and v_rotations");
+        opacities = st->opacities;         // the activated values the forward composited with
+    }
     if (st->n_isects > 0) {
         ProfScope prof(1, s);
         rc = gspl_composite_bwd_packed(N, st->n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width,
@@ -305,7 +320,8 @@ extern "C" int gspl_rasterize_inria_bwd(
                                        packed, 9, 0, hit_flags, s);
         if (rc != GSPL_OK) return rc;
     }
-    return gspl_inria_preprocess_bwd(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
+    return inria_preprocess_bwd_impl(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
                                      tanfovx, tanfovy, scale_modifier, radii, st->clamped, packed, packed + 2, packed + 6, 9, v_means3D, v_scales,
-                                     v_rotations, v_cov3D, v_shs, v_shs_rest, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac, s);
+                                     v_rotations, v_cov3D, v_shs, v_shs_rest, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac,
+                                     raw ? st->opacities : nullptr, s);
 }

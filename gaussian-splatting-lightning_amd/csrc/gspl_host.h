@@ -45,4 +45,20 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs, const float* dirs, con
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream,
                   const float* jac /* nullable: the forward's Jacobian; v_dirs then needs no coefficient read */);
+// inria.hip -> fused.hip: the geometry phase and the preprocess backward with the model's RAW parameters (GSPL_INRIA_RAW_PARAMS)
+int inria_geometry_launch(int N, const float* means, const float* scales, const float* quats, const float* cov3d_precomp,
+                          const float* viewmatrix, const float* projmatrix, int width, int height, int tile_size,
+                          float tanfovx, float tanfovy, float scale_modifier,
+                          int32_t* radii, float* means2d, float* depths, float* conics, float* cov3d,
+                          const float* raw_opacities /* nullable: activated parameters */, float* opacities_out, hipStream_t s);
+int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs, const float* means, const float* scales, const float* quats,
+                              const float* cov3d, const float* shs, const float* shs_rest,
+                              const float* viewmatrix, const float* projmatrix, const float* campos,
+                              int width, int height, float tanfovx, float tanfovy, float scale_modifier,
+                              const int32_t* radii, const uint8_t* clamped,
+                              const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
+                              float* v_means, float* v_scales, float* v_quats,
+                              float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
+                              float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac,
+                              const float* opac_act /* nullable: activated parameters */, void* stream);
 }  // namespace gspl

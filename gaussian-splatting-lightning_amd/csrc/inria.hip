@@ -95,6 +95,15 @@ __device__ __forceinline__ bool inria_geom(const InriaCam& cam, const float p[3]
     return G.det != 0.f;
 }
 
+// The model's activations, for the RAW-parameter form of the fused call (GSPL_INRIA_RAW_PARAMS): what the reference's model applies
+// in torch before every render and differentiates after every backward — `scale_activation` = exp, `rotation_activation` =
+// F.normalize (x / max(|x|, 1e-12)), `opacity_activation` = sigmoid (internal/models/vanilla_gaussian.py:345-358; ten elementwise
+// launches and a reduction per step at 1 M Gaussians, profiles/r05f_loop_sequence.txt) — evaluated where the parameters are read.
+// expf / IEEE division: the arithmetic of torch.exp / torch.sigmoid.
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float act_quat_norm(const float q[4]) { return fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f); }
+
+template <bool RAW>
 __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
     int N,
     const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
@@ -102,7 +111,8 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int width, int height, int tile_size, float tanfovx, float tanfovy, float scale_modifier,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
-    float* __restrict__ conics, float* __restrict__ cov3d) {
+    float* __restrict__ conics, float* __restrict__ cov3d,
+    const float* __restrict__ raw_opacities, float* __restrict__ opacities_out) {
     // rows of this block in LDS: inputs means[3] | scales[3] quats[4] (or cov3d_precomp[6]); then, over the same memory, the outputs
     // cov3d[6] | means2d[2] | conics[3]
     __shared__ __attribute__((aligned(16))) float s_buf[256 * 11];
@@ -129,9 +139,18 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
 #pragma unroll
             for (int k = 0; k < 6; ++k) S6[k] = s_a[t * 6 + k];
         } else {
-            const float s[3] = {s_a[t * 3 + 0] * scale_modifier, s_a[t * 3 + 1] * scale_modifier, s_a[t * 3 + 2] * scale_modifier};
+            float s[3] = {s_a[t * 3 + 0], s_a[t * 3 + 1], s_a[t * 3 + 2]};
             const float4 qv = *reinterpret_cast<const float4*>(s_q + t * 4);
-            const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            if constexpr (RAW) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) s[j] = expf(s[j]);
+                const float inv = 1.f / act_quat_norm(q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] *= inv;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s[j] *= scale_modifier;
             float R[9];
             quat_to_rotmat(q, R);
             cov3d_from_scale_rot(s, R, S6);
@@ -160,6 +179,7 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
         }
         radii[g] = o_radius;            // 4-byte columns: already one full line per 32 lanes
         depths[g] = o_depth;
+        if constexpr (RAW) opacities_out[g] = act_sigmoid(raw_opacities[g]);
     }
     __syncthreads();                    // every lane has read its input rows: the memory now takes the output rows
     float* s_cov = s_buf;
@@ -181,7 +201,9 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
 // (Measured, round 3: the LDS-staged form of this kernel — every array copied through LDS as 16-byte rows, as the forward does —
 // is SLOWER, 40.5 against 34.5 us at 1 M Gaussians: 31 KB of LDS per block and three barriers cost more occupancy than the
 // strided loads cost bandwidth; the kernel carries ~400 flops per Gaussian between its loads and its stores.)
-template <bool ACCUM>
+// RAW: `scales` / `quats` are the raw parameters and v_scales / v_quats / v_opac_dst their gradients (chain rule of exp, normalize,
+// sigmoid: v s, (v - q (q.v)) / |raw|, v o (1 - o)); `opac_act` = the activated opacities the forward stored.
+template <bool ACCUM, bool RAW>
 __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     int N,
     const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
@@ -192,10 +214,14 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     const float* __restrict__ v_means2d, const float* __restrict__ v_conics, int gs2, int gs3,
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
     float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc,
-    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst) {
+    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst, const float* __restrict__ opac_act) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
-    if (v_opac_dst) v_opac_dst[g] = v_opac_src[(int64_t)g * gs2];
+    if (v_opac_dst) {
+        float v = v_opac_src[(int64_t)g * gs2];
+        if constexpr (RAW) { const float o = opac_act[g]; v *= o * (1.f - o); }
+        v_opac_dst[g] = v;
+    }
     float vp[3] = {0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
     float G6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ndc[2] = {0.f, 0.f};
@@ -227,11 +253,28 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
         for (int r = 0; r < 3; ++r) vp[r] += cam.V[r * 4 + 0] * vpv[0] + cam.V[r * 4 + 1] * vpv[1] + cam.V[r * 4 + 2] * vpv[2];
 
         if (v_scales) {
-            const float s[3] = {scales[g * 3 + 0] * scale_modifier, scales[g * 3 + 1] * scale_modifier, scales[g * 3 + 2] * scale_modifier};
-            const float q[4] = {quats[g * 4 + 0], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+            float s[3] = {scales[g * 3 + 0], scales[g * 3 + 1], scales[g * 3 + 2]};
+            float q[4] = {quats[g * 4 + 0], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
+            float act_s[3] = {1.f, 1.f, 1.f}, inv_norm = 1.f;
+            if constexpr (RAW) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { act_s[j] = expf(s[j]); s[j] = act_s[j]; }
+                inv_norm = 1.f / act_quat_norm(q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] *= inv_norm;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s[j] *= scale_modifier;
             cov3d_bwd(s, q, G6, vs, vq);
 #pragma unroll
             for (int j = 0; j < 3; ++j) vs[j] *= scale_modifier;
+            if constexpr (RAW) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) vs[j] *= act_s[j];
+                const float qv = q[0] * vq[0] + q[1] * vq[1] + q[2] * vq[2] + q[3] * vq[3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vq[j] = (vq[j] - q[j] * qv) * inv_norm;
+            }
         }
     }
 #pragma unroll
@@ -265,6 +308,26 @@ __global__ __launch_bounds__(256) void masked_copy3_kernel(int N, const int32_t*
     }
 }
 
+// geometry phase, activated parameters (raw_opacities == NULL) or the model's raw ones (-> opacities_out [N] = sigmoid)
+int inria_geometry_launch(int N, const float* means, const float* scales, const float* quats, const float* cov3d_precomp,
+                          const float* viewmatrix, const float* projmatrix, int width, int height, int tile_size,
+                          float tanfovx, float tanfovy, float scale_modifier,
+                          int32_t* radii, float* means2d, float* depths, float* conics, float* cov3d,
+                          const float* raw_opacities, float* opacities_out, hipStream_t s) {
+    const int grid = (N + 255) / 256;
+    if (raw_opacities) {
+        if (cov3d_precomp || !opacities_out) return fail_arg("inria_preprocess_fwd: raw parameters need scales + rotations and room for the opacities");
+        hipLaunchKernelGGL(inria_preprocess_fwd_kernel<true>, dim3(grid), dim3(256), 0, s,
+                           N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
+                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d, raw_opacities, opacities_out);
+    } else {
+        hipLaunchKernelGGL(inria_preprocess_fwd_kernel<false>, dim3(grid), dim3(256), 0, s,
+                           N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
+                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d, (const float*)nullptr, (float*)nullptr);
+    }
+    return check_launch("inria_preprocess_fwd");
+}
+
 }  // namespace gspl
 
 extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
@@ -288,10 +351,8 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
     hipStream_t s = (hipStream_t)stream;
     const int grid = (N + 255) / 256;
     if (phases & GSPL_INRIA_GEOMETRY) {
-        hipLaunchKernelGGL(inria_preprocess_fwd_kernel, dim3(grid), dim3(256), 0, s,
-                           N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
-                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d);
-        int rc = check_launch("inria_preprocess_fwd");
+        int rc = inria_geometry_launch(N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size, tanfovx, tanfovy,
+                                       scale_modifier, radii, means2d, depths, conics, cov3d, nullptr, nullptr, s);
         if (rc != GSPL_OK) return rc;
     }
     if (!(phases & GSPL_INRIA_COLOURS)) return GSPL_OK;
@@ -308,7 +369,9 @@ extern "C" int gspl_inria_preprocess_fwd(int N, int degree, int n_coeffs,
                          GSPL_SH_ADD_HALF_CLAMP, colors, clamped, stream, sh_jac);
 }
 
-extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
+namespace gspl {
+// opac_act != NULL: scales / quats are RAW parameters (see inria_preprocess_fwd_kernel<true>), opac_act the activated opacities
+int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs,
                                          const float* means, const float* scales, const float* quats,
                                          const float* cov3d, const float* shs, const float* shs_rest,
                                          const float* viewmatrix, const float* projmatrix, const float* campos,
@@ -317,8 +380,8 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
                                          const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
                                          float* v_means, float* v_scales, float* v_quats,
                                          float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
-                                         float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac, void* stream) {
-    using namespace gspl;
+                                         float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac,
+                                         const float* opac_act, void* stream) {
     if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
     if (v_opacities && (!v_opacities_packed || grad_stride <= 0)) return fail_arg("inria_preprocess_bwd: v_opacities needs the packed gradient buffer");
     if (N == 0) return GSPL_OK;
@@ -351,13 +414,29 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
         int rc = check_launch("inria_preprocess_bwd(colors_precomp)");
         if (rc != GSPL_OK) return rc;
     }
-    if (accum)
-        hipLaunchKernelGGL(inria_preprocess_bwd_kernel<true>, dim3(grid), dim3(256), 0, s,
-                           N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
-                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities);
-    else
-        hipLaunchKernelGGL(inria_preprocess_bwd_kernel<false>, dim3(grid), dim3(256), 0, s,
-                           N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier,
-                           radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities);
+    if (opac_act && (!v_scales || !v_opacities || v_cov3d_precomp)) return fail_arg("inria_preprocess_bwd: raw parameters need v_scales, v_quats and v_opacities");
+#define GSPL_LAUNCH_PRE_BWD(A, R) hipLaunchKernelGGL((inria_preprocess_bwd_kernel<A, R>), dim3(grid), dim3(256), 0, s, \
+        N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier, \
+        radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities, opac_act)
+    if (accum) { if (opac_act) GSPL_LAUNCH_PRE_BWD(true, true); else GSPL_LAUNCH_PRE_BWD(true, false); }
+    else { if (opac_act) GSPL_LAUNCH_PRE_BWD(false, true); else GSPL_LAUNCH_PRE_BWD(false, false); }
+#undef GSPL_LAUNCH_PRE_BWD
     return check_launch("inria_preprocess_bwd");
+}
+}  // namespace gspl
+
+extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
+                                         const float* means, const float* scales, const float* quats,
+                                         const float* cov3d, const float* shs, const float* shs_rest,
+                                         const float* viewmatrix, const float* projmatrix, const float* campos,
+                                         int width, int height, float tanfovx, float tanfovy, float scale_modifier,
+                                         const int32_t* radii, const uint8_t* clamped,
+                                         const float* v_means2d, const float* v_conics, const float* v_colors, int grad_stride,
+                                         float* v_means, float* v_scales, float* v_quats,
+                                         float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
+                                         float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac, void* stream) {
+    return gspl::inria_preprocess_bwd_impl(N, degree, n_coeffs, means, scales, quats, cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
+                                           tanfovx, tanfovy, scale_modifier, radii, clamped, v_means2d, v_conics, v_colors, grad_stride, v_means, v_scales,
+                                           v_quats, v_cov3d_precomp, v_shs, v_shs_rest, v_colors_precomp, v_means2d_ndc, v_opacities_packed, v_opacities,
+                                           sh_jac, nullptr, stream);
 }

@@ -193,7 +193,9 @@ def _view(buf: Tensor, ptr: int, shape, dtype) -> Tensor:
 class _InriaFusedFn(torch.autograd.Function):
     @staticmethod
     @_guarded(1)
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest=None):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings, sh_rest=None, raw_params=False):
+        """raw_params: `opacities`, `scales`, `rotations` are the model's RAW parameters; sigmoid / exp / normalize run inside the preprocess
+        kernels (GSPL_INRIA_RAW_PARAMS) and the backward returns the raw parameters' gradients."""
         import ctypes
         s: GaussianRasterizationSettings = settings
         dev = means3D.device
@@ -211,6 +213,7 @@ class _InriaFusedFn(torch.autograd.Function):
         guess = S.last_isects.get(key, 0)
         hint = min(int(guess * 1.25) + 65536, MAX_ISECTS) if (S.speculative_emit and guess > 0) else 0
         state = L.InriaState()
+        state.flags = L.GSPL_INRIA_RAW_PARAMS if raw_params else 0
         holder = {"device": dev}
         _ALLOC_TLS.holder = holder
         side = _side_stream(dev)
@@ -262,7 +265,8 @@ class _InriaFusedFn(torch.autograd.Function):
             img = holder[L.GSPL_BUF_IMAGE][0]
             nI = int(state.n_isects)
             S.last_raster = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=_view(geom, state.means2d, (N, 2), torch.float32),
-                               conics=_view(geom, state.conics, (N, 3), torch.float32), opacities=opac,
+                               conics=_view(geom, state.conics, (N, 3), torch.float32),
+                               opacities=(_view(geom, state.opacities, (N,), torch.float32) if raw_params else opac),
                                colors=_view(geom, state.colors, (N, 3), torch.float32),
                                flatten_ids=(lists[:4 * nI].view(torch.int32) if lists is not None else torch.empty(0, dtype=torch.int32, device=dev)),
                                offsets=_view(img, state.offsets, (tile_w * tile_h,), torch.int32), radii=radii,
@@ -300,7 +304,7 @@ class _InriaFusedFn(torch.autograd.Function):
             for t in (v_means, v_ndc, v_opac):
                 t.zero_()
         ctx.holder = None
-        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest
+        return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest, None
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -313,8 +317,12 @@ class GaussianRasterizer(torch.nn.Module):
         self.raster_settings = raster_settings
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, shs_rest=None):
-        """`shs_rest` (extension; also accepted as `shs=(shs_dc, shs_rest)`): the model's two SH parameters as they are stored."""
+                cov3D_precomp=None, shs_rest=None, raw_parameters: bool = False):
+        """`shs_rest` (extension; also accepted as `shs=(shs_dc, shs_rest)`): the model's two SH parameters as they are stored.
+        `raw_parameters` (extension): `opacities`, `scales`, `rotations` are the model's RAW parameters — logits, log-scales,
+        unnormalised quaternions — and the activations of the reference's model (sigmoid / exp / F.normalize,
+        internal/models/vanilla_gaussian.py:345-358) run inside the preprocess kernels, forward and backward, instead of as ten torch
+        launches and a reduction per step around the call."""
         if isinstance(shs, (tuple, list)):
             shs, shs_rest = shs
         if (shs is None) == (colors_precomp is None):
@@ -326,4 +334,11 @@ class GaussianRasterizer(torch.nn.Module):
         fn = _InriaFusedFn if S.fused_inria else _InriaRasterizeFn
         if shs_rest is not None and shs_rest.shape[1] == 0:
             shs_rest = None
+        if raw_parameters:
+            if cov3D_precomp is not None:
+                raise Exception("raw_parameters needs the scale/rotation pair")
+            if S.fused_inria:
+                return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, None, self.raster_settings, shs_rest, True)
+            # the stage-by-stage orchestration takes activated values: the same three activations through torch
+            opacities, scales, rotations = torch.sigmoid(opacities), torch.exp(scales), torch.nn.functional.normalize(rotations)
         return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings, shs_rest)

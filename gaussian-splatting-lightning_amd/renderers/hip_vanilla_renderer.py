@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import ops
-from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars, model_sh_pair
+from .renderer import Renderer, RendererOutputInfo, RendererOutputTypes, camera_hw, camera_scalars, model_sh_pair, model_raw_parameters
 
 
 def _tan_half(fov):
@@ -22,10 +22,14 @@ def _tan_half(fov):
 
 
 class HipVanillaRenderer(Renderer):
-    def __init__(self, compute_cov3D_python: bool = False, convert_SHs_python: bool = False):
+    def __init__(self, compute_cov3D_python: bool = False, convert_SHs_python: bool = False, fuse_activations: bool = True):
+        """fuse_activations (extension): a model whose getters are exp / normalize / sigmoid of stored parameters
+        (`renderer.model_raw_parameters`) hands the rasterizer its RAW parameters and the activations run inside the preprocess
+        kernels; False: the getters are always called."""
         super().__init__()
         self.compute_cov3D_python = compute_cov3D_python
         self.convert_SHs_python = convert_SHs_python
+        self.fuse_activations = fuse_activations
 
     @staticmethod
     def _settings(viewpoint_camera, bg_color, scaling_modifier, sh_degree):
@@ -60,11 +64,16 @@ class HipVanillaRenderer(Renderer):
         settings = self._settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree)
         rasterizer = ops.GaussianRasterizer(raster_settings=settings)
 
-        scales = rotations = cov3D_precomp = None
+        scales = rotations = cov3D_precomp = opacities = None
+        raw = model_raw_parameters(pc) if (self.fuse_activations and not self.compute_cov3D_python) else None
         if self.compute_cov3D_python:
             cov3D_precomp = pc.get_covariance(scaling_modifier)
+        elif raw is not None:
+            scales, rotations, opacities = raw
         else:
             scales, rotations = pc.get_scaling, pc.get_rotation
+        if opacities is None:
+            opacities = pc.get_opacity
 
         shs = shs_rest = colors_precomp = None
         if override_color is None:
@@ -82,7 +91,8 @@ class HipVanillaRenderer(Renderer):
 
         rendered_image, radii = rasterizer(
             means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
-            opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, shs_rest=shs_rest)
+            opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, shs_rest=shs_rest,
+            raw_parameters=raw is not None)
         return {
             rendered_image_key: rendered_image,
             "viewspace_points": screenspace_points,

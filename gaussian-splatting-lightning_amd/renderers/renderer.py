@@ -148,6 +148,50 @@ def model_sh_pair(pc):
     return pc.get_features, None
 
 
+_REFERENCE_ACTIVATIONS = {"scale_activation": "exp", "rotation_activation": "normalize", "opacity_activation": "sigmoid"}
+
+
+def _defined_by_reference_vanilla_model(fn, name: str) -> bool:
+    """`fn` is the function object `VanillaGaussianModel` of the reference defines (internal/models/vanilla_gaussian.py) — not an
+    override of a subclass, not the identity a pre-activated model installs on the instance."""
+    fn = getattr(fn, "__func__", fn)
+    module = getattr(fn, "__module__", "") or ""
+    return (module == "internal.models.vanilla_gaussian" or module.endswith(".internal.models.vanilla_gaussian")) and \
+        (getattr(fn, "__qualname__", "") or "") == "VanillaGaussianModel." + name
+
+
+def model_raw_parameters(pc):
+    """(raw scales, raw rotations, raw opacities) when the model's activated getters are exactly exp / F.normalize / sigmoid of
+    parameters it stores — then the rasterizer applies them inside its preprocess kernels (`raw_parameters=True`) and the step
+    loses the ten elementwise launches and the reduction that `get_scaling` / `get_rotation` / `get_opacity` and their autograd
+    backward cost (profiles/r05f_loop_sequence.txt: ~0.17 ms of a 1.48 ms step at 1 M Gaussians) — else None (any other model:
+    the getters are called, as the reference's renderer does, vanilla_renderer.py:62-77).  Two ways to qualify:
+      * the model DECLARES it: `fused_activations = {"scales": "exp", "rotations": "normalize", "opacities": "sigmoid"}` next to
+        `get_property(name)` returning the stored tensors (this package's models, bench_loop.RawGaussians);
+      * it is the reference's `VanillaGaussianModel` with its own activation methods and vanilla getters untouched
+        (vanilla_gaussian.py:345-358, 421-441) and not pre-activated; a subclass that overrides one of them (MipSplatting's
+        filtered scales, a glossy model's opacity, ...) does not qualify."""
+    if getattr(pc, "is_pre_activated", False):
+        return None
+    declared = getattr(pc, "fused_activations", None)
+    if declared is not None:
+        if dict(declared) != {"scales": "exp", "rotations": "normalize", "opacities": "sigmoid"}:
+            return None
+    else:
+        cls = type(pc)
+        for name in _REFERENCE_ACTIVATIONS:
+            if not _defined_by_reference_vanilla_model(getattr(pc, name, None), name):
+                return None
+        for name in ("get_scaling", "get_rotation", "get_opacity"):
+            prop = getattr(cls, name, None)
+            if not isinstance(prop, property) or not _defined_by_reference_vanilla_model(prop.fget, name):
+                return None
+    try:
+        return pc.get_property("scales"), pc.get_property("rotations"), pc.get_property("opacities")
+    except (KeyError, AttributeError):
+        return None
+
+
 _TILE_NOTE = set()
 
 

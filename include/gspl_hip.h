@@ -383,7 +383,7 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
  *    and call, except GSPL_BUF_LISTS_WORK which may be asked for twice (speculative emission with `capacity_hint` = a guess of
  *    the list length, e.g. the previous frame's x 1.25; 0 = no speculation).  No hipMalloc, no global state.
  *    out_color [3,H,W], radii [N] are caller-allocated outputs; `state` receives the pointers the backward needs and
- *    n_isects (the list length — feed it back as the next frame's hint).
+ *    n_isects (the list length — feed it back as the next frame's hint); its `flags` field is read BEFORE it is filled.
  * ---------------------------------------------------------------------------------------- */
 enum { GSPL_BUF_GEOMETRY = 1, GSPL_BUF_BINNING = 2, GSPL_BUF_IMAGE = 3, GSPL_BUF_LISTS_WORK = 4, GSPL_BUF_LISTS = 5 };
 typedef void* (*gspl_alloc_fn)(void* ctx, int tag, size_t bytes);      /* device memory, 256-byte aligned; NULL = failure */
@@ -393,7 +393,16 @@ typedef struct gspl_inria_state {
     float* means2d; float* depths; float* conics; float* colors; uint8_t* clamped; float* cov3d; float* sh_jac;      /* GSPL_BUF_GEOMETRY */
     float* alphas; float* final_Ts; int32_t* last_ids; int32_t* offsets;                               /* GSPL_BUF_IMAGE */
     int32_t* flatten_ids;                                                                              /* GSPL_BUF_LISTS */
+    float* opacities;      /* GSPL_BUF_GEOMETRY: the opacities compositing read — the caller's tensor, or with GSPL_INRIA_RAW_PARAMS
+                              sigmoid(raw) [N] as the forward stored it */
+    int flags;             /* IN (forward; the backward reads it back): 0 — a zeroed struct — or GSPL_INRIA_RAW_PARAMS */
 } gspl_inria_state;
+/* GSPL_INRIA_RAW_PARAMS: `scales`, `rotations`, `opacities` are the model's RAW parameters and the activations of the reference's
+ *    model — scale_activation = exp, rotation_activation = F.normalize (x / max(|x|, 1e-12)), opacity_activation = sigmoid
+ *    (internal/models/vanilla_gaussian.py:345-358, applied by `get_scaling` / `get_rotation` / `get_opacity` in
+ *    vanilla_renderer.py:62-77 before every render, differentiated by autograd after every backward) — run inside the preprocess
+ *    kernels; the backward returns the gradients of the raw parameters.  Needs scales + rotations (no cov3D_precomp). */
+enum { GSPL_INRIA_RAW_PARAMS = 1 };
 size_t gspl_rasterize_inria_geometry_bytes(int N);
 size_t gspl_rasterize_inria_image_bytes(int width, int height);
 int gspl_rasterize_inria_fwd(int N, int degree, int n_coeffs,

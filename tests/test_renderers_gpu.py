@@ -72,6 +72,96 @@ def test_hip_vanilla_renderer_contract_and_parity():
     assert "depth" in d and d["depth"].shape == (3, cam["height"], cam["width"]) and float(d["depth"].detach().max()) > 0
 
 
+class _RawModel(torch.nn.Module):
+    """Raw parameters behind exp / normalize / sigmoid getters, as the reference's VanillaGaussianModel keeps them
+    (internal/models/vanilla_gaussian.py:345-358, 421-441), declaring so (renderer.model_raw_parameters)."""
+    fused_activations = {"scales": "exp", "rotations": "normalize", "opacities": "sigmoid"}
+
+    def __init__(self, means, scales, quats, opac, shs, active_sh_degree=3, quat_norms=None):
+        super().__init__()
+        P = lambda t: torch.nn.Parameter(t.clone().contiguous())
+        o = opac.reshape(-1, 1).clamp(1e-6, 1 - 1e-6)
+        q = quats if quat_norms is None else quats * quat_norms.reshape(-1, 1)        # unnormalised, as an optimizer leaves them
+        self.g = {"means": P(means), "scales": P(torch.log(scales)), "rotations": P(q), "opacities": P(torch.log(o / (1 - o))),
+                  "shs_dc": P(shs[:, :1]), "shs_rest": P(shs[:, 1:])}
+        self.active_sh_degree, self.max_sh_degree, self.is_pre_activated = active_sh_degree, 3, False
+
+    def get_property(self, name): return self.g[name]
+    get_xyz = property(lambda s: s.g["means"])
+    get_scaling = property(lambda s: torch.exp(s.g["scales"]))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s.g["rotations"]))
+    get_opacity = property(lambda s: torch.sigmoid(s.g["opacities"]))
+    get_features = property(lambda s: torch.cat((s.g["shs_dc"], s.g["shs_rest"]), dim=1))
+    def get_shs_dc(self): return self.g["shs_dc"]
+    def get_shs_rest(self): return self.g["shs_rest"]
+
+
+@pytest.mark.parametrize("scaling_modifier", [1.0, 0.7])
+def test_hip_vanilla_renderer_raw_parameters_activations_inside_the_kernels(scaling_modifier):
+    """`fuse_activations` (GSPL_INRIA_RAW_PARAMS): the model's raw parameters go to the rasterizer, exp / normalize / sigmoid and
+    their derivatives run in the preprocess kernels.  Against (1) the fp64 oracle differentiated through the same activations in
+    torch fp64, (2) the same renderer with the getters left to torch."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.renderers import HipVanillaRenderer
+    params, cam, wimg, bg = _scene(seed=77)
+    g = torch.Generator().manual_seed(5)
+    norms = 0.25 + 3.0 * torch.rand(params[0].shape[0], generator=g)
+    names = ("means", "scales", "rotations", "opacities", "shs_dc", "shs_rest")
+    camera = FakeCamera(cam, DEV)
+
+    def run(fuse):
+        model = _RawModel(*[p.to(DEV) for p in params], quat_norms=norms.to(DEV))
+        out = HipVanillaRenderer(fuse_activations=fuse)(camera, model, bg.to(DEV), scaling_modifier=scaling_modifier)
+        out["viewspace_points"].retain_grad()
+        (out["render"] * wimg.to(DEV)).sum().backward()
+        return model, out
+
+    fused, out_f = run(True)
+    plain, out_p = run(False)
+    # (2) same kernels either way; the activations differ by at most an ulp or two (normalize: torch's reduction order)
+    assert torch.equal(out_f["radii"], out_p["radii"])
+    assert_pixels_close(out_f["render"].detach().cpu().numpy(), out_p["render"].detach().cpu().numpy(), tol=2e-6, name="fused vs torch activations")
+    for n in names:
+        assert_close_scaled(fused.g[n].grad.cpu().numpy(), plain.g[n].grad.cpu().numpy(), 1e-4, "fused vs torch: " + n, frac_ok=0.999, rel_all=0.5)
+    assert_close_scaled(out_f["viewspace_points"].grad.cpu().numpy(), out_p["viewspace_points"].grad.cpu().numpy(), 1e-4, "viewspace", 0.999, rel_all=0.5)
+
+    # (1) the oracle through torch fp64 activations
+    W, H = cam["width"], cam["height"]
+    raw64 = {n: fused.g[n].detach().cpu().double().requires_grad_(True) for n in names}
+    r = O.render_inria(raw64["means"], torch.exp(raw64["scales"]), torch.nn.functional.normalize(raw64["rotations"]),
+                       torch.sigmoid(raw64["opacities"]).reshape(-1), torch.cat((raw64["shs_dc"], raw64["shs_rest"]), dim=1), 3,
+                       cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
+                       cam["tanfovx"], cam["tanfovy"], W, H, bg.double(), scale_modifier=scaling_modifier)
+    (r["render"] * wimg.double()).sum().backward()
+    assert_pixels_close(out_f["render"].detach().cpu().numpy(), r["render"].detach().numpy())
+    # (a radius is a ceil of an fp32 expression of fp32 exp(raw): one in a few thousand may sit on an integer within an ulp)
+    assert float((out_f["radii"].cpu() == torch.as_tensor(r["radii"]).to(torch.int32)).float().mean()) >= 0.999
+    for n in names:
+        assert_close_scaled(fused.g[n].grad.cpu().numpy(), raw64[n].grad.numpy(), 1e-4, "vs oracle: " + n, frac_ok=0.995, rel_all=0.5)
+
+
+def test_raw_parameters_need_a_zeroed_state_and_the_scale_rotation_pair():
+    import ctypes
+    import gspl_amd  # noqa: F401
+    from gspl_amd import _lib as L, ops
+    params, cam, wimg, bg = _scene(n=500)
+    m, s, q, o, sh = [p.to(DEV) for p in params]
+    settings = ops.GaussianRasterizationSettings(cam["height"], cam["width"], cam["tanfovx"], cam["tanfovy"], bg.to(DEV), 1.0,
+                                                 cam["world_to_camera"].to(DEV), cam["full_projection"].to(DEV), 3, cam["camera_center"].to(DEV))
+    cov = torch.zeros(500, 6, device=DEV)
+    with pytest.raises(Exception, match="scale/rotation"):
+        ops.GaussianRasterizer(settings)(m, torch.zeros_like(m), o, shs=sh, cov3D_precomp=cov, raw_parameters=True)
+    # the C boundary itself: unknown flag bits are refused before anything is launched
+    state = L.InriaState()
+    state.flags = 6
+    out, radii = torch.empty(3, cam["height"], cam["width"], device=DEV), torch.empty(500, dtype=torch.int32, device=DEV)
+    cb = L.ALLOC_FN(lambda ctx, tag, n: 0)
+    with pytest.raises(Exception, match="flags"):
+        L.call("gspl_rasterize_inria_fwd", 500, 3, 16, L.ptr(m), L.ptr(s), L.ptr(q), None, L.ptr(sh), None, None, L.ptr(o),
+               L.ptr(settings.viewmatrix), L.ptr(settings.projmatrix), L.ptr(settings.campos), L.ptr(settings.bg), cam["width"], cam["height"],
+               float(cam["tanfovx"]), float(cam["tanfovy"]), 1.0, cb, None, 0, L.ptr(out), L.ptr(radii), ctypes.byref(state), L.stream(), None)
+
+
 def test_config1_lego_proxy_800x800_100k_vanilla_renderer_vs_oracle():
     """BASELINE.json configs[0]/[1] proxy (S-800-100k: 100 000 Gaussians of the Blender init box at 800x800, SH degree 3,
     vanilla renderer) end to end against the fp64 oracle: render within 1e-5, every parameter gradient within 1e-4."""

@@ -175,14 +175,19 @@ def test_reference_consumer_code_drives_the_plugin_and_matches_the_restatement_c
     from fakes import FakeCamera
 
     oracle_render = OracleVanillaRenderer()
+    seen_raw = []
 
     class OracleRasterizer:          # stands in for ops.GaussianRasterizer (the one native call of the plugin)
         def __init__(self, raster_settings):
             self.s = raster_settings
 
         def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                     shs_rest=None):
+                     shs_rest=None, raw_parameters=False):
             s = self.s
+            seen_raw.append(bool(raw_parameters))
+            if raw_parameters:            # the real VanillaGaussianModel qualifies (renderer.model_raw_parameters): the plugin hands over
+                # its raw parameters and the rasterizer owns the three activations
+                opacities, scales, rotations = torch.sigmoid(opacities), torch.exp(scales), torch.nn.functional.normalize(rotations)
             if shs_rest is not None:      # the plugin hands over the model's two SH parameters as they are stored
                 shs = torch.cat((shs, shs_rest), dim=1)
             r = O.render_inria(means3D, scales, rotations, opacities, shs, s.sh_degree, s.viewmatrix, s.projmatrix, s.campos,
@@ -223,6 +228,7 @@ def test_reference_consumer_code_drives_the_plugin_and_matches_the_restatement_c
                            on_step=_seeded_steps(None), controller_is_reference=True, pl_module=module)
     finally:
         ops.GaussianRasterizer = saved
+    assert seen_raw and all(seen_raw)          # the reference's own model was recognised in every step
 
     # ---- the restatement on the same inputs
     model2, opts2, ctrl2 = _restated_setup(init, torch.device("cpu"), opacity_reset_interval=60)
