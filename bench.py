@@ -99,6 +99,7 @@ def parse():
                         "behind exp / sigmoid / normalize getters, the restated density controller densifying every 100 steps from the "
                         "workload's Gaussians, opacity reset, SH-degree raise, the renderer plugin) and report `reference_shaped_loop`")
     p.add_argument("--loop-steps", type=int, default=450)
+    p.add_argument("--no-loop-comparison", action="store_true", help="skip the second run of the reference-shaped loop (activations left to torch)")
     p.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU baseline leg and print it (no GPU needed)")
     p.add_argument("--stage-times", action="store_true",
                    help="time EVERY C-ABI call with events (stages_ms); default: only the compositing kernels the roofline needs")
@@ -904,9 +905,10 @@ def main():
             try:
                 line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps)
                 # the same loop with the activations left to torch (what the reference's renderer does with the same model)
-                other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False)
-                line["reference_shaped_loop"]["with_torch_activations"] = {
-                    k: other[k] for k in ("activations", "images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end")}
+                if not args.no_loop_comparison:
+                    other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False)
+                    line["reference_shaped_loop"]["with_torch_activations"] = {
+                        k: other[k] for k in ("activations", "images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end")}
             except Exception as e:  # an extra: it must never take the bench line down
                 line["reference_shaped_loop"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

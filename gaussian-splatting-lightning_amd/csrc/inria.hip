@@ -98,7 +98,7 @@ __device__ __forceinline__ bool inria_geom(const InriaCam& cam, const float p[3]
 // The model's activations, for the RAW-parameter form of the fused call (GSPL_INRIA_RAW_PARAMS): what the reference's model applies
 // in torch before every render and differentiates after every backward — `scale_activation` = exp, `rotation_activation` =
 // F.normalize (x / max(|x|, 1e-12)), `opacity_activation` = sigmoid (internal/models/vanilla_gaussian.py:345-358; ten elementwise
-// launches and a reduction per step at 1 M Gaussians, profiles/r05f_loop_sequence.txt) — evaluated where the parameters are read.
+// launches and a reduction per step at 1 M Gaussians, profiles/r05f_loop_sequence_torch_activations.txt) — evaluated where the parameters are read.
 // expf / IEEE division: the arithmetic of torch.exp / torch.sigmoid.
 __device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float act_quat_norm(const float q[4]) { return fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f); }

@@ -164,7 +164,7 @@ def model_raw_parameters(pc):
     """(raw scales, raw rotations, raw opacities) when the model's activated getters are exactly exp / F.normalize / sigmoid of
     parameters it stores — then the rasterizer applies them inside its preprocess kernels (`raw_parameters=True`) and the step
     loses the ten elementwise launches and the reduction that `get_scaling` / `get_rotation` / `get_opacity` and their autograd
-    backward cost (profiles/r05f_loop_sequence.txt: ~0.17 ms of a 1.48 ms step at 1 M Gaussians) — else None (any other model:
+    backward cost (profiles/r05f_loop_sequence_torch_activations.txt: ~0.17 ms of a 1.48 ms step at 1 M Gaussians) — else None (any other model:
     the getters are called, as the reference's renderer does, vanilla_renderer.py:62-77).  Two ways to qualify:
       * the model DECLARES it: `fused_activations = {"scales": "exp", "rotations": "normalize", "opacities": "sigmoid"}` next to
         `get_property(name)` returning the stored tensors (this package's models, bench_loop.RawGaussians);
