@@ -632,7 +632,12 @@ def main():
 
     PROFILE_PERIOD = 1 if args.stage_times else 4
 
-    def timed_region(full_step, steps, warmup):
+    def timed_region(full_step, steps, warmup, instrumented=False):
+        # instrumented=False — the contract's timed region: NO per-step events (an event record idles the stream for ~6-7 us:
+        # profiles/r05d_sequence.txt, the three gaps at the step's marks; three per step were 1.6 % of the step); only the GRADED
+        # kernel's launch is bracketed, every fourth step, for `roofline` ("HIP events over the timed region").
+        # instrumented=True — the pass that follows it, same steps: three events per step (fwd_ms / bwd_ms / step_ms percentiles)
+        # and the forward compositing launch bracketed too.
         # Host hygiene: a full (generation-2) pass of Python's cyclic GC walks every object torch has imported — 30-40 ms during
         # which no kernel is launched, once every ~130 steps.  Freezing what exists once the first warm-up steps have created their
         # lazily-built objects keeps later collections to the objects of the steps themselves.  The collection sits INSIDE the
@@ -655,12 +660,16 @@ def main():
             import ctypes
             ctypes.CDLL(None).fflush(None)
         torch.cuda.synchronize()
-        step.state["marks"] = []
+        if instrumented:
+            step.state["marks"] = []
+        else:
+            step.state.pop("marks", None)
         ops.SPECULATION.update(frames=0, cold=0, misses=0)
         # the roofline needs the launch duration of the graded kernel from HIP events on its stream; an event pair idles the stream
-        # for ~6 us on either side of the launch, so only every fourth compositing launch of the timed region is bracketed
-        _lib.profile_start(None if args.stage_times else ("gspl_composite_bwd_packed", "gspl_composite_bwd", "gspl_composite_fwd"),
-                           period=PROFILE_PERIOD)
+        # for ~6 us on either side of the launch, so only every fourth launch is bracketed
+        graded = ("gspl_composite_bwd_packed", "gspl_composite_bwd")
+        _lib.profile_start(None if (args.stage_times and instrumented) else (graded + ("gspl_composite_fwd",) if instrumented else graded),
+                           period=PROFILE_PERIOD if instrumented else 4)
         mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
         t0 = time.perf_counter()
         for k in range(steps):
@@ -672,7 +681,7 @@ def main():
         # hipMalloc calls of torch's caching allocator inside the timed region (a new list capacity that no cached block holds)
         step.state["device_mallocs"] = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
         prof = _lib.profile_stop()
-        marks = step.state.pop("marks")
+        marks = step.state.pop("marks", [])
         if dist is not None:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -723,11 +732,16 @@ def main():
         for t in tensors:
             t.grad = None
     ops.LAST_RASTER = None
-    elapsed, prof, marks = timed_region(make_full_step(optimizer, args.optimizer), args.steps, args.warmup)
+    the_step = make_full_step(optimizer, args.optimizer)
+    elapsed, prof_graded, _ = timed_region(the_step, args.steps, args.warmup)
     device_mallocs = step.state.get("device_mallocs")
+    speculation = dict(ops.SPECULATION)
+    # the instrumented pass: the same steps again, with the per-step events
+    elapsed_instrumented, prof, marks = timed_region(the_step, args.steps, 0, instrumented=True)
+    for k_, v_ in prof_graded.items():          # the graded kernel's durations are the timed region's
+        prof[k_] = v_
     phase_fwd = sum(marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks), 3)) / args.steps
     phase_bwd = sum(marks[i + 1].elapsed_time(marks[i + 2]) for i in range(0, len(marks), 3)) / args.steps
-    speculation = dict(ops.SPECULATION)
     # device-side span of every step of the timed region: start of step i to start of step i + 1
     starts = marks[0::3]
     spans = sorted(starts[i].elapsed_time(starts[i + 1]) for i in range(len(starts) - 1))
@@ -740,7 +754,7 @@ def main():
     renderer_only = None
     if world == 1 and optimizer is not None and not args.no_renderer_only:
         # second timed region of the same run: the step without a parameter update (round 1's `value`)
-        e2, _, m2 = timed_region(make_full_step(None, "none"), args.steps, 2)
+        e2, _, m2 = timed_region(make_full_step(None, "none"), args.steps, 2, instrumented=True)
         renderer_only = {"images_per_s": round(args.steps / e2, 3), "ms_per_step": round(e2 / args.steps * 1e3, 4),
                          "fwd_ms": round(sum(m2[i].elapsed_time(m2[i + 1]) for i in range(0, len(m2), 3)) / args.steps, 4),
                          "bwd_ms": round(sum(m2[i + 1].elapsed_time(m2[i + 2]) for i in range(0, len(m2), 3)) / args.steps, 4)}
@@ -795,7 +809,8 @@ def main():
         mean = lambda name: (sum(prof[name]) / len(prof[name])) if prof.get(name) else None
         # per-STEP totals (an entry point called twice per step, e.g. the two phases of the Inria preprocess, counts twice)
         # (with sampled timing: mean of the timed calls x calls per step)
-        stages = {k: round(sum(v) / len(v) * max(1, round(len(v) * PROFILE_PERIOD / args.steps)), 4) for k, v in prof.items() if v}
+        period_of = lambda k: 4 if (k in prof_graded) else PROFILE_PERIOD
+        stages = {k: round(sum(v) / len(v) * max(1, round(len(v) * period_of(k) / args.steps)), 4) for k, v in prof.items() if v}
         P = W * H
         bwd_ms = mean("gspl_composite_bwd_packed") or mean("gspl_composite_bwd")
         avg = lambda key: (sum(e[key] for e in per_cam) / len(per_cam)) if per_cam and key in per_cam[0] else None
@@ -889,6 +904,10 @@ def main():
             # device time between the events at the start of the step, before loss.backward() and after it
             "fwd_ms": round(phase_fwd, 4),
             "bwd_ms": round(phase_bwd, 4),
+            # fwd_ms / bwd_ms / step_ms / stages_ms.gspl_composite_fwd: from the instrumented pass right after the timed region (same
+            # steps + three events per step, each a ~6-7 us idle stream); the timed region itself carries no per-step events, only
+            # the graded kernel's launch is bracketed every fourth step (roofline.avg_ms)
+            "instrumented_pass": {"ms_per_step": round(elapsed_instrumented / args.steps * 1e3, 4), "events_per_step": 3},
             "roofline": roofline,
             "stage_rooflines": stage_rooflines,
             # device-side span of a step (start to start) over the timed region

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
                                          _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_profile_enable": (c_int, [c_int]),
+    "gspl_profile_enable2": (c_int, [c_int, c_int]),
     "gspl_profile_read": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),
     "gspl_rasterize_inria_geometry_bytes": (c_size_t, [c_int]),
     "gspl_rasterize_inria_image_bytes": (c_size_t, [c_int, c_int]),
@@ -196,7 +197,8 @@ def profile_start(names=None, period: int = 1):
     _PROFILE = []
     _PROFILE_NAMES = None if names is None else frozenset(names)
     _PROFILE_PERIOD, _PROFILE_SEEN = max(int(period), 1), {}
-    lib().gspl_profile_enable(_PROFILE_PERIOD)
+    on = lambda name: _PROFILE_PERIOD if (_PROFILE_NAMES is None or name in _PROFILE_NAMES) else 0
+    lib().gspl_profile_enable2(on("gspl_composite_fwd"), on("gspl_composite_bwd_packed"))
 
 
 def profile_stop():

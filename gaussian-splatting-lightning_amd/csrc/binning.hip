@@ -535,12 +535,13 @@ extern "C" size_t gspl_bin_workspace_bytes(int N, int64_t n_isects) {
     return n_isects > 0 ? w.total : w.total_count;
 }
 
-extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
+namespace gspl {
+// gspl_bin_count; ticket != 0: host_counts has a third word that receives the ticket AFTER the two numbers (the caller polls it)
+int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
                               const float* conics, const float* opacities,
                               int tile_size, int tile_w, int tile_h,
                               int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
-                              void* workspace, size_t workspace_bytes, void* stream) {
-    using namespace gspl;
+                              void* workspace, size_t workspace_bytes, void* stream, unsigned long long ticket) {
     if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_count: bad sizes");
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_count: bad mode");
     if (N == 0) return GSPL_OK;
@@ -579,7 +580,18 @@ extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32
     if (rc != GSPL_OK) return rc;
     // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte read-back
     // gives the host both numbers
-    return scan_gathered_counts(nullptr, (const int32_t*)kbuf[dp.passes & 1], cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s, host_counts);
+    return scan_gathered_counts(nullptr, (const int32_t*)kbuf[dp.passes & 1], cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s, host_counts,
+                                host_counts ? ticket : 0ull);
+}
+}  // namespace gspl
+
+extern "C" int gspl_bin_count(int N, int mode, const float* means2d, const int32_t* radii, const float* depths,
+                              const float* conics, const float* opacities,
+                              int tile_size, int tile_w, int tile_h,
+                              int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return gspl::bin_count_ticket(N, mode, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, order, cum_tiles, big_list, spans, host_counts,
+                                  workspace, workspace_bytes, stream, 0ull);
 }
 
 // Emission half of gspl_bin_emit_sort.  `capacity` = records the workspace (gspl_bin_workspace_bytes(N, capacity)) has

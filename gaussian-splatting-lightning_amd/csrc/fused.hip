@@ -58,12 +58,37 @@ static int64_t* pinned_words() {
     return p;
 }
 
+// The host's wait for the frame's one number (the list length): it POLLS the pinned word the scan kernel stores its ticket into.
+// An event for it — hipEventRecord between the scan and the emission kernels — costs the stream a ~6 us bubble every frame.
+// Bounded: every ~65 k polls the stream is queried; a stream that has drained (or failed) without the ticket arriving ends the wait.
+static bool wait_for_ticket(const int64_t* host, unsigned long long ticket, hipStream_t s) {
+    const volatile unsigned long long* flag = (const volatile unsigned long long*)(host + 2);
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n((const unsigned long long*)flag, __ATOMIC_ACQUIRE) == ticket) return true;
+        __builtin_ia32_pause();
+        if ((spins & 0xffffu) == 0u) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return __atomic_load_n((const unsigned long long*)flag, __ATOMIC_ACQUIRE) == ticket;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); return false; }
+        }
+    }
+}
+static unsigned long long next_ticket() {
+    static thread_local unsigned long long t = 0ull;
+    return ++t;
+}
+
 // three events per host thread (geometry done, colours done, count copied), created once
+// (Measured, round 4: hipEventReleaseToDevice / hipEventDisableSystemFence on geo and col do not shorten the ~7 us the stream idles
+// at an event record — it is the marker packet itself, not its fence.)
+#ifndef GSPL_EVENT_FLAGS
+#define GSPL_EVENT_FLAGS hipEventDisableTiming
+#endif
 struct FrameEvents { hipEvent_t geo = nullptr, col = nullptr, cnt = nullptr; bool ok = false; };
 static FrameEvents& frame_events() {
     static thread_local FrameEvents ev;
     if (!ev.ok)
-        ev.ok = hipEventCreateWithFlags(&ev.geo, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev.col, hipEventDisableTiming) == hipSuccess &&
+        ev.ok = hipEventCreateWithFlags(&ev.geo, GSPL_EVENT_FLAGS) == hipSuccess && hipEventCreateWithFlags(&ev.col, GSPL_EVENT_FLAGS) == hipSuccess &&
                 hipEventCreateWithFlags(&ev.cnt, hipEventDisableTiming) == hipSuccess;
     return ev;
 }
@@ -88,15 +113,15 @@ extern "C" void* gspl_low_priority_stream(void) {
 // Optional timing of the two compositing launches INSIDE the fused calls (bench.py's roofline: the launches cannot be bracketed
 // from Python any more).  Events are recorded on the launch stream; durations are read after a synchronisation.
 struct ProfSlot { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
-static int g_prof_period = 0;   // 0: off; k: every k-th launch is timed (an event pair costs ~6 us of stream idle time per side)
+static int g_prof_period[2] = {0, 0};   // per direction; 0: off; k: every k-th launch is timed (an event pair costs ~6 us of stream idle time per side)
 static unsigned g_prof_seen[2] = {0u, 0u};
 static std::mutex g_prof_mu;
 static ProfSlot g_prof[2];      // 0: composite forward, 1: composite backward
 struct ProfScope {
     int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     ProfScope(int w, hipStream_t st) : which(w), s(st) {
-        if (g_prof_period <= 0) return;
-        if ((g_prof_seen[w]++ % (unsigned)g_prof_period) != 0u) return;
+        if (g_prof_period[w] <= 0) return;
+        if ((g_prof_seen[w]++ % (unsigned)g_prof_period[w]) != 0u) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
         (void)hipEventRecord(a, s);
     }
@@ -110,9 +135,10 @@ struct ProfScope {
 
 }  // namespace gspl
 
-extern "C" int gspl_profile_enable(int period) {
+extern "C" int gspl_profile_enable2(int period_fwd, int period_bwd) {
     std::lock_guard<std::mutex> lk(gspl::g_prof_mu);
-    gspl::g_prof_period = period > 0 ? period : 0;
+    gspl::g_prof_period[0] = period_fwd > 0 ? period_fwd : 0;
+    gspl::g_prof_period[1] = period_bwd > 0 ? period_bwd : 0;
     gspl::g_prof_seen[0] = gspl::g_prof_seen[1] = 0u;
     for (auto& slot : gspl::g_prof) {
         for (auto& e : slot.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -120,6 +146,8 @@ extern "C" int gspl_profile_enable(int period) {
     }
     return GSPL_OK;
 }
+
+extern "C" int gspl_profile_enable(int period) { return gspl_profile_enable2(period, period); }
 
 // which: 0 = composite forward, 1 = composite backward launches of the fused calls since gspl_profile_enable(1).
 // Synchronises with the recorded events; returns the number of launches and their total duration.
@@ -222,38 +250,39 @@ extern "C" int gspl_rasterize_inria_fwd(
         if (rc == GSPL_OK && ev_col) (void)hipEventRecord(ev_col, cs);
         if (rc != GSPL_OK) return rc;
         {
-            rc = gspl_bin_count(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
-                                spans, host, ws1, ws1_bytes, s);      // the scan kernel stores the two numbers into `host` itself
+            const unsigned long long ticket = next_ticket();
+            rc = bin_count_ticket(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
+                                  spans, host, ws1, ws1_bytes, s, ticket);      // the scan kernel stores the two numbers, then the ticket, into `host`
             if (rc != GSPL_OK) return rc;
-            hipEvent_t ev_cnt = fe.cnt;
-            (void)hipEventRecord(ev_cnt, s);
+            auto wait_count = [&]() -> bool { return wait_for_ticket(host, ticket, s); };
             // speculative emission with the caller's guess of the list length, while the host waits for the real one
             if (ws2) {
                 rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
                                    capacity, ws2, ws2_bytes, s);
-                if (rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return rc; }
+                if (rc != GSPL_OK) { (void)wait_count(); return rc; }
             }
             if (ws2) {
                 // The host does not wait for the list length: the sort reads it on the device (the grid is sized by `capacity`), the
                 // compositing kernel finds the end of the last list in offsets[n_tiles].  The number is looked at AFTER everything is
                 // enqueued — by then the scan has long finished — and only a guess that turns out too low costs a second round.
                 st->flatten_ids = (int32_t*)alloc(alloc_ctx, GSPL_BUF_LISTS, 4 * (size_t)capacity);
-                if (!st->flatten_ids) { (void)hipEventSynchronize(ev_cnt); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+                if (!st->flatten_ids) { (void)wait_count(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
                 rc = gspl_bin_sort_device_count(N, tile_w, tile_h, cum + (N - 1), capacity, st->flatten_ids, st->offsets, ws2, ws2_bytes, s);
-                if (rc != GSPL_OK) { (void)hipEventSynchronize(ev_cnt); return rc; }
+                if (rc != GSPL_OK) { (void)wait_count(); return rc; }
                 if (ev_col) (void)hipStreamWaitEvent(s, ev_col, 0);      // colours are ready before compositing reads them
                 {
                     ProfScope prof(0, s);
                     rc = gspl_composite_fwd(N, -1, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height,
                                             tile, tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
                 }
-                (void)hipEventSynchronize(ev_cnt);
+                const bool arrived = wait_count();
                 n_isects = host[0];
                 if (rc != GSPL_OK) return rc;
+                if (!arrived) return check_hip(hipStreamSynchronize(s), "rasterize_inria_fwd: the list length never arrived") ? GSPL_ERR_LAUNCH : fail_arg("rasterize_inria_fwd: the list length never arrived");
                 if (n_isects <= capacity) { st->n_isects = n_isects; return GSPL_OK; }
                 ws2 = nullptr;                                  // too low a guess: the frame is redone below with the real length
             } else {
-                (void)hipEventSynchronize(ev_cnt);
+                if (!wait_count()) return check_hip(hipStreamSynchronize(s), "rasterize_inria_fwd: the list length never arrived") ? GSPL_ERR_LAUNCH : fail_arg("rasterize_inria_fwd: the list length never arrived");
                 n_isects = host[0];
             }
             if (n_isects > (int64_t)((1u << 30) - 1u)) {

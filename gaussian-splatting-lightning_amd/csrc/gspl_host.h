@@ -45,6 +45,10 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs, const float* dirs, con
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream,
                   const float* jac /* nullable: the forward's Jacobian; v_dirs then needs no coefficient read */);
+// binning.hip -> fused.hip: gspl_bin_count whose scan stores `ticket` into host_counts[2] after the two numbers
+int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii, const float* depths, const float* conics, const float* opacities,
+                     int tile_size, int tile_w, int tile_h, int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
+                     void* workspace, size_t workspace_bytes, void* stream, unsigned long long ticket);
 // inria.hip -> fused.hip: the geometry phase and the preprocess backward with the model's RAW parameters (GSPL_INRIA_RAW_PARAMS)
 int inria_geometry_launch(int N, const float* means, const float* scales, const float* quats, const float* cov3d_precomp,
                           const float* viewmatrix, const float* projmatrix, int width, int height, int tile_size,

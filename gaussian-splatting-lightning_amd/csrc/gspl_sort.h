@@ -84,6 +84,7 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* worksp
 static constexpr int SCAN_TILE = 2048;
 size_t scan_workspace_bytes(size_t n);
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* workspace, int32_t* tagged_list, void* stream,
-                         int64_t* host_words = nullptr);
+                         int64_t* host_words = nullptr /* pinned: [0] total, [1] tagged count, and with a ticket [2] = ticket, stored last */,
+                         unsigned long long ticket = 0);
 
 }  // namespace gspl

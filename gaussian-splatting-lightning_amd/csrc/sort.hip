@@ -609,7 +609,8 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(unsigned long long* __r
 
 __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
                                                                  int64_t* __restrict__ cum, uint32_t n, const unsigned long long* __restrict__ bases,
-                                                                 int32_t* __restrict__ tagged_list, int64_t* __restrict__ host_words) {
+                                                                 int32_t* __restrict__ tagged_list, int64_t* __restrict__ host_words,
+                                                                 unsigned long long ticket) {
     __shared__ unsigned long long s_wave[RS_WAVES];
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const uint32_t first = blockIdx.x * (uint32_t)SCAN_TILE + (uint32_t)t * SC_IPT;       // SC_IPT consecutive items per thread
@@ -639,6 +640,9 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
                 host_words[0] = (int64_t)(run & ((1ull << 40) - 1ull));
                 host_words[1] = (int64_t)(run >> 40);
                 __threadfence_system();
+                // ticket != 0: the host POLLS host_words[2] for it instead of waiting for an event (an event record between two
+                // kernels of one stream is a ~6 us bubble on this part: profiles/r05d_sequence.txt, the gaps in front of radix_zero)
+                if (ticket) __hip_atomic_store((unsigned long long*)host_words + 2, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -650,14 +654,14 @@ size_t scan_workspace_bytes(size_t n) {
 }
 
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* workspace, int32_t* tagged_list, void* stream,
-                         int64_t* host_words) {
+                         int64_t* host_words, unsigned long long ticket) {
     if (n == 0) return GSPL_OK;
     const unsigned blocks = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
     unsigned long long* sums = (unsigned long long*)workspace;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(scan_gather_sums_kernel, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, (uint32_t)n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, blocks);
-    hipLaunchKernelGGL(scan_gather_kernel, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, cum, (uint32_t)n, (const unsigned long long*)sums, tagged_list, host_words);
+    hipLaunchKernelGGL(scan_gather_kernel, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, cum, (uint32_t)n, (const unsigned long long*)sums, tagged_list, host_words, ticket);
     return check_launch("scan_gathered_counts");
 }
 

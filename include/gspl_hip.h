@@ -437,6 +437,7 @@ void* gspl_low_priority_stream(void);
  * either side of the launch) and drops what was recorded, gspl_profile_read synchronises and returns the count and the summed
  * duration of the timed forward (which = 0) or backward (1) compositing launches since then; enable(0) stops. */
 int gspl_profile_enable(int period);
+int gspl_profile_enable2(int period_fwd, int period_bwd);      /* the two directions apart (0 = that direction is not timed) */
 int gspl_profile_read(int which, int* count, float* total_ms);
 
 /* ------------------------------------------------------------------------------------------

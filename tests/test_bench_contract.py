@@ -49,12 +49,19 @@ def test_single_gpu_line():
               "inria_preprocess_bwd_with_sh_bwd", "adam"):
         assert sr[k]["ms"] > 0 and sr[k]["bytes"] > 0 and abs(sr[k]["frac"] - sr[k]["GBps"] / 8000.0) <= 2e-4, k
     assert roof["traffic"] is None or "same ABI and kernel sources" in roof["traffic_source"]      # stale PMC files are refused
+    # round 4: the timed region carries no per-step events; fwd_ms / bwd_ms / step_ms come from the instrumented pass after it
+    assert line["instrumented_pass"]["events_per_step"] == 3 and line["instrumented_pass"]["ms_per_step"] > 0
+    assert line["fwd_ms"] > 0 and line["bwd_ms"] > 0 and line["step_ms"]["p50"] > 0 and line["roofline"]["avg_ms"] > 0
     # round 4: the reference-shaped loop (raw parameters, density controller, N changes) rides in the same line
     loop = line["reference_shaped_loop"]
     assert "failed" not in loop, loop
     assert loop["images_per_s_densifying"] > 0 and loop["steps"] == 450 and loop["sh_degree_end"] == 3
     assert sum(1 for e in loop["events"] if "n_after" in e) >= 3 and any(e.get("opacity_reset") for e in loop["events"])
     assert loop["speculation"]["frames"] == 450 and loop["loss_first_last"][1] < loop["loss_first_last"][0]
+    # the plugin's default for a raw-parameter model (activations inside the kernels) beside the torch-getter run of the same loop
+    other = loop["with_torch_activations"]
+    assert "inside the preprocess kernels" in loop["activations"] and "torch getters" in other["activations"]
+    assert loop["ms_per_step_between_events_p50"] < other["ms_per_step_between_events_p50"]
 
 
 @pytest.mark.gpu
