@@ -119,7 +119,7 @@ def _mark():
     return e
 
 
-def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True):
+def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prewarm=False):
     """`--loop reference-shaped` (images/s of the Lightning loop, not of a static-N step on activated leaves): the
     consumer side restated in bench_loop.py drives `HipVanillaRenderer` through what `GaussianSplatting.training_step` does
     (internal/gaussian_splatting.py:329-397) — raw parameters behind exp / normalize / sigmoid getters (fuse_activations: evaluated
@@ -132,24 +132,34 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True):
     from gspl_amd.optimizers import FusedAdam
     from gspl_amd.renderers import HipVanillaRenderer
     W, H = wl["width"], wl["height"]
-    torch.cuda.empty_cache()          # every run of the loop starts with a cold caching allocator (the event steps' device mallocs are part of it)
-    clean = synthetic.scene(wl["n"], seed=42)
     cams = [synthetic.CameraObject(c, dev, idx=i) for i, c in enumerate(cam_dicts)]
     renderer = HipVanillaRenderer(fuse_activations=fuse_activations)
     bg = torch.zeros(3, device=dev)
-    # targets: the clean scene from every camera (degree 3); the trained model starts from a perturbed copy at degree 1
-    truth = synthetic.ModelObject(*[t.to(dev) for t in clean], active_sh_degree=3)
-    with torch.no_grad():
-        targets = [renderer(c, truth, bg)["render"].clone() for c in cams]
-    del truth
-    model = BL.RawGaussians(*[t.to(dev) for t in BL.perturbed(clean)], active_sh_degree=1, max_sh_degree=3)
-    optimizers = model.make_optimizers(1.0, FusedAdam)
+    loss_fn = lambda img, gt: ops.photometric_loss(img, gt, 0.2)
+
+    def setup(n, from_iter, interval, reset):
+        clean = synthetic.scene(n, seed=42)
+        # targets: the clean scene from every camera (degree 3); the trained model starts from a perturbed copy at degree 1
+        truth = synthetic.ModelObject(*[t.to(dev) for t in clean], active_sh_degree=3)
+        with torch.no_grad():
+            targets = [renderer(c, truth, bg)["render"].clone() for c in cams]
+        model = BL.RawGaussians(*[t.to(dev) for t in BL.perturbed(clean)], active_sh_degree=1, max_sh_degree=3)
+        controller = BL.DensityController(model.n_gaussians, dev, cameras_extent=2.6, densify_from_iter=from_iter, densification_interval=interval,
+                                          opacity_reset_interval=reset)
+        return targets, model, model.make_optimizers(1.0, FusedAdam), controller
+
+    if prewarm:
+        # the torch kernels of a densification event (mask gathers, cats, multinomial-free split sampling ...) are loaded on first use
+        # — hundreds of milliseconds once per process, which belong to neither run of the loop: a 20 k-Gaussian model goes through
+        # two events and an opacity reset first, untimed
+        t_, m_, o_, c_ = setup(20_000, 40, 40, 80)
+        BL.run(renderer, m_, c_, o_, cams, t_, 90, bg, loss_fn, sh_degree_up_interval=45)
+        del t_, m_, o_, c_
+    torch.cuda.empty_cache()          # every run of the loop starts with a cold caching allocator (the event steps' device mallocs are part of it)
     # the reference's defaults (vanilla_density_controller.py:14-40) except the schedule, compressed so that a few hundred steps see
     # every kind of event: densification from step 100 every 100 steps (reference: from 500), opacity reset at step 300 (3000),
     # SH degree up every 150 steps (1000)
-    controller = BL.DensityController(model.n_gaussians, dev, cameras_extent=2.6, densify_from_iter=100, densification_interval=100,
-                                      opacity_reset_interval=300)
-    loss_fn = lambda img, gt: ops.photometric_loss(img, gt, 0.2)
+    targets, model, optimizers, controller = setup(wl["n"], 100, 100, 300)
     frames0, misses0, cold0 = (ops.SPECULATION[k] for k in ("frames", "misses", "cold"))
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     res = BL.run(renderer, model, controller, optimizers, cams, targets, steps, bg, loss_fn, sh_degree_up_interval=150)
@@ -922,7 +932,7 @@ def main():
         }
         if world == 1 and mode == "single" and args.loop == "reference-shaped" and api == "vanilla" and SH_DEGREE == 3:
             try:
-                line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps)
+                line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, prewarm=True)
                 # the same loop with the activations left to torch (what the reference's renderer does with the same model)
                 if not args.no_loop_comparison:
                     other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False)
