@@ -75,8 +75,10 @@ class OracleRasterizer:
         self.s = raster_settings
 
     def __call__(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                 shs_rest=None):
+                 shs_rest=None, raw_parameters=False):
         s = self.s
+        if raw_parameters:      # the reference's VanillaGaussianModel qualifies (renderer.model_raw_parameters): the rasterizer owns the activations
+            opacities, scales, rotations = torch.sigmoid(opacities), torch.exp(scales), torch.nn.functional.normalize(rotations)
         if shs_rest is not None:
             shs = torch.cat((shs, shs_rest), dim=1)
         r = O.render_inria(means3D, scales, rotations, opacities, shs, s.sh_degree, s.viewmatrix, s.projmatrix, s.campos,
