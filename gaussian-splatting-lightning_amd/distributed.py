@@ -241,26 +241,63 @@ class PeerExchange:
         self.close()
         self.cap_total, self.cap_rank = int(total * 1.5) + 1024, int(biggest * 1.5) + 1024
         self._layout = lay = self._plan(self.cap_total, self.cap_rank)
+        # Set-up is COLLECTIVE and must fail on every rank or on none: a rank that raised out of it alone would leave the others in the
+        # barrier below (or in the next collective of the caller).  So every step that can fail locally is followed by an exchange of
+        # the ranks' verdicts, and an error anywhere is raised everywhere — the caller (bench.py's `auto` transport, a renderer
+        # configured with a fall-back) can then take the collective route on all ranks together.
+        def agree(local_error, what):
+            errors = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(errors, None if local_error is None else f"rank {self.rank}: {local_error}", group=self.group)
+            else:
+                errors = [None if local_error is None else str(local_error)]
+            failed = [e for e in errors if e is not None]
+            if failed:
+                self._release_local()
+                raise RuntimeError(f"PeerExchange: {what} failed ({'; '.join(failed)})")
+
         with torch.cuda.device(self.device):
             ptr, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-            L.check(L.lib().gspl_peer_alloc(lay["total"], ctypes.byref(ptr), handle), "gspl_peer_alloc")
-            self._mine = int(ptr.value)
+            err = None
+            try:
+                L.check(L.lib().gspl_peer_alloc(lay["total"], ctypes.byref(ptr), handle), "gspl_peer_alloc")
+                self._mine = int(ptr.value)
+            except Exception as e:      # noqa: BLE001 — whatever it was, the other ranks must hear of it
+                err = e
+            agree(err, "allocation of the receive buffers")
             handles = [None] * self.world
             if self.world > 1:
                 dist.all_gather_object(handles, (self.rank, handle.raw), group=self.group)
             else:
                 handles = [(self.rank, handle.raw)]
             self.base, self._opened = [0] * self.world, []
-            for r, raw in handles:
-                if r == self.rank:
-                    self.base[r] = self._mine
-                    continue
-                p = ctypes.c_void_p()
-                L.check(L.lib().gspl_peer_open(ctypes.create_string_buffer(raw, 64), ctypes.byref(p)), "gspl_peer_open")
-                self.base[r] = int(p.value)
-                self._opened.append(int(p.value))
+            err = None
+            try:
+                for r, raw in handles:
+                    if r == self.rank:
+                        self.base[r] = self._mine
+                        continue
+                    p = ctypes.c_void_p()
+                    L.check(L.lib().gspl_peer_open(ctypes.create_string_buffer(raw, 64), ctypes.byref(p)), "gspl_peer_open")
+                    self.base[r] = int(p.value)
+                    self._opened.append(int(p.value))
+            except Exception as e:      # noqa: BLE001
+                err = e
+            agree(err, "mapping of the peers' receive buffers (HIP IPC)")
         if self.world > 1:
             dist.barrier(group=self.group)          # nobody writes into a buffer its owner has not mapped and cleared yet
+
+    def _release_local(self):
+        """Frees this rank's buffer and mappings without any collective (the failure path of `_ensure`)."""
+        if self._mine is None and not self._opened:
+            return
+        from . import _lib as L
+        with torch.cuda.device(self.device):
+            for p in self._opened:
+                L.lib().gspl_peer_close(p)
+            if self._mine is not None:
+                L.lib().gspl_peer_free(self._mine)
+        self._mine, self._opened, self.base = None, [], []
 
     def close(self):
         if self._mine is None:

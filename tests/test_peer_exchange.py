@@ -74,3 +74,62 @@ def test_single_rank_counted_matrix():
         px.route([10], [[11]])
     px.check()
     px.close()
+
+
+def _failing_setup_worker(rank, world, port, tmpdir, fail_at):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gspl_amd  # noqa: F401
+        from gspl_amd import distributed as D, _lib as L
+        dev = torch.device("cuda:0")
+        if rank == 1:          # this rank's allocation / IPC mapping is refused, the other rank's works
+            lib = L.lib()
+            real = getattr(lib, fail_at)
+            setattr(lib, fail_at, lambda *a: 1)
+        px = D.PeerExchange(rank, None, dev)
+        try:
+            px.route([100, 100])
+            outcome = "no error"
+        except RuntimeError as e:
+            outcome = str(e)
+        # the set-up failed on BOTH ranks, with the failing rank named, and nobody is left inside a collective: this one pairs up
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        assert int(t) == 3
+        assert "rank 1" in outcome and "failed" in outcome, outcome
+        assert px._mine is None and px._opened == []
+        if rank == 1:
+            setattr(lib, fail_at, real)
+        # ... and the same object sets up fine afterwards
+        fwd, _ = px.route([100, 100])
+        rows = torch.full((200, D.RECORD_FLOATS), float(rank + 1), device=dev)
+        got = fwd(rows)
+        torch.cuda.synchronize()
+        px.check()
+        assert got.shape == (200, D.RECORD_FLOATS) and torch.equal(got[:100], torch.full_like(got[:100], 1.0)) and torch.equal(got[100:], torch.full_like(got[100:], 2.0))
+        dist.barrier()
+        px.close()
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_at", ["gspl_peer_alloc", "gspl_peer_open"])
+def test_a_set_up_failure_on_one_rank_is_raised_on_every_rank(tmp_path, fail_at):
+    """PeerExchange set-up is collective (handles all-gathered, a barrier before the first put): a rank whose allocation or IPC
+    mapping is refused must not leave the others waiting in it — every rank raises, naming the rank that failed, and the caller
+    (bench.py's `auto` transport) falls back to the collective route on all ranks together.  Two processes on one GPU."""
+    import torch.multiprocessing as mp
+    from conftest import free_port
+    mp.spawn(_failing_setup_worker, args=(2, free_port(), str(tmp_path), fail_at), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
