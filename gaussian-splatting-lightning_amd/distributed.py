@@ -148,9 +148,21 @@ class HostMailbox:
             dist.broadcast_object_list(names, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if self.rank != 0:
             self._shm = shared_memory.SharedMemory(name=names[0])
+            # Python < 3.13 registers an ATTACHED segment with this process's resource tracker too, which then unlinks it (and warns
+            # of a leak) when this process exits — the segment belongs to rank 0
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:      # noqa: BLE001 — book-keeping only
+                pass
         self._rows = np.ndarray((2, self.world, self.width + 1), dtype=np.int64, buffer=self._shm.buf)      # [..., -1] = sequence number
         if self.world > 1:
             dist.barrier(group=group)
+        # a process that ends without close() (the bench, a training run that is interrupted) still releases / unlinks the segment
+        import atexit
+        import weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())
 
     def exchange(self, values: Sequence[int], timeout_s: float = 120.0) -> List[List[int]]:
         """My row in, everybody's rows out (rank order); blocks until every rank has posted its row of this call."""
