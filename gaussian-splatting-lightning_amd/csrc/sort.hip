@@ -245,6 +245,19 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
             old = __shfl(old, leader);
             rk[r] = old + below;
 #else
+            // A wave whose items all carry ONE digit (the top byte of depth keys: a handful of values for a whole frame) needs no
+            // matching: the rank is the lane's position among the valid lanes.  64 lanes OR-ing into one LDS word serialise — the
+            // last depth pass ran 40 % longer than the others (16.4 against 11.5 us at 1 M keys, 115 against 72 at 6 M).
+            const unsigned long long act = __ballot(valid);
+            const int first = act ? (int)__builtin_ctzll(act) : 0;
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+            if (act != 0ull && __ballot(valid && d != d0) == 0ull) {
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                const uint32_t old = sh.wcnt[w][d0];
+                __builtin_amdgcn_wave_barrier();
+                if (l == first) sh.wcnt[w][d0] = old + (uint32_t)__builtin_popcountll(act);
+                rk[r] = old + below;
+            } else {
             // LDS operations of one wave execute in program order: every lane's OR lands before the reads below
             unsigned long long peers = 0ull;
             uint32_t old = 0u;
@@ -261,6 +274,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const KeyT* _
                 sh.match[w][d] = 0ull;
             }
             rk[r] = old + below;
+            }
 #endif
             __builtin_amdgcn_wave_barrier();
         }
