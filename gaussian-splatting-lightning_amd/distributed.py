@@ -158,11 +158,13 @@ class HostMailbox:
         self._rows = np.ndarray((2, self.world, self.width + 1), dtype=np.int64, buffer=self._shm.buf)      # [..., -1] = sequence number
         if self.world > 1:
             dist.barrier(group=group)
-        # a process that ends without close() (the bench, a training run that is interrupted) still releases / unlinks the segment
-        import atexit
-        import weakref
-        ref = weakref.ref(self)
-        atexit.register(lambda: ref() is not None and ref().close())
+        # every rank has the segment mapped: its NAME can go now (the memory lives as long as a mapping does), so that no way of ending
+        # a process — an exception, a kill, a multiprocessing child that skips its exit handlers — leaves a segment behind in /dev/shm
+        if self.rank == 0:
+            try:
+                self._shm.unlink()
+            except FileNotFoundError:
+                pass
 
     def exchange(self, values: Sequence[int], timeout_s: float = 120.0) -> List[List[int]]:
         """My row in, everybody's rows out (rank order); blocks until every rank has posted its row of this call."""
@@ -184,12 +186,7 @@ class HostMailbox:
         shm, self._shm = getattr(self, "_shm", None), None
         if shm is not None:
             self._rows = None
-            shm.close()
-            if self.rank == 0:
-                try:
-                    shm.unlink()
-                except FileNotFoundError:
-                    pass
+            shm.close()          # (the name was unlinked as soon as every rank had attached)
 
 
 class _DevicePtr:
