@@ -106,6 +106,9 @@ def _mailbox_worker(rank, world, port, tmpdir):
         import gspl_amd  # noqa: F401
         from gspl_amd import distributed as D
         box = D.HostMailbox(rank, None, width=3)
+        # the segment's NAME is gone as soon as every rank has attached (nothing can be left behind in /dev/shm, however a rank ends);
+        # the mapping lives on
+        assert not os.path.exists("/dev/shm/" + box._shm.name.lstrip("/")), box._shm.name
         for call in range(1, 400):
             if rank == call % world and call % 7 == 0:
                 time.sleep(0.002)                  # ranks drift: a fast rank posts its next row while a slow one still reads
