@@ -147,14 +147,17 @@ class HostMailbox:
         if self.world > 1:
             dist.broadcast_object_list(names, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if self.rank != 0:
-            self._shm = shared_memory.SharedMemory(name=names[0])
-            # Python < 3.13 registers an ATTACHED segment with this process's resource tracker too, which then unlinks it (and warns
-            # of a leak) when this process exits — the segment belongs to rank 0
+            # Python < 3.13 registers an ATTACHED segment with the resource tracker too (no `track=False` yet).  The segment belongs to
+            # rank 0: an attaching rank must leave no trace there — registering and unregistering again is not the same thing when the
+            # ranks share one tracker (multiprocessing children do): the name is one set entry, and rank 0's unlink would then
+            # unregister a name that is already gone (a KeyError traceback from the tracker at exit)
+            from multiprocessing import resource_tracker
+            register = resource_tracker.register
+            resource_tracker.register = lambda *a, **k: None
             try:
-                from multiprocessing import resource_tracker
-                resource_tracker.unregister(self._shm._name, "shared_memory")
-            except Exception:      # noqa: BLE001 — book-keeping only
-                pass
+                self._shm = shared_memory.SharedMemory(name=names[0])
+            finally:
+                resource_tracker.register = register
         self._rows = np.ndarray((2, self.world, self.width + 1), dtype=np.int64, buffer=self._shm.buf)      # [..., -1] = sequence number
         if self.world > 1:
             dist.barrier(group=group)
@@ -165,6 +168,9 @@ class HostMailbox:
                 self._shm.unlink()
             except FileNotFoundError:
                 pass
+        # ... and nobody leaves the constructor before it is gone: "the name no longer exists" holds on every rank from here on
+        if self.world > 1:
+            dist.barrier(group=group)
 
     def exchange(self, values: Sequence[int], timeout_s: float = 120.0) -> List[List[int]]:
         """My row in, everybody's rows out (rank order); blocks until every rank has posted its row of this call."""

@@ -23,12 +23,17 @@ WORKLOADS = {
     # BASELINE.json configs[4] proxy (MatrixCity aerial partition, configs/matrixcity/gsplat-aerial.yaml:25 + configs/gsplat-absgrad.yaml:6-8):
     # ~20 M small Gaussians at SH degree 0 (56 B of parameters each), gsplat API, absgrad densification statistics
     "S-1080p-20M-sh0-absgrad": dict(n=20_000_000, width=1920, height=1080, fx=1600.0, sh_degree=0, scale_mul=0.4, api="gsplat", absgrad=True),
+    # a scene shaped like a TRAINED capture (`scene_surfaces`): opaque closed surfaces, opacity mass near 1, a heavy tail of large
+    # anisotropic splats, an empty sky band — early termination after tens of splats, long lists in a few tiles
+    "S-1080p-1M-surfaces": dict(n=1_000_000, width=1920, height=1080, fx=1600.0, scene="surfaces"),
+    "S-smoke-surfaces": dict(n=30_000, width=320, height=208, fx=300.0, scene="surfaces", scale_mul=5.0),
 }
 
 
 def workload_scene(wl: dict, seed: int = 42):
     """`scene` with the workload's SH degree and scale multiplier."""
-    means, scales, quats, opac, shs = scene(wl["n"], seed=seed, sh_degree=wl.get("sh_degree", 3))
+    make = scene_surfaces if wl.get("scene") == "surfaces" else scene
+    means, scales, quats, opac, shs = make(wl["n"], seed=seed, sh_degree=wl.get("sh_degree", 3))
     return means, scales * wl.get("scale_mul", 1.0), quats, opac, shs
 
 
@@ -43,6 +48,77 @@ def scene(n: int, seed: int = 42, sh_degree: int = 3):
     opac = torch.sigmoid(torch.randn(n, 1, generator=g))
     shs = torch.randn(n, K, 3, generator=g) * 0.2
     return means, scales, quats, opac, shs
+
+
+def scene_surfaces(n: int, seed: int = 42, sh_degree: int = 3):
+    """A scene with the statistics of a TRAINED model rather than of an initialisation (`scene` above is the Blender init box,
+    blender_dataparser.py:137: a uniform translucent cloud, 54 blended splats per pixel, no saturation anywhere):
+
+      * Gaussians lie ON a few closed / opaque surfaces — a ground plane, a back wall and three ellipsoids standing in front of it —
+        flattened along the surface normal (normal scale = 0.15 x the tangent scales) and rotated into the tangent frame, the way the
+        optimiser of vanilla_gaussian.py leaves them;
+      * opacity is bimodal with its mass near 1 (75 % sigmoid(N(3.5, 1.2)), 25 % sigmoid(N(-2, 1)): the survivors of the
+        opacity resets and the ones about to be pruned, vanilla_density_controller.py:16-24) — a pixel saturates after tens of splats
+        and the rear side of every object sits BEHIND the stop, in the lists but never composited;
+      * tangent scales are log-normal with a heavy tail: 2 % needles (one tangent axis x 8), 0.5 % big blobs (both x 6): long lists in
+        the tiles they cross;
+      * the top ~30 % of the frame of `camera()` is sky: empty tiles next to full ones;
+      * colours vary smoothly over a surface (SH dc from a low-frequency field), higher orders decay with the degree.
+
+    Same return signature as `scene` (activated tensors).  Deterministic in `seed`."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    K = (sh_degree + 1) ** 2
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    nrm = lambda *s: torch.randn(*s, generator=g)
+    # surface samplers: points p [m,3] and outward unit normals nv [m,3] (world frame of `camera()`: +y is down in the image, the
+    # camera sits at z = -distance looking along +z)
+    ellipsoids = [((-0.9, 0.3, 0.2), (0.6, 0.6, 0.6)), ((0.6, 0.45, -0.3), (0.45, 0.45, 0.45)), ((0.2, 0.05, 1.2), (0.9, 0.85, 0.7))]
+    share = [0.33, 0.19] + [0.16, 0.10, 0.22]               # ground, wall, ellipsoids (roughly by area)
+    counts = [int(n * f) for f in share]
+    counts[0] += n - sum(counts)
+    pts, nrms = [], []
+    m = counts[0]                                           # ground y = 0.9, facing the camera's up (-y)
+    pts.append(torch.stack([rnd(m) * 6 - 3, torch.full((m,), 0.9), rnd(m) * 6 - 2], dim=1))
+    nrms.append(torch.tensor([0.0, -1.0, 0.0]).expand(m, 3))
+    m = counts[1]                                           # back wall z = 2.5, facing the camera (-z)
+    pts.append(torch.stack([rnd(m) * 5 - 2.5, rnd(m) * 1.5 - 0.6, torch.full((m,), 2.5)], dim=1))
+    nrms.append(torch.tensor([0.0, 0.0, -1.0]).expand(m, 3))
+    for (c, r), m in zip(ellipsoids, counts[2:]):
+        u = torch.nn.functional.normalize(nrm(m, 3), dim=-1)
+        c, r = torch.tensor(c), torch.tensor(r)
+        pts.append(c + u * r)
+        nrms.append(torch.nn.functional.normalize(u / r, dim=-1))
+    p, nv = torch.cat(pts), torch.cat(nrms).contiguous()
+    perm = torch.randperm(n, generator=g)                   # no surface-by-surface order in memory (a trained model has none)
+    p, nv = p[perm], nv[perm]
+    means = p + nv * (nrm(n, 1) * 0.003)
+    # scales: (tangent 1, tangent 2, normal); the local z axis of the splat is the surface normal
+    tang = torch.exp(nrm(n, 2) * 0.5 - 4.8)
+    kind = rnd(n)
+    needle, blob = kind < 0.02, (kind >= 0.02) & (kind < 0.025)
+    tang[:, 0] = torch.where(needle, tang[:, 0] * 8.0, tang[:, 0])
+    tang = torch.where(blob[:, None], tang * 6.0, tang)
+    scales = torch.cat([tang, 0.15 * tang.min(dim=1, keepdim=True).values], dim=1)
+    # rotation (wxyz): the shortest arc taking +z to the normal, after a random turn about z
+    w_ = 1.0 + nv[:, 2]
+    align = torch.stack([w_, -nv[:, 1], nv[:, 0], torch.zeros(n)], dim=1)
+    align = torch.where((w_ < 1e-6)[:, None], torch.tensor([0.0, 1.0, 0.0, 0.0]).expand(n, 4), align)
+    align = torch.nn.functional.normalize(align, dim=-1)
+    th = rnd(n) * math.pi
+    cz, sz = torch.cos(th), torch.sin(th)
+    aw, ax, ay, az = align.unbind(dim=1)
+    quats = torch.stack([aw * cz - az * sz, ax * cz + ay * sz, ay * cz - ax * sz, aw * sz + az * cz], dim=1)      # align (x) (cz, 0, 0, sz)
+    quats = torch.nn.functional.normalize(quats, dim=-1)
+    solid = rnd(n, 1) < 0.75
+    opac = torch.sigmoid(torch.where(solid, nrm(n, 1) * 1.2 + 3.5, nrm(n, 1) - 2.0))
+    freq = torch.tensor([[2.1, 1.3, 0.7], [0.9, 2.3, 1.7], [1.5, 0.6, 2.6]])
+    base = 0.5 + 0.35 * torch.sin(p @ freq + torch.tensor([0.3, 1.1, 2.0]))
+    shs = torch.empty(n, K, 3)
+    shs[:, 0] = (base - 0.5) / 0.28209479177387814 + nrm(n, 3) * 0.05
+    for deg in range(1, sh_degree + 1):
+        shs[:, deg * deg:(deg + 1) * (deg + 1)] = nrm(n, 2 * deg + 1, 3) * (0.08 / deg)
+    return means.contiguous(), scales.contiguous(), quats.contiguous(), opac, shs
 
 
 def camera(width: int, height: int, fx: float, fy: float = None, distance: float = 4.0):
