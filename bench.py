@@ -73,7 +73,7 @@ def parse():
     p.add_argument("--loss", default="photometric", choices=["l1", "photometric"],
                    help="l1: mean |render - target| with torch ops; photometric: the reference's training loss "
                         "0.8 L1 + 0.2 (1 - SSIM) (vanilla_metrics.py:66-68) through the fused HIP loss kernels")
-    p.add_argument("--optimizer", default="fused-adam", choices=["none", "fused-adam", "selective-adam", "torch-adam", "masked-adam"],
+    p.add_argument("--optimizer", default="fused-adam", choices=["none", "fused-adam", "fused-bwd-adam", "selective-adam", "torch-adam", "masked-adam"],
                    help="optimizer step inside the timed step (default: the package's fused Adam; none = renderer fwd+bwd rate only; "
                         "masked-adam: --parallelism replicated with the visibility-masked reduce-scatter / all-gather and the optimizer "
                         "state sharded by row ownership, distributed.MaskedReplicaAdam)")
@@ -113,6 +113,18 @@ def parse():
     return p.parse_args()
 
 
+def entries_walked(last, W, H, tile=16):
+    """List entries the compositing kernels WALK in this frame: per tile, from the head of its list to the deepest entry any of its
+    pixels blended (`last_ids` = one past it; the backward starts there, the forward stops within a round of it).  In a scene that
+    saturates this is far below the list length — the byte model is priced on it, not on entries the kernels never read."""
+    li, offs = last["last_ids"], last["offsets"]
+    th, tw = (H + tile - 1) // tile, (W + tile - 1) // tile
+    pad = torch.zeros((th * tile, tw * tile), dtype=li.dtype, device=li.device)
+    pad[:H, :W] = li
+    deepest = pad.view(th, tile, tw, tile).amax(dim=(1, 3)).reshape(-1)
+    return int((deepest - offs[:th * tw]).clamp_min(0).sum(dtype=torch.int64).item())
+
+
 def _mark():
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -138,7 +150,7 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
     loss_fn = lambda img, gt: ops.photometric_loss(img, gt, 0.2)
 
     def setup(n, from_iter, interval, reset):
-        clean = synthetic.scene(n, seed=42)
+        clean = (synthetic.scene_surfaces if wl.get("scene") == "surfaces" else synthetic.scene)(n, seed=42)
         # targets: the clean scene from every camera (degree 3); the trained model starts from a perturbed copy at degree 1
         truth = synthetic.ModelObject(*[t.to(dev) for t in clean], active_sh_degree=3)
         with torch.no_grad():
@@ -289,7 +301,7 @@ def cpu_baseline(workload_name, api):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
+    means, scales, quats, opac, shs = synthetic.workload_scene(wl, seed=42)
     cam = synthetic.camera(wl["width"], wl["height"], wl["fx"])
     W, H = wl["width"], wl["height"]
     leaves = [t.clone().requires_grad_(True) for t in (means, scales, quats, opac, shs)]
@@ -369,7 +381,7 @@ def reference_projection_sh(workload_name, cores):
     gp, sh = mods
     wl = synthetic.WORKLOADS[workload_name]
     torch.set_num_threads(cores)
-    means, scales, quats, opac, shs = synthetic.scene(wl["n"], seed=42)
+    means, scales, quats, opac, shs = synthetic.workload_scene(wl, seed=42)
     cam = synthetic.camera(wl["width"], wl["height"], wl["fx"])
     W, H = wl["width"], wl["height"]
     t = torch.tensor
@@ -505,6 +517,14 @@ def main():
         # single GPU: the update of shs_rest (45 of a Gaussian's 59 floats) runs on the rasterizer's colour stream, under the next
         # frame's geometry and binning kernels (FusedAdam(deferred=...): same kernel, bit-identical parameters)
         deferred = ("shs_rest",) if (mode == "single" and args.overlap_sh_update and not args.no_overlap_sh_update) else None
+        if kind == "fused-bwd-adam":
+            # the same update applied by the rasterizer's backward (FusedAdam(fuse_into_backward=True), gspl_rasterize_inria_bwd_adam): the
+            # parameter gradients never reach HBM.  Off until the step that has a `step()` behind every backward is built (below).
+            if mode != "single" or api != "vanilla":
+                sys.exit("--optimizer fused-bwd-adam: one GPU, vanilla API (the fused Inria backward applies the update)")
+            opt = gopt.FusedAdam(groups, eps=1e-15, fuse_into_backward=True)
+            opt.fuse_into_backward = False
+            return opt
         return (gopt.FusedAdam if kind == "fused-adam" else gopt.SelectiveAdam)(groups, eps=1e-15, deferred=deferred)
 
     DENSIFY_INTERVAL = 100      # the reference consumes the statistics every 100 steps (vanilla_density_controller.py:16,86)
@@ -605,7 +625,11 @@ def main():
 
     def make_full_step(optimizer, opt_kind):
         def full_step(force_reduce=False):
+            if opt_kind == "fused-bwd-adam":
+                optimizer.fuse_into_backward = True       # (a plain attribute store; the other passes of the bench run with it off)
             st = step()
+            if opt_kind == "fused-bwd-adam":
+                optimizer.fuse_into_backward = False
             with torch.no_grad():
                 stats(st, accum, denom, max_radii)
                 if optimizer is not None:
@@ -721,7 +745,8 @@ def main():
                 last = ops.LAST_RASTER
                 count = ops.composite_scores(last["means2d"], last["conics"], last["opacities"], W, H, 16, last["offsets"],
                                              last["flatten_ids"], mode=last["mode"])[0]
-                entry = {"list_entries": int(last["flatten_ids"].shape[0]), "valid_pairs": int(count.sum(dtype=torch.int64).item())}
+                entry = {"list_entries": int(last["flatten_ids"].shape[0]), "valid_pairs": int(count.sum(dtype=torch.int64).item()),
+                         "entries_walked": entries_walked(last, W, H)}
                 if api == "vanilla":      # every tile-rect intersection in the Inria convention: the same binning without culling
                     entry["I"] = int(ops.bin_gaussians(last["means2d"], last["depths"], last["radii"], H, W, 16, mode=_lib.GSPL_MODE_INRIA)[0].shape[0])
                     entry["V"] = int((last["radii"] > 0).sum().item())
@@ -791,6 +816,8 @@ def main():
                                              last["flatten_ids"], mode=last["mode"])[0]
                 for e in per_cam:
                     e["list_entries"], e["valid_pairs"] = int(last["flatten_ids"].shape[0]), int(count.sum(dtype=torch.int64).item())
+                    if last.get("last_ids") is not None:
+                        e["entries_walked"] = entries_walked(last, W, H)
         else:
             per_cam = per_cam_before
 
@@ -825,6 +852,7 @@ def main():
         bwd_ms = mean("gspl_composite_bwd_packed") or mean("gspl_composite_bwd")
         avg = lambda key: (sum(e[key] for e in per_cam) / len(per_cam)) if per_cam and key in per_cam[0] else None
         I, list_entries, valid_pairs, V = avg("I"), avg("list_entries"), avg("valid_pairs"), avg("V")
+        walked = avg("entries_walked")
         roofline = None
         if bwd_ms and per_cam:
             kernel = _lib.lib().gspl_composite_bwd_kernel_name().decode()
@@ -832,15 +860,19 @@ def main():
             t_s = bwd_ms * 1e-3
             bytes_I = (76.0 * I + 20.0 * P) if I is not None else None
             bytes_L = (76.0 * list_entries + 20.0 * P) if list_entries is not None else None
-            # The launch walks the CULLED per-tile lists (list_entries = I'), so `frac` is priced on those units; the figure on every
-            # rect intersection of the benched API (I: what SURVEY.md §8(d) counts and rounds 1-3 reported as `frac`) stays beside it.
-            alg = bytes_L if bytes_L is not None else bytes_I
+            bytes_W = (76.0 * walked + 20.0 * P) if walked is not None else None
+            # The launch walks the CULLED per-tile lists (I') from each tile's deepest blended entry to its head, so `frac` is priced on
+            # the entries WALKED (round 5: in a saturating scene the lists continue far behind the stop and the kernel never reads that
+            # part; at the metric point walked ~ I').  The figures on I' (rounds 4) and on every rect intersection of the benched API
+            # (I: what SURVEY.md §8(d) counts and rounds 1-3 reported as `frac`) stay beside it.
+            alg = bytes_W if bytes_W is not None else (bytes_L if bytes_L is not None else bytes_I)
             achieved = alg / t_s / 1e9
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_bytes": alg, "bytes_model": "76 B x list entries the launch walks + 20 B x pixels",
                         "avg_ms": round(bwd_ms, 4),
-                        "intersections": I, "list_entries": list_entries,
+                        "intersections": I, "list_entries": list_entries, "entries_walked": walked,
+                        "frac_on_list_entries": round(bytes_L / t_s / 1e9 / HBM_PEAK_GBS, 5) if bytes_L else None,
                         "frac_on_rect_intersections": round(bytes_I / t_s / 1e9 / HBM_PEAK_GBS, 5) if bytes_I else None,
                         "valid_pairs": valid_pairs, "flop_per_pair": 70,
                         "valu_frac": round(valid_pairs * 70.0 / t_s / (FP32_PEAK_TFLOPS * 1e12), 5) if valid_pairs else None,
@@ -851,6 +883,7 @@ def main():
         if stage_prof is not None and I is not None and V is not None:
             K = 16
             N_, Ip = float(wl["n"]), float(list_entries)
+            Iw = float(walked) if walked is not None else Ip
             ov, al = stage_prof["overlapped"], stage_prof["alone"]
             per_step = lambda pr, names: (sum(sum(pr.get(n, [])) for n in names) / len(cam_dicts)) if any(pr.get(n) for n in names) else None
             phase = lambda pr, k: (lambda v: (sum(v[k::2]) / max(len(v[k::2]), 1)) if v else None)(pr.get("gspl_inria_preprocess_fwd", []))
@@ -864,15 +897,17 @@ def main():
             stage_rooflines = {
                 "method": f"staged pass after the timed regions ({len(cam_dicts)} steps, one per camera): stage-by-stage C-ABI calls (GSPL_FUSED_INRIA=0) "
                           "with a HIP event pair around every call; bytes = SURVEY.md §8(d) per-unit figures x mean units over the camera set",
-                "units": {"N": int(N_), "V": round(V, 1), "I": round(I, 1), "list_entries": round(Ip, 1), "P": P},
+                "units": {"N": int(N_), "V": round(V, 1), "I": round(I, 1), "list_entries": round(Ip, 1), "entries_walked": round(Iw, 1), "P": P},
                 "inria_preprocess_fwd": entry(phase(al, 0), 76.0 * N_, "76 N"),
                 "sh_fwd_alone": entry(phase(al, 1), (12.0 * K + 24.0) * V, "(12 K + 24) V"),
                 "sh_fwd_overlapped_with_binning": entry(phase(ov, 1), (12.0 * K + 24.0) * V, "(12 K + 24) V"),
                 "binning": entry(per_step(al, bin_names), 72.0 * N_ + 32.0 * V + 44.0 * Ip,
                                  "depth sort 8 N (1 + 2*4) + emit 32 V + 8 I' + tile sort 36 I'"),
-                "composite_fwd": entry(per_step(al, ("gspl_composite_fwd",)), 40.0 * Ip + 20.0 * P, "40 I' + 20 P (list entries walked)",
+                "composite_fwd": entry(per_step(al, ("gspl_composite_fwd",)), 40.0 * Iw + 20.0 * P, "40 x entries walked + 20 P",
+                                       frac_on_list_entries=_frac_on(per_step(al, ("gspl_composite_fwd",)), 40.0 * Ip + 20.0 * P),
                                        frac_on_rect_intersections=_frac_on(per_step(al, ("gspl_composite_fwd",)), 40.0 * I + 20.0 * P)),
-                "composite_bwd": entry(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * Ip + 20.0 * P, "76 I' + 20 P (list entries walked)",
+                "composite_bwd": entry(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * Iw + 20.0 * P, "76 x entries walked + 20 P",
+                                       frac_on_list_entries=_frac_on(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * Ip + 20.0 * P),
                                        frac_on_rect_intersections=_frac_on(per_step(al, ("gspl_composite_bwd_packed",)), 76.0 * I + 20.0 * P)),
                 "inria_preprocess_bwd_with_sh_bwd": entry(per_step(al, ("gspl_inria_preprocess_bwd",)), (116.0 + 24.0 * K) * V, "(36 + 40 + 40) V + 2 * 12 K V"),
                 "loss_fwd_bwd": entry(per_step(al, ("gspl_loss_l1_ssim_fwd", "gspl_loss_photometric_fwd", "gspl_loss_l1_ssim_bwd")), 4.0 * 3 * P * (2 + 3 + 4), "3 P floats: 2 read fwd, 3 maps written, 3 read + 1 written bwd"),

@@ -38,6 +38,17 @@ class AdamTensor(ctypes.Structure):
                 ("exp_avg_sq", ctypes.c_void_p), ("lr", ctypes.c_float), ("row_elems", ctypes.c_int32)]
 
 
+class BwdAdamTensor(ctypes.Structure):
+    """`gspl_bwd_adam_tensor` of include/gspl_hip.h (moments + hyper-parameters of one parameter updated inside the backward)."""
+    _fields_ = [("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("lr", ctypes.c_float), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("bias_correction1", ctypes.c_float), ("bias_correction2_sqrt", ctypes.c_float)]
+
+
+class BwdAdamPlan(ctypes.Structure):
+    """`gspl_bwd_adam_plan`."""
+    _fields_ = [(n, BwdAdamTensor) for n in ("means", "scales", "rotations", "opacities", "shs", "shs_rest")]
+
+
 class HipLibraryError(RuntimeError):
     pass
 
@@ -125,6 +136,8 @@ _SIGNATURES = {
                                          ALLOC_FN, _P, c_int64, _P, _P, ctypes.POINTER(InriaState), _P, _P]),
     "gspl_rasterize_inria_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
                                          _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_rasterize_inria_bwd_adam": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float,
+                                              _P, ctypes.POINTER(InriaState), _P, _P, _P, _P, _P, ctypes.POINTER(BwdAdamPlan), _P]),
     "gspl_profile_enable": (c_int, [c_int]),
     "gspl_profile_enable2": (c_int, [c_int, c_int]),
     "gspl_profile_read": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),

@@ -27,11 +27,7 @@ struct AdamTensorDev {
 };
 struct AdamBatchDev { AdamTensorDev t[GSPL_ADAM_MAX_TENSORS]; };
 
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float step, float b1, float b2, float inv_bc2, float eps) {
-    m = b1 * m + (1.f - b1) * g;
-    v = b2 * v + (1.f - b2) * g * g;
-    p -= step * m / (sqrtf(v) * inv_bc2 + eps);
-}
+// (adam_elem: gspl_device.h — shared with the backward kernels that apply the update themselves)
 
 __global__ __launch_bounds__(256) void selective_adam_kernel(AdamBatchDev batch, int N, const uint8_t* __restrict__ visible,
                                                              float b1, float b2, float eps, float inv_bc1, float inv_bc2) {

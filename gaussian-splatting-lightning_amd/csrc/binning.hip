@@ -169,7 +169,7 @@ __device__ __forceinline__ SplatCull make_cull(float mx, float my, float a, floa
     SplatCull s;
     s.mx = mx; s.my = my; s.a = a; s.b = b;
     const float tau = __logf(255.f * opacity);
-    s.det = a * c - b * b;
+    s.det = conic_det(a, b, c);      // (without the cancellation of a c - b b: the spans of long anisotropic splats hang on it)
     if (!(tau > 0.f)) { s.kind = 0; return s; }
     if (!(s.det > 0.f) || !(a > 0.f) || !(c > 0.f)) { s.kind = 2; return s; }
     s.kind = 1;

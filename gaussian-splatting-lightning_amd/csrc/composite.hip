@@ -44,8 +44,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     __shared__ __attribute__((aligned(16))) float s_x[FLIST];
     __shared__ __attribute__((aligned(16))) float s_y[FLIST];
     __shared__ __attribute__((aligned(16))) float s_ha[FLIST];
-    __shared__ __attribute__((aligned(16))) float s_b[FLIST];
-    __shared__ __attribute__((aligned(16))) float s_hc[FLIST];
+    __shared__ __attribute__((aligned(16))) float s_k[FLIST];       // sigma_coef: sigma = ha (dx + k dy)^2 + hd dy^2
+    __shared__ __attribute__((aligned(16))) float s_hd[FLIST];
     __shared__ __attribute__((aligned(16))) float s_op[FLIST];
     __shared__ __attribute__((aligned(16))) int s_pos[FLIST];      // list index (base + lane) of each candidate
     __shared__ __attribute__((aligned(16))) float s_col[FLIST * D];
@@ -92,13 +92,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             if (cand) {
                 s_x[slot] = xy.x; s_y[slot] = xy.y;
-                s_ha[slot] = 0.5f * ca; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op;
+                const SigmaCoef sc = sigma_coef(ca, cb, cc);
+                s_ha[slot] = sc.ha; s_k[slot] = sc.k; s_hd[slot] = sc.hd; s_op[slot] = op;
                 s_pos[slot] = i + 1;
 #pragma unroll
                 for (int c = 0; c < D; ++c) s_col[slot * D + c] = colors[(int64_t)g * D + c];
             }
             if (l == 0) {        // padding entry for an odd count: opacity 0 -> alpha 0 -> never valid
-                s_x[ncand] = 0.f; s_y[ncand] = 0.f; s_ha[ncand] = 0.f; s_b[ncand] = 0.f; s_hc[ncand] = 0.f; s_op[ncand] = 0.f;
+                s_x[ncand] = 0.f; s_y[ncand] = 0.f; s_ha[ncand] = 0.f; s_k[ncand] = 0.f; s_hd[ncand] = 0.f; s_op[ncand] = 0.f;
                 s_pos[ncand] = 0;
 #pragma unroll
                 for (int c = 0; c < D; ++c) s_col[ncand * D + c] = 0.f;
@@ -109,12 +110,12 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
                 const v2f x2 = *reinterpret_cast<const v2f*>(&s_x[k]);
                 const v2f y2 = *reinterpret_cast<const v2f*>(&s_y[k]);
                 const v2f ha2 = *reinterpret_cast<const v2f*>(&s_ha[k]);
-                const v2f b2 = *reinterpret_cast<const v2f*>(&s_b[k]);
-                const v2f hc2 = *reinterpret_cast<const v2f*>(&s_hc[k]);
+                const v2f k2 = *reinterpret_cast<const v2f*>(&s_k[k]);
+                const v2f hd2 = *reinterpret_cast<const v2f*>(&s_hd[k]);
                 const v2f op2 = *reinterpret_cast<const v2f*>(&s_op[k]);
                 const int2 pos2 = *reinterpret_cast<const int2*>(&s_pos[k]);
                 const v2f dx2 = x2 - pxf2, dy2 = y2 - pyf2;
-                const v2f sigma2 = eval_sigma2(ha2, b2, hc2, dx2, dy2);
+                const v2f sigma2 = eval_sigma2(ha2, k2, hd2, dx2, dy2);
                 const v2f arg2 = sigma2 * (v2f){-1.4426950408889634f, -1.4426950408889634f};
                 const v2f e2 = {__builtin_amdgcn_exp2f(arg2.x), __builtin_amdgcn_exp2f(arg2.y)};
                 const v2f raw2 = op2 * e2;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64) void composite_scores_kernel(
     int32_t* __restrict__ count, float* __restrict__ opacity_sum, float* __restrict__ alpha_sum, float* __restrict__ vis_sum,
     float* __restrict__ weighted_sum, float* __restrict__ dist_sum) {
     using TR = ModeTraits<MODE>;
-    __shared__ float s_x[64], s_y[64], s_ha[64], s_b[64], s_hc[64], s_op[64];
+    __shared__ float s_x[64], s_y[64], s_ha[64], s_k[64], s_hd[64], s_op[64];
     __shared__ int s_g[64];
     const int unit = blockIdx.x;
     const int tile = unit >> 2, w = unit & 3, l = threadIdx.x;
@@ -222,12 +223,16 @@ __global__ __launch_bounds__(64) void composite_scores_kernel(
         const int ncand = __builtin_popcountll(mask);
         const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         __builtin_amdgcn_wave_barrier();
-        if (cand) { s_x[slot] = mx; s_y[slot] = my; s_ha[slot] = 0.5f * ca; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op; s_g[slot] = g; }
+        if (cand) {
+            const SigmaCoef sc = sigma_coef(ca, cb, cc);
+            s_x[slot] = mx; s_y[slot] = my; s_ha[slot] = sc.ha; s_k[slot] = sc.k; s_hd[slot] = sc.hd; s_op[slot] = op; s_g[slot] = g;
+        }
         __builtin_amdgcn_wave_barrier();
         for (int k = 0; k < ncand; ++k) {
             const float dx = s_x[k] - pxf, dy = s_y[k] - pyf, o = s_op[k];
-            const float sigma = s_ha[k] * dx * dx + s_hc[k] * dy * dy + s_b[k] * dx * dy;
-            const float alpha = fminf(TR::kAlphaMax, o * __expf(-sigma));
+            // the compositing kernels' own expression tree (eval_sigma, exp2 of the scaled argument): the same pairs are counted as blended
+            const float sigma = eval_sigma(s_ha[k], s_k[k], s_hd[k], dx, dy);
+            const float alpha = fminf(TR::kAlphaMax, o * __builtin_amdgcn_exp2f(sigma * -1.4426950408889634f));
             const bool valid = !done && (sigma >= 0.f) && (alpha >= kAlphaMin);
             const float next_T = T * (1.f - alpha);
             const bool stop = valid && (TR::kStopInclusive ? (next_T <= kTStop) : (next_T < kTStop));

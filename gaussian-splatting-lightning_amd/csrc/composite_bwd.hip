@@ -13,9 +13,10 @@
 
 namespace gspl {
 
-// Staged record of composite_bwd2_kernel in LDS (floats): x y a/2 c/2 | b opacity quadrant-mask - | colour[D] (padded to a
+// Staged record of composite_bwd2_kernel in LDS (floats): x y a/2 k | hd opacity quadrant-mask b | colour[D] c/2 (padded to a
 // multiple of 4): one address register per candidate, the fields are fetched with immediate offsets (b128 + b64 [+ colour]).
-template <int D> struct BwdRec { static constexpr int STRIDE = 8 + ((D + 3) & ~3); };
+// (a/2, k, hd) = sigma_coef: what the walk evaluates sigma with; b and c/2 are what phase 2 turns the moments into gradients with.
+template <int D> struct BwdRec { static constexpr int STRIDE = 8 + ((D + 1 + 3) & ~3); static constexpr int HC = 8 + D; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward, TWO PIXELS PER LANE.  A workgroup is 2 waves per tile; wave w owns the 16x8 half tile of rows [8w, 8w+8)
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         float ca = 0.f, cb = 0.f, cc_ = 0.f, co_ = 1.f;
         if (live) {
             const float* rec = s_rec + j * RS;
-            const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 c/2
-            const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // b opacity
-            ca = 2.f * r0.z; cb = r1.x; cc_ = 2.f * r0.w; co_ = r1.y;
+            const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 k
+            const float4 r1 = *reinterpret_cast<const float4*>(rec + 4);      // hd opacity mask b
+            ca = 2.f * r0.z; cb = r1.w; cc_ = 2.f * rec[BwdRec<D>::HC]; co_ = r1.y;
             const float dx = r0.x - (hx0 + (float)pc);
             const float dy0 = r0.y - hy0;
             const v2f dy0v = {dy0, dy0};
@@ -227,10 +228,12 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
             const float mx = means2d[g * 2 + 0], my = means2d[g * 2 + 1];
             const unsigned qm = band_half_mask<2>(mx, my, ca, cb, cc, op, (float)tx + TR::kPixelCentre, (float)ty + TR::kPixelCentre);
             float* rec = s_rec + t * RS;
-            *reinterpret_cast<float4*>(rec) = make_float4(mx, my, 0.5f * ca, 0.5f * cc);
-            *reinterpret_cast<float4*>(rec + 4) = make_float4(cb, op, __uint_as_float(qm), 0.f);
+            const SigmaCoef sc = sigma_coef(ca, cb, cc);
+            *reinterpret_cast<float4*>(rec) = make_float4(mx, my, sc.ha, sc.k);
+            *reinterpret_cast<float4*>(rec + 4) = make_float4(sc.hd, op, __uint_as_float(qm), cb);
 #pragma unroll
             for (int c = 0; c < D; ++c) rec[8 + c] = colors[(int64_t)g * D + c];
+            rec[BwdRec<D>::HC] = 0.5f * cc;
         }
         __syncthreads();
         if (wave_last > lo) {
@@ -246,18 +249,18 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                     mask &= mask - 1;
                     const int idx = hi - 1 - j;
                     const float* rec = s_rec + j * RS;
-                    const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 c/2
-                    const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // b opacity
+                    const float4 r0 = *reinterpret_cast<const float4*>(rec);          // x y a/2 k
+                    const float2 r1 = *reinterpret_cast<const float2*>(rec + 4);      // hd opacity
                     float col[D];                                                    // fetched with the record: one LDS round trip per candidate
 #pragma unroll
                     for (int c = 0; c < D; ++c) col[c] = rec[8 + c];
-                    // sigma, bit-identical per element to eval_sigma: fma(ha dx, dx, fma(hc dy, dy, (b dx) dy))
+                    // sigma, bit-identical per element to eval_sigma: u = fma(k, dy, dx); fma(ha u, u, (hd dy) dy) — dy, and with it the
+                    // second term, is shared by the lane's two pixels (same row)
                     const v2f dx2 = (v2f){r0.x, r0.x} - pxf2;
                     const float dy = r0.y - pyf;
-                    const float hcdy = r0.w * dy;
-                    const v2f dy2 = {dy, dy};
-                    const v2f inner = __builtin_elementwise_fma((v2f){hcdy, hcdy}, dy2, ((v2f){r1.x, r1.x} * dx2) * dy2);
-                    const v2f sigma2 = __builtin_elementwise_fma((v2f){r0.z, r0.z} * dx2, dx2, inner);
+                    const float e = (r1.x * dy) * dy;
+                    const v2f u2 = __builtin_elementwise_fma((v2f){r0.w, r0.w}, (v2f){dy, dy}, dx2);
+                    const v2f sigma2 = __builtin_elementwise_fma((v2f){r0.z, r0.z} * u2, u2, (v2f){e, e});
                     const v2f arg2 = sigma2 * (v2f){-1.4426950408889634f, -1.4426950408889634f};
                     const v2f vis2 = {__builtin_amdgcn_exp2f(arg2.x), __builtin_amdgcn_exp2f(arg2.y)};
                     const v2f raw2 = (v2f){r1.y, r1.y} * vis2;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(64) void composite_bwd_block_kernel(
     uint8_t* __restrict__ hit_flags, ListTiles lt) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
-    __shared__ float s_x[64], s_y[64], s_ha[64], s_b[64], s_hc[64], s_op[64];
+    __shared__ float s_x[64], s_y[64], s_ha[64], s_b[64], s_hc[64], s_op[64], s_k[64], s_hd[64];
     __shared__ float s_col[64 * D];
     __shared__ int s_g[64], s_idx[64];
 
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(64) void composite_bwd_block_kernel(
         const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         __syncthreads();
         if (cand) {
-            s_x[slot] = mx; s_y[slot] = my; s_ha[slot] = 0.5f * ca; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op;
+            const SigmaCoef sc = sigma_coef(ca, cb, cc);
+            s_x[slot] = mx; s_y[slot] = my; s_ha[slot] = sc.ha; s_b[slot] = cb; s_hc[slot] = 0.5f * cc; s_op[slot] = op;
+            s_k[slot] = sc.k; s_hd[slot] = sc.hd;
             s_g[slot] = g; s_idx[slot] = idx;
 #pragma unroll
             for (int c = 0; c < D; ++c) s_col[slot * D + c] = colors[(int64_t)g * D + c];
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(64) void composite_bwd_block_kernel(
             const int kidx = s_idx[k];
             const float ha = s_ha[k], b = s_b[k], hc = s_hc[k], o = s_op[k];
             const float dx = s_x[k] - pxf, dy = s_y[k] - pyf;
-            const float sigma = eval_sigma(ha, b, hc, dx, dy);
+            const float sigma = eval_sigma(ha, s_k[k], s_hd[k], dx, dy);
             const float vis = __builtin_amdgcn_exp2f(sigma * -1.4426950408889634f);
             const float raw = o * vis;
             const bool valid = (kidx < last) && (sigma >= 0.f) && (raw >= kAlphaMin);

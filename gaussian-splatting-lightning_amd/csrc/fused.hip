@@ -314,7 +314,51 @@ extern "C" int gspl_rasterize_inria_fwd(
                               tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
 }
 
+namespace gspl {
+static int rasterize_inria_bwd_impl(
+    int degree, int n_coeffs,
+    const float* means3D, const float* scales, const float* rotations, const float* shs, const float* shs_rest, const float* opacities,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+    float tanfovx, float tanfovy, float scale_modifier,
+    const int32_t* radii, const gspl_inria_state* st, const float* v_out_color,
+    float* packed, uint8_t* hit_flags,
+    float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_shs_rest, float* v_colors_precomp, float* v_opacities,
+    float* v_scales, float* v_rotations, float* v_cov3D, void* stream, const gspl_bwd_adam_plan* plan);
+}
+
 extern "C" int gspl_rasterize_inria_bwd(
+    int degree, int n_coeffs,
+    const float* means3D, const float* scales, const float* rotations, const float* shs, const float* shs_rest, const float* opacities,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+    float tanfovx, float tanfovy, float scale_modifier,
+    const int32_t* radii, const gspl_inria_state* st, const float* v_out_color,
+    float* packed, uint8_t* hit_flags,
+    float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_shs_rest, float* v_colors_precomp, float* v_opacities,
+    float* v_scales, float* v_rotations, float* v_cov3D, void* stream) {
+    return gspl::rasterize_inria_bwd_impl(degree, n_coeffs, means3D, scales, rotations, shs, shs_rest, opacities, viewmatrix, projmatrix, campos, bg,
+                                          tanfovx, tanfovy, scale_modifier, radii, st, v_out_color, packed, hit_flags, v_means3D, v_means2D_ndc, v_shs,
+                                          v_shs_rest, v_colors_precomp, v_opacities, v_scales, v_rotations, v_cov3D, stream, nullptr);
+}
+
+// The same backward with the optimizer INSIDE it: the per-Gaussian kernels at the end of the backward (SH backward,
+// preprocess backward) apply the Adam update to the parameter rows they have just produced the gradient of, instead of writing
+// 236 B of gradient per Gaussian for a separate optimizer launch to read back.  The parameters are updated IN PLACE; only the
+// screen-space gradient (what the density controller reads, vanilla_density_controller.py:101-123) is written.
+extern "C" int gspl_rasterize_inria_bwd_adam(
+    int degree, int n_coeffs,
+    float* means3D, float* scales, float* rotations, float* shs, float* shs_rest, float* opacities,
+    const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+    float tanfovx, float tanfovy, float scale_modifier,
+    const int32_t* radii, const gspl_inria_state* st, const float* v_out_color,
+    float* packed, uint8_t* hit_flags, float* scratch_means, float* v_means2D_ndc, const gspl_bwd_adam_plan* plan, void* stream) {
+    if (!plan) return gspl::fail_arg("rasterize_inria_bwd_adam: NULL plan");
+    if (!scales || !rotations || !shs || !opacities) return gspl::fail_arg("rasterize_inria_bwd_adam: needs scales, rotations, SH coefficients and opacities");
+    return gspl::rasterize_inria_bwd_impl(degree, n_coeffs, means3D, scales, rotations, shs, shs_rest, opacities, viewmatrix, projmatrix, campos, bg,
+                                          tanfovx, tanfovy, scale_modifier, radii, st, v_out_color, packed, hit_flags, scratch_means, v_means2D_ndc, shs,
+                                          shs_rest, nullptr, opacities, scales, rotations, nullptr, stream, plan);
+}
+
+static int gspl::rasterize_inria_bwd_impl(
     int degree, int n_coeffs,
     const float* means3D, const float* scales, const float* rotations, const float* shs, const float* shs_rest, const float* opacities,
     const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
@@ -322,7 +366,7 @@ extern "C" int gspl_rasterize_inria_bwd(
     const int32_t* radii, const gspl_inria_state* st, const float* v_out_color,
     float* packed /* [N, 9] scratch */, uint8_t* hit_flags,
     float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_shs_rest, float* v_colors_precomp, float* v_opacities,
-    float* v_scales, float* v_rotations, float* v_cov3D, void* stream) {
+    float* v_scales, float* v_rotations, float* v_cov3D, void* stream, const gspl_bwd_adam_plan* plan) {
     using namespace gspl;
     if (!st || st->N < 0) return fail_arg("rasterize_inria_bwd: bad state");
     const int N = st->N, width = st->width, height = st->height;
@@ -352,5 +396,5 @@ extern "C" int gspl_rasterize_inria_bwd(
     return inria_preprocess_bwd_impl(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
                                      tanfovx, tanfovy, scale_modifier, radii, st->clamped, packed, packed + 2, packed + 6, 9, v_means3D, v_scales,
                                      v_rotations, v_cov3D, v_shs, v_shs_rest, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac,
-                                     raw ? st->opacities : nullptr, s);
+                                     raw ? st->opacities : nullptr, s, plan);
 }

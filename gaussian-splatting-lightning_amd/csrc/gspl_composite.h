@@ -14,15 +14,43 @@ static constexpr int TILE = 16;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// sigma = 0.5 (a dx^2 + c dy^2) + b dx dy, written with explicit fma so that forward and backward
-// evaluate bit-identical values (the skip / stop decisions of the two passes must agree).
-__device__ __forceinline__ float eval_sigma(float half_a, float b, float half_c, float dx, float dy) {
-    return fmaf(half_a * dx, dx, fmaf(half_c * dy, dy, (b * dx) * dy));
+// sigma = 0.5 (a dx^2 + c dy^2) + b dx dy, evaluated in the FACTORED form
+//     sigma = ha u^2 + hd dy^2,   u = dx + k dy,   ha = a / 2,  k = b / a,  hd = (c - b^2 / a) / 2 = det / (2 a).
+// Why (round 5): the three-term form cancels.  A long anisotropic splat (a trained scene's "needles": footprints of hundreds of
+// pixels, a c / det ~ 1e4) has a dx^2, c dy^2 and 2 b dx dy ~ 1e5-1e6 each for a sum of ~5 on its ridge, and fp32 then carries an
+// absolute error of 1e-3 ... 4e-2 in sigma — 0.1 ... 4 % in alpha, far outside the 2e-5 band in which the oracle calls a 1/255
+// decision fragile (tests/test_locked_parity.py on `synthetic.scene_surfaces`: robust pixels off by one flipped splat, 2.8e-3).
+// Both terms of the factored form are products of the same sign; what is left is the rounding of u (1e-7 x the distance to the
+// centre): measured worst |d sigma| over the 3000 largest splats of that scene 1.5e-3 -> 1e-5.  Same instruction count per pixel
+// pair.  The forward and the backward evaluate bit-identical values (their skip / stop decisions must agree): explicit fma, one
+// definition, and the per-splat factors come from `sigma_coef` in both.
+struct SigmaCoef { float ha, k, hd; };
+// (conic_det: gspl_device.h — a c - b^2 without the cancellation of its two products)
+__device__ __forceinline__ SigmaCoef sigma_coef(float a, float b, float c) {
+    SigmaCoef s;
+    s.ha = 0.5f * a;
+    if (a != 0.f) {
+        // k: a correctly rounded division — its rounding, times the distance to the centre, is what is left of sigma's error.  hd only
+        // scales the (positive, <= tau) second term: the 1-ulp hardware reciprocal is plenty
+        s.k = b / a;
+        s.hd = (0.5f * conic_det(a, b, c)) * __builtin_amdgcn_rcpf(a);
+    } else {
+        // a == 0: sigma = b dx dy + c dy^2 / 2.  With b == 0 that IS the factored form (k = 0, hd = c / 2); with b != 0 the matrix is
+        // indefinite (det = -b^2 < 0) — not a Gaussian: such a splat is never composited (sigma = NaN fails every `sigma >= 0`)
+        s.k = 0.f;
+        s.hd = (b == 0.f) ? 0.5f * c : __builtin_nanf("");
+    }
+    return s;
+}
+__device__ __forceinline__ float eval_sigma(float ha, float k, float hd, float dx, float dy) {
+    const float u = fmaf(k, dy, dx);
+    return fmaf(ha * u, u, (hd * dy) * dy);
 }
 
 // Two splats (or two pixels) at once with packed fp32 math; each component is bit-identical to eval_sigma.
-__device__ __forceinline__ v2f eval_sigma2(v2f half_a, v2f b, v2f half_c, v2f dx, v2f dy) {
-    return __builtin_elementwise_fma(half_a * dx, dx, __builtin_elementwise_fma(half_c * dy, dy, (b * dx) * dy));
+__device__ __forceinline__ v2f eval_sigma2(v2f ha, v2f k, v2f hd, v2f dx, v2f dy) {
+    const v2f u = __builtin_elementwise_fma(k, dy, dx);
+    return __builtin_elementwise_fma(ha * u, u, (hd * dy) * dy);
 }
 
 // Exact test "can this splat reach alpha >= 1/255 at some pixel centre of the box [x0,x1] x [y0,y1]" (continuous box,
@@ -35,7 +63,7 @@ __device__ __forceinline__ bool box_reachable(float mx, float my, float a, float
                                               float x0, float x1, float y0, float y1) {
     const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
     if (!(tau > 0.f)) return false;
-    const float det = a * c - b * b;
+    const float det = conic_det(a, b, c);
     if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return true;     // not an ellipse: never cull
     const float two_tau = 2.f * tau;
     const float rdet = __builtin_amdgcn_rcpf(det);
@@ -64,7 +92,7 @@ __device__ __forceinline__ unsigned band_half_mask(float mx, float my, float a, 
     constexpr float BH = (float)(TILE / BANDS);
     const float tau = __logf(255.f * opacity) * 1.0002f + 2e-4f;
     if (!(tau > 0.f)) return 0u;
-    const float det = a * c - b * b;
+    const float det = conic_det(a, b, c);
     if (!(det > 0.f) || !(a > 0.f) || !(c > 0.f)) return (1u << (2 * BANDS)) - 1u;      // not an ellipse: never cull
     const float two_tau = 2.f * tau;
     const float rdet = __builtin_amdgcn_rcpf(det);

@@ -388,6 +388,29 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// a c - b^2 without the cancellation of its two products (Kahan): w = fl(b b), e = w - b b exactly, f = fl(a c - w); det = f + e
+__device__ __forceinline__ float conic_det(float a, float b, float c) {
+    const float w = b * b;
+    const float e = fmaf(-b, b, w);
+    const float f = fmaf(a, c, -w);
+    return f + e;
+}
+
+// One element of the Adam update (adam.hip; the per-Gaussian kernels of the backward in their Adam-applying form, sh.hip / inria.hip).
+// Written with explicit fmaf so that every translation unit contracts it the same way: the two-kernel path (gradient written, read
+// back by selective_adam_kernel) and the update inside the backward are bit-identical for identical gradients.
+//     m = b1 m + (1 - b1) g;   v = b2 v + (1 - b2) g^2;   p -= step m / (sqrt(v) inv_bc2 + eps)
+struct AdamHyper { float step, b1, b2, inv_bc2, eps; };      // step = lr * (1 / bias_correction1), inv_bc2 = 1 / bias_correction2_sqrt: as selective_adam_kernel forms them
+struct AdamTarget { float* p; float* m; float* v; AdamHyper h; };
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float step, float b1, float b2, float inv_bc2, float eps) {
+    m = fmaf(b1, m, (1.f - b1) * g);
+    v = fmaf(b2, v, ((1.f - b2) * g) * g);
+    p -= (step * m) / fmaf(sqrtf(v), inv_bc2, eps);
+}
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamHyper& h) {
+    adam_elem(p, g, m, v, h.step, h.b1, h.b2, h.inv_bc2, h.eps);
+}
+
 // XCD-aware tile order.  The dispatcher places workgroup b on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"),
 // and each XCD runs its workgroups in increasing b.  Units are dealt to the XCDs in RUNS of `run` consecutive units
 // (run r -> XCD r % 8): neighbouring tiles of a run share splat records (L2 hits inside the XCD), while all eight XCDs

@@ -40,11 +40,15 @@ int sh_fwd_launch(int N, int C, int degree, const float* dirs, const float* orig
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags,
                   float* colors, uint8_t* clamped, void* stream, float* jac /* nullable [N,9]: d colour / d unit direction */);
+// Adam applied inside the per-Gaussian backward kernels (gspl_rasterize_inria_bwd_adam): moments + hyper-parameters of one parameter
+typedef gspl_bwd_adam_tensor ShAdamTargetHost;
+struct ShAdamHost { ShAdamTargetHost dc, rest; };
 int sh_bwd_launch(int N, int C, int degree, int n_coeffs, const float* dirs, const float* origin,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream,
-                  const float* jac /* nullable: the forward's Jacobian; v_dirs then needs no coefficient read */);
+                  const float* jac /* nullable: the forward's Jacobian; v_dirs then needs no coefficient read */,
+                  const ShAdamHost* adam /* nullable; not NULL: v_dc / v_rest are the PARAMETERS, updated in place, no gradient is written */);
 // binning.hip -> fused.hip: gspl_bin_count whose scan stores `ticket` into host_counts[2] after the two numbers
 int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii, const float* depths, const float* conics, const float* opacities,
                      int tile_size, int tile_w, int tile_h, int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
@@ -64,5 +68,7 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs, const float* mean
                               float* v_means, float* v_scales, float* v_quats,
                               float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
                               float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac,
-                              const float* opac_act /* nullable: activated parameters */, void* stream);
+                              const float* opac_act /* nullable: activated parameters */, void* stream,
+                              const gspl_bwd_adam_plan* adam = nullptr /* not NULL: v_shs / v_shs_rest / v_scales / v_quats / v_opacities are
+                              the PARAMETERS (as means, scales, quats are), updated in place; v_means is scratch [N,3] */);
 }  // namespace gspl

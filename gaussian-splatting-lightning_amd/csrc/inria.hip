@@ -16,6 +16,11 @@
 // GSPL_SH_ADD_HALF_CLAMP, masked by radii); backward writes dL/d(dir) into v_means first and the
 // geometry kernel then accumulates the projection/covariance terms on top.
 // Roofline: HBM-bound elementwise.
+// Floating-point contraction as the LANGUAGE defines it (a * b + c inside one expression), not as the back end finds it: the
+// gradient-writing and the Adam-applying instantiations of the backward kernels below must produce bit-identical gradient values
+// (tests/test_fused_backward_adam.py), and -ffp-contract=fast (hipcc's default) lets the DAG combiner fuse across statements
+// differently in each instantiation (measured: the means' gradient differed in its last bit from the third step on).
+#pragma clang fp contract(on)
 #include "gspl_device.h"
 #include "gspl_host.h"
 
@@ -203,10 +208,15 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
 // strided loads cost bandwidth; the kernel carries ~400 flops per Gaussian between its loads and its stores.)
 // RAW: `scales` / `quats` are the raw parameters and v_scales / v_quats / v_opac_dst their gradients (chain rule of exp, normalize,
 // sigmoid: v s, (v - q (q.v)) / |raw|, v o (1 - o)); `opac_act` = the activated opacities the forward stored.
-template <bool ACCUM, bool RAW>
+// ADAM: v_means is SCRATCH (the SH backward's direction gradient, read, not written), v_scales / v_quats / v_opac_dst are not written:
+// the kernel applies the Adam update to the rows of means, scales, rotations and opacities it has just produced the gradient of
+// (`adam`: parameter, moments, hyper-parameters; every row, the invisible ones with a zero gradient, as torch.optim.Adam does).
+// The parameters are read and written through `adam.*.p` (no __restrict__ promise on memory this kernel writes).
+struct PreAdam { AdamTarget means, scales, quats, opac; };
+template <bool ACCUM, bool RAW, bool ADAM = false>
 __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     int N,
-    const float* __restrict__ means, const float* __restrict__ scales, const float* __restrict__ quats,
+    const float* means, const float* scales, const float* quats,
     const float* __restrict__ cov3d,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix,
     int width, int height, float tanfovx, float tanfovy, float scale_modifier,
@@ -214,13 +224,19 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     const float* __restrict__ v_means2d, const float* __restrict__ v_conics, int gs2, int gs3,
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
     float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc,
-    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst, const float* __restrict__ opac_act) {
+    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst, const float* __restrict__ opac_act, PreAdam adam) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= N) return;
-    if (v_opac_dst) {
+    if (ADAM || v_opac_dst) {
         float v = v_opac_src[(int64_t)g * gs2];
         if constexpr (RAW) { const float o = opac_act[g]; v *= o * (1.f - o); }
-        v_opac_dst[g] = v;
+        if constexpr (ADAM) {
+            float p = adam.opac.p[g], m = adam.opac.m[g], w = adam.opac.v[g];
+            adam_elem(p, v, m, w, adam.opac.h);
+            adam.opac.p[g] = p; adam.opac.m[g] = m; adam.opac.v[g] = w;
+        } else {
+            v_opac_dst[g] = v;
+        }
     }
     float vp[3] = {0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
     float G6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 3; ++r) vp[r] += cam.V[r * 4 + 0] * vpv[0] + cam.V[r * 4 + 1] * vpv[1] + cam.V[r * 4 + 2] * vpv[2];
 
-        if (v_scales) {
+        if (ADAM || v_scales) {
             float s[3] = {scales[g * 3 + 0], scales[g * 3 + 1], scales[g * 3 + 2]};
             float q[4] = {quats[g * 4 + 0], quats[g * 4 + 1], quats[g * 4 + 2], quats[g * 4 + 3]};
             float act_s[3] = {1.f, 1.f, 1.f}, inv_norm = 1.f;
@@ -276,6 +292,24 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
                 for (int j = 0; j < 4; ++j) vq[j] = (vq[j] - q[j] * qv) * inv_norm;
             }
         }
+    }
+    if constexpr (ADAM) {
+        // the gradient rows never reach HBM: parameter + moments are read, updated, written (same sums, in the same order, as the
+        // gradient-writing form below: bit-identical parameters for identical inputs)
+        auto apply = [&](const AdamTarget& T, int row, int j, float grad) {
+            const int64_t e = (int64_t)g * row + j;
+            float p = T.p[e], m = T.m[e], w = T.v[e];
+            adam_elem(p, grad, m, w, T.h);
+            T.p[e] = p; T.m[e] = m; T.v[e] = w;
+        };
+#pragma unroll
+        for (int j = 0; j < 3; ++j) apply(adam.means, 3, j, ACCUM ? v_means[g * 3 + j] + vp[j] : vp[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) apply(adam.scales, 3, j, vs[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) apply(adam.quats, 4, j, vq[j]);
+        v_means2d_ndc[g * 3 + 0] = ndc[0]; v_means2d_ndc[g * 3 + 1] = ndc[1]; v_means2d_ndc[g * 3 + 2] = 0.f;
+        return;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -381,8 +415,21 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs,
                                          float* v_means, float* v_scales, float* v_quats,
                                          float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
                                          float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac,
-                                         const float* opac_act, void* stream) {
+                                         const float* opac_act, void* stream, const gspl_bwd_adam_plan* plan) {
     if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
+    if (plan) {
+        // Adam inside the backward: v_shs / v_shs_rest / v_scales / v_quats / v_opacities ARE the parameters (means, scales, quats too)
+        if (!v_shs || !v_scales || !v_quats || !v_opacities || v_cov3d_precomp || v_colors_precomp || grad_stride <= 0)
+            return fail_arg("inria_preprocess_bwd(adam): needs SH coefficients, scales + rotations and the packed gradient buffer");
+        if (v_scales != scales || v_quats != quats || v_shs != shs || v_shs_rest != shs_rest)
+            return fail_arg("inria_preprocess_bwd(adam): the update targets must be the parameters the backward reads");
+        const gspl_bwd_adam_tensor* all[6] = {&plan->means, &plan->scales, &plan->rotations, &plan->opacities, &plan->shs, &plan->shs_rest};
+        for (int k = 0; k < 6; ++k) {
+            if (k == 5 && !shs_rest) continue;
+            if (!all[k]->exp_avg || !all[k]->exp_avg_sq || !(all[k]->bias_correction1 > 0.f) || !(all[k]->bias_correction2_sqrt > 0.f))
+                return fail_arg("inria_preprocess_bwd(adam): moments missing or bias corrections not positive (1 = none)");
+        }
+    }
     if (v_opacities && (!v_opacities_packed || grad_stride <= 0)) return fail_arg("inria_preprocess_bwd: v_opacities needs the packed gradient buffer");
     if (N == 0) return GSPL_OK;
     if (!means || !cov3d || !viewmatrix || !projmatrix || !radii || !v_means2d || !v_conics || !v_colors || !v_means || !v_means2d_ndc)
@@ -401,11 +448,14 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs,
         const int stride = 3 * n_coeffs;
         // dL/d(dir) lands in v_means; the geometry kernel accumulates on top
         if ((shs_rest == nullptr) != (v_shs_rest == nullptr)) return fail_arg("inria_preprocess_bwd: shs_rest and v_shs_rest go together");
+        ShAdamHost sh_adam;
+        if (plan) { sh_adam.dc = plan->shs; sh_adam.rest = shs_rest ? plan->shs_rest : plan->shs; }
+        const ShAdamHost* sha = plan ? &sh_adam : nullptr;
         int rc = shs_rest
             ? sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, 3, shs_rest, stride - 3, nullptr, radii,
-                            GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs_rest, v_means, stream, sh_jac)
+                            GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs_rest, v_means, stream, sh_jac, sha)
             : sh_bwd_launch(N, 1, degree, n_coeffs, means, campos, shs, stride, shs + 3, stride, nullptr, radii,
-                            GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream, sh_jac);
+                            GSPL_SH_ADD_HALF_CLAMP, clamped, v_colors, gs3, v_shs, v_shs + 3, v_means, stream, sh_jac, sha);
         if (rc != GSPL_OK) return rc;
         accum = true;
     }
@@ -415,11 +465,22 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs,
         if (rc != GSPL_OK) return rc;
     }
     if (opac_act && (!v_scales || !v_opacities || v_cov3d_precomp)) return fail_arg("inria_preprocess_bwd: raw parameters need v_scales, v_quats and v_opacities");
-#define GSPL_LAUNCH_PRE_BWD(A, R) hipLaunchKernelGGL((inria_preprocess_bwd_kernel<A, R>), dim3(grid), dim3(256), 0, s, \
+    PreAdam pre = {};
+    if (plan) {
+        auto target = [](float* p, const gspl_bwd_adam_tensor& t) {
+            return AdamTarget{p, t.exp_avg, t.exp_avg_sq, AdamHyper{t.lr * (1.f / t.bias_correction1), t.beta1, t.beta2, 1.f / t.bias_correction2_sqrt, t.eps}};
+        };
+        pre.means = target(const_cast<float*>(means), plan->means);
+        pre.scales = target(v_scales, plan->scales);
+        pre.quats = target(v_quats, plan->rotations);
+        pre.opac = target(v_opacities, plan->opacities);
+    }
+#define GSPL_LAUNCH_PRE_BWD(A, R, AD) hipLaunchKernelGGL((inria_preprocess_bwd_kernel<A, R, AD>), dim3(grid), dim3(256), 0, s, \
         N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier, \
-        radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities, opac_act)
-    if (accum) { if (opac_act) GSPL_LAUNCH_PRE_BWD(true, true); else GSPL_LAUNCH_PRE_BWD(true, false); }
-    else { if (opac_act) GSPL_LAUNCH_PRE_BWD(false, true); else GSPL_LAUNCH_PRE_BWD(false, false); }
+        radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities, opac_act, pre)
+    if (plan) { if (opac_act) GSPL_LAUNCH_PRE_BWD(true, true, true); else GSPL_LAUNCH_PRE_BWD(true, false, true); }
+    else if (accum) { if (opac_act) GSPL_LAUNCH_PRE_BWD(true, true, false); else GSPL_LAUNCH_PRE_BWD(true, false, false); }
+    else { if (opac_act) GSPL_LAUNCH_PRE_BWD(false, true, false); else GSPL_LAUNCH_PRE_BWD(false, false, false); }
 #undef GSPL_LAUNCH_PRE_BWD
     return check_launch("inria_preprocess_bwd");
 }
@@ -438,5 +499,5 @@ extern "C" int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
     return gspl::inria_preprocess_bwd_impl(N, degree, n_coeffs, means, scales, quats, cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
                                            tanfovx, tanfovy, scale_modifier, radii, clamped, v_means2d, v_conics, v_colors, grad_stride, v_means, v_scales,
                                            v_quats, v_cov3d_precomp, v_shs, v_shs_rest, v_colors_precomp, v_means2d_ndc, v_opacities_packed, v_opacities,
-                                           sh_jac, nullptr, stream);
+                                           sh_jac, nullptr, stream, nullptr);
 }

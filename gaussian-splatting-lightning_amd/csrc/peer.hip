@@ -70,6 +70,9 @@ extern "C" int gspl_peer_alloc(size_t bytes, void** ptr, void* handle_out /* 64 
     hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) return check_hip(e, "peer_alloc: hipExtMallocWithFlags(fine-grained)");
     e = hipMemset(p, 0, bytes);
+    // the fill of DEVICE memory may still be executing when hipMemset returns: it must be over before the handle leaves this process
+    // (a late fill would wipe a peer's first flag store: a spurious wait time-out)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(p); return check_hip(e, "peer_alloc: clear"); }
     hipIpcMemHandle_t h;
     e = hipIpcGetMemHandle(&h, p);

@@ -12,6 +12,11 @@
 // workgroup streams its 256 rows as one flat, fully coalesced 16-B-per-lane copy into LDS
 // (odd row stride -> conflict-free), and lanes then read their own row from LDS.  Backward writes
 // the coefficient gradients the same way in reverse.
+// Floating-point contraction as the LANGUAGE defines it (a * b + c inside one expression), not as the back end finds it: the
+// gradient-writing and the Adam-applying instantiations of the backward kernels below must produce bit-identical gradient values
+// (tests/test_fused_backward_adam.py), and -ffp-contract=fast (hipcc's default) lets the DAG combiner fuse across statements
+// differently in each instantiation (measured: the means' gradient differed in its last bit from the third step on).
+#pragma clang fp contract(on)
 #include "gspl_device.h"
 #include "gspl_host.h"
 
@@ -183,6 +188,62 @@ __device__ __forceinline__ void tile_store(float* __restrict__ g, int rows, int 
     }
 }
 
+// The Adam-applying counterpart of tile_store (backward kernels of the "update inside the backward" form): the rows of
+// LDS hold the GRADIENT of `rows` rows x `rs` floats; parameter and moments are streamed through once, flat and coalesced, 16 bytes
+// per lane (two chunks = six loads in flight per lane), updated and written back — the gradient never reaches HBM.
+__device__ __forceinline__ void tile_adam(const AdamTarget& T, int64_t base, int rows, int rs, int ls, float inv_rs, const float* lds, bool vec_ok) {
+    const int total = rows * rs;
+    const int t = threadIdx.x;
+    float* __restrict__ gp = T.p + base;
+    float* __restrict__ gm = T.m + base;
+    float* __restrict__ gv = T.v + base;
+    int done = 0;
+    if (vec_ok) {
+        const int n4 = total >> 2;
+        float4* p4 = reinterpret_cast<float4*>(gp);
+        float4* m4 = reinterpret_cast<float4*>(gm);
+        float4* v4 = reinterpret_cast<float4*>(gv);
+        for (int b4 = t; b4 < n4; b4 += 2 * SH_BLOCK) {
+            float4 p[2], m[2], v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e4 = b4 + u * SH_BLOCK;
+                if (e4 < n4) { p[u] = sh_load16(p4 + e4); m[u] = sh_load16(m4 + e4); v[u] = sh_load16(v4 + e4); }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e4 = b4 + u * SH_BLOCK;
+                if (e4 >= n4) continue;
+                float g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e4 * 4 + k;
+                    const int row = (int)(((float)e + 0.5f) * inv_rs);
+                    g[k] = lds[row * ls + (e - row * rs)];
+                }
+                adam_elem(p[u].x, g[0], m[u].x, v[u].x, T.h);
+                adam_elem(p[u].y, g[1], m[u].y, v[u].y, T.h);
+                adam_elem(p[u].z, g[2], m[u].z, v[u].z, T.h);
+                adam_elem(p[u].w, g[3], m[u].w, v[u].w, T.h);
+                p4[e4] = p[u];                       // read again by the next frame's colour kernel: a plain store
+                sh_store16(m4 + e4, m[u]);
+                sh_store16(v4 + e4, v[u]);
+            }
+        }
+        done = n4 << 2;
+    }
+    for (int e = done + t; e < total; e += SH_BLOCK) {
+        const int row = (int)(((float)e + 0.5f) * inv_rs);
+        float p = gp[e], m = gm[e], v = gv[e];
+        adam_elem(p, lds[row * ls + (e - row * rs)], m, v, T.h);
+        gp[e] = p; gm[e] = m; gv[e] = v;
+    }
+}
+
+// Adam targets of sh_bwd_kernel<.., ADAM = true>: `tile` = the parameter the staged rows belong to (shs_rest, or the merged shs),
+// `dc` = the separate DC parameter ([N, 1, 3]; unused when merged)
+struct ShAdam { AdamTarget tile, dc; };
+
 // tile geometry:
 //   merged  : tile rows are the full [K,3] rows starting at dc (row stride rs = dc_stride), dc at col 0
 //   separate: tile rows are the `rest` rows (row stride rs = rest_stride); dc is read per lane
@@ -269,14 +330,16 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_fwd_kernel(
 }
 
 // WITH_DIRS: also produce v_dirs (needs the coefficients -> stages them first).
-template <int DEG, bool WITH_DIRS>
+// ADAM: the coefficient gradients are not written: the kernel applies the Adam update to the coefficient rows it has just produced the
+// gradient of (tile_adam; v_dc / v_rest are then only consulted for the layout, `adam` carries parameter, moments and hyper-parameters).
+template <int DEG, bool WITH_DIRS, bool ADAM = false>
 __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
     int N, int C, int n_coeffs,
     const float* __restrict__ dirs, const float* __restrict__ origin,
     const float* __restrict__ dc, int dc_stride, const float* __restrict__ rest,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ mask32, int flags, const uint8_t* __restrict__ clamped,
     const float* __restrict__ v_colors, int vc_stride, ShTile tile, int vec_ok_in, int vec_ok_out,
-    float* __restrict__ v_dc, float* __restrict__ v_rest, float* __restrict__ v_dirs, const float* __restrict__ jac) {
+    float* __restrict__ v_dc, float* __restrict__ v_rest, float* __restrict__ v_dirs, const float* __restrict__ jac, ShAdam adam) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int n0 = blockIdx.x * SH_BLOCK;
     const int rows = min(SH_BLOCK, N - n0);
@@ -388,14 +451,28 @@ __global__ __launch_bounds__(SH_BLOCK) void sh_bwd_kernel(
         }
         if (has_tile && tile.merged) { row[0] = d0[0]; row[1] = d0[1]; row[2] = d0[2]; }
         if (!tile.merged || !has_tile) {
+            if constexpr (ADAM) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v_dc[(int64_t)n * dc_stride + c] = d0[c];
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t e = (int64_t)n * dc_stride + c;
+                    float p = adam.dc.p[e], m = adam.dc.m[e], v = adam.dc.v[e];
+                    adam_elem(p, d0[c], m, v, adam.dc.h);
+                    adam.dc.p[e] = p; adam.dc.m[e] = m; adam.dc.v[e] = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v_dc[(int64_t)n * dc_stride + c] = d0[c];
+            }
         }
     }
     if (has_tile) {
         __syncthreads();
-        float* base = tile.merged ? v_dc + (int64_t)n0 * tile.rs : v_rest + (int64_t)n0 * tile.rs;
-        tile_store(base, rows, tile.rs, tile.ls, 1.f / (float)tile.rs, lds, vec_ok_out != 0);
+        if constexpr (ADAM) {
+            tile_adam(adam.tile, (int64_t)n0 * tile.rs, rows, tile.rs, tile.ls, 1.f / (float)tile.rs, lds, vec_ok_out != 0);
+        } else {
+            float* base = tile.merged ? v_dc + (int64_t)n0 * tile.rs : v_rest + (int64_t)n0 * tile.rs;
+            tile_store(base, rows, tile.rs, tile.ls, 1.f / (float)tile.rs, lds, vec_ok_out != 0);
+        }
     }
 }
 
@@ -465,8 +542,16 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs,
                   const float* dc, int dc_stride, const float* rest, int rest_stride,
                   const uint8_t* mask, const int32_t* mask32, int flags, const uint8_t* clamped,
                   const float* v_colors, int vc_stride,
-                  float* v_dc, float* v_rest, float* v_dirs, void* stream, const float* jac) {
+                  float* v_dc, float* v_rest, float* v_dirs, void* stream, const float* jac, const ShAdamHost* adam_host) {
     if (N < 0 || C < 1 || degree < 0 || degree > 4 || n_coeffs < (degree + 1) * (degree + 1)) return fail_arg("sh_bwd: bad N/C/degree/n_coeffs");
+    // adam_host: apply the Adam update instead of writing the coefficient gradients; v_dc / v_rest are then the PARAMETERS (the
+    // layout is decided on them as it would be on the gradient arrays, which have the parameters' strides)
+    ShAdam adam = {};
+    if (adam_host) {
+        if (C != 1 || !v_dirs) return fail_arg("sh_bwd: the Adam-applying form is the one-camera backward with the direction gradient");
+        if (!v_dc || !adam_host->dc.exp_avg || !adam_host->dc.exp_avg_sq || (n_coeffs > 1 && (!v_rest || !adam_host->rest.exp_avg || !adam_host->rest.exp_avg_sq)))
+            return fail_arg("sh_bwd: Adam targets missing");
+    }
     if (jac && !v_dirs) jac = nullptr;
     if (C > 1 && (v_dirs || !origin)) return fail_arg("sh_bwd: several cameras need their origins and give no direction gradient");
     if (N == 0) return GSPL_OK;
@@ -486,24 +571,33 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs,
     const float* in_base = tile.merged ? dc : rest;
     float* out_base = tile.merged ? v_dc : v_rest;
     const int vec_in = (in_base && aligned16(in_base)) ? 1 : 0;
-    const int vec_out = (out_base && aligned16(out_base)) ? 1 : 0;
+    int vec_out = (out_base && aligned16(out_base)) ? 1 : 0;
+    if (adam_host) {
+        auto target = [](float* p, const ShAdamTargetHost& t) {
+            return AdamTarget{p, t.exp_avg, t.exp_avg_sq, AdamHyper{t.lr * (1.f / t.bias_correction1), t.beta1, t.beta2, 1.f / t.bias_correction2_sqrt, t.eps}};
+        };
+        // merged: one parameter (dc + rest rows in one tensor) -> its moments are `dc`'s; separate: tile = rest, dc on its own
+        adam.tile = tile.merged ? target(v_dc, adam_host->dc) : target(v_rest, adam_host->rest);
+        adam.dc = target(v_dc, adam_host->dc);
+        if (n_coeffs > 1 && !(aligned16(adam.tile.p) && aligned16(adam.tile.m) && aligned16(adam.tile.v))) vec_out = 0;
+    }
     const size_t lds_bytes = n_coeffs > 1 ? (size_t)SH_BLOCK * tile.ls * sizeof(float) : 0;
     if (lds_bytes > 160 * 1024) return fail_arg("sh_bwd: coefficient row too long for LDS staging");
     const int grid = (N + SH_BLOCK - 1) / SH_BLOCK;
-#define GSPL_SH_BWD(DEG, WD)                                                                                          \
+#define GSPL_SH_BWD(DEG, WD, AD)                                                                                      \
     {                                                                                                                 \
         if (lds_bytes > 64 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sh_bwd_kernel<DEG, WD>),                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sh_bwd_kernel<DEG, WD, AD>),             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
             if (e != hipSuccess) return check_hip(e, "sh_bwd: hipFuncSetAttribute");                                  \
         }                                                                                                             \
-        hipLaunchKernelGGL((sh_bwd_kernel<DEG, WD>), dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, C, \
+        hipLaunchKernelGGL((sh_bwd_kernel<DEG, WD, AD>), dim3(grid), dim3(SH_BLOCK), lds_bytes, (hipStream_t)stream, N, C, \
                            n_coeffs, dirs, origin, dc, dc_stride, rest, mask, mask32, flags, clamped, v_colors, vc_stride, tile, vec_in, \
-                           vec_out, v_dc, v_rest, v_dirs, jac);                                                       \
+                           vec_out, v_dc, v_rest, v_dirs, jac, adam);                                                 \
     }
 #define GSPL_SH_BWD_CASE(DEG) \
     case DEG:                 \
-        if (v_dirs) GSPL_SH_BWD(DEG, true) else GSPL_SH_BWD(DEG, false) break;
+        if (adam_host) GSPL_SH_BWD(DEG, true, true) else if (v_dirs) GSPL_SH_BWD(DEG, true, false) else GSPL_SH_BWD(DEG, false, false) break;
     switch (degree) { GSPL_SH_BWD_CASE(0) GSPL_SH_BWD_CASE(1) GSPL_SH_BWD_CASE(2) GSPL_SH_BWD_CASE(3) GSPL_SH_BWD_CASE(4) }
 #undef GSPL_SH_BWD_CASE
 #undef GSPL_SH_BWD
@@ -518,7 +612,7 @@ extern "C" int gspl_sh_bwd(int N, int degree, int n_coeffs,
                            const float* v_colors, int v_colors_stride,
                            float* v_dc, float* v_rest, float* v_dirs, void* stream) {
     return gspl::sh_bwd_launch(N, 1, degree, n_coeffs, dirs, origin, dc, dc_stride, rest, rest_stride, mask, nullptr, flags, clamped, v_colors,
-                               v_colors_stride > 0 ? v_colors_stride : 3, v_dc, v_rest, v_dirs, stream, nullptr);
+                               v_colors_stride > 0 ? v_colors_stride : 3, v_dc, v_rest, v_dirs, stream, nullptr, nullptr);
 }
 
 // Backward of gspl_sh_fwd_batched: v_colors [C,N,3] (dense) -> v_dc / v_rest summed over the cameras, written once.
@@ -528,5 +622,5 @@ extern "C" int gspl_sh_bwd_batched(int C, int N, int degree, int n_coeffs,
                                    const int32_t* radii, int flags, const uint8_t* clamped,
                                    const float* v_colors, float* v_dc, float* v_rest, void* stream) {
     return gspl::sh_bwd_launch(N, C, degree, n_coeffs, means, origins, nullptr, dc_stride, nullptr, rest_stride, nullptr, radii, flags, clamped,
-                               v_colors, 3, v_dc, v_rest, nullptr, stream, nullptr);
+                               v_colors, 3, v_dc, v_rest, nullptr, stream, nullptr, nullptr);
 }

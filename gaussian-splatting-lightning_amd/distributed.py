@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -136,6 +138,17 @@ class HostMailbox:
         self.rank, self.group = int(rank), group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.width, self.seq = int(width), 0
+        # the collectives' patience, not a few seconds: a rank that writes a checkpoint or logs images keeps the others waiting here
+        self.timeout_s = float(os.environ.get("GSPL_MAILBOX_TIMEOUT_S", "1800"))
+        if self.world > 1:
+            # ONE node, verified collectively: on a second node `SharedMemory(name=...)` would fail on those ranks only and leave
+            # the first node's ranks in the barrier below — every rank raises, or none
+            import socket
+            hosts = [None] * self.world
+            dist.all_gather_object(hosts, socket.gethostname(), group=group)
+            if len(set(hosts)) != 1:
+                raise RuntimeError(f"HostMailbox: the ranks of the group run on {len(set(hosts))} hosts ({sorted(set(hosts))}); shared host memory "
+                                   "(and the peer transport that uses it) is a one-node transport — use exchange_transport='collective'")
         # two copies of the table, used alternately: a rank can be one call ahead of the slowest reader of the previous call (never
         # two: the call after the next needs everybody's rows of the next), so its new row must not land where that reader looks
         nbytes = 8 * 2 * self.world * (self.width + 1)
@@ -172,9 +185,11 @@ class HostMailbox:
         if self.world > 1:
             dist.barrier(group=group)
 
-    def exchange(self, values: Sequence[int], timeout_s: float = 120.0) -> List[List[int]]:
-        """My row in, everybody's rows out (rank order); blocks until every rank has posted its row of this call."""
+    def exchange(self, values: Sequence[int], timeout_s: Optional[float] = None) -> List[List[int]]:
+        """My row in, everybody's rows out (rank order); blocks until every rank has posted its row of this call (at most `timeout_s`
+        seconds, default `self.timeout_s` = GSPL_MAILBOX_TIMEOUT_S or 1800: the scale of a process group's timeout)."""
         import time
+        timeout_s = self.timeout_s if timeout_s is None else timeout_s
         self.seq += 1
         table = self._rows[self.seq & 1]
         table[self.rank, :self.width] = [int(v) for v in values]
@@ -221,7 +236,10 @@ class PeerExchange:
     Buffers grow (x 1.5, identically on every rank) when the Gaussian counts outgrow them; the handles are exchanged again then."""
 
     FLOATS = RECORD_FLOATS
-    MAX_POLLS = 4_000_000          # ~ a few seconds of polling before a wait gives up and raises the error word
+    # Polls (~1 us each) before a device-side wait gives up and raises the error word instead of hanging the GPU.  A collective would
+    # block for the process group's timeout (minutes): the default is of that scale — a peer that is merely slow (a first-use path, an
+    # allocator stall, a checkpoint on another rank) must not turn into an error; GSPL_PEER_MAX_POLLS overrides it.
+    MAX_POLLS = int(os.environ.get("GSPL_PEER_MAX_POLLS", "120000000"))
 
     def __init__(self, rank: int, group, device):
         self.rank, self.group, self.device = int(rank), group, torch.device(device)
@@ -234,6 +252,10 @@ class PeerExchange:
         self._mine = None
         self._opened: List[int] = []
         self._layout = None
+        # the waits' error word lives in PINNED HOST memory: the wait kernel stores into it, the host reads it without a
+        # synchronisation — `check()` is free and runs on every step (a wait that gave up is an exception on the next step at the
+        # latest, never a silent stretch of steps over stale rows)
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else torch.zeros(1, dtype=torch.int32)
 
     # ---- layout (identical on every rank) -----------------------------------------------------------------------------
     def _plan(self, cap_total: int, cap_rank: int):
@@ -328,12 +350,13 @@ class PeerExchange:
         self._mine, self._opened, self.base = None, [], []
 
     def check(self):
-        """Raises if a wait of this rank gave up (a peer that never signalled).  Synchronises the current stream."""
-        if self._mine is None:
-            return
-        err = int(torch.as_tensor(_DevicePtr(self._mine + self._layout["err"], (1,), "<i4"), device=self.device).item())
+        """Raises if a wait of this rank gave up (a peer that never signalled) — as soon as the kernel that gave up has run; no
+        synchronisation (the word is in pinned host memory).  Clears the word: the exchange can be used again (or torn down)."""
+        err = int(self._err_host[0])
         if err:
-            raise RuntimeError(f"PeerExchange: rank {self.rank} gave up waiting for the records of rank {err - 1} (step {self.step})")
+            self._err_host[0] = 0
+            raise RuntimeError(f"PeerExchange: rank {self.rank} gave up waiting for the records of rank {err - 1} after {self.MAX_POLLS} polls "
+                               f"(step {self.step}); rows received since then are stale")
 
     # ---- one exchange ---------------------------------------------------------------------------------------------------
     def _send(self, rows: torch.Tensor, begin: List[int], dst: List[int], flag_dst: List[int], my_flags: int, value: int):
@@ -344,7 +367,7 @@ class PeerExchange:
         with torch.cuda.device(self.device):
             L.call("gspl_peer_put_rows", W, L.ptr(rows), (ctypes.c_int64 * (W + 1))(*begin), (ctypes.c_void_p * W)(*dst), self.FLOATS, L.stream())
             L.call("gspl_peer_signal", W, (ctypes.c_void_p * W)(*flag_dst), value, L.stream())
-            L.call("gspl_peer_wait", ctypes.c_void_p(my_flags), W, value, self.MAX_POLLS, ctypes.c_void_p(self._mine + self._layout["err"]), L.stream())
+            L.call("gspl_peer_wait", ctypes.c_void_p(my_flags), W, value, self.MAX_POLLS, ctypes.c_void_p(self._err_host.data_ptr()), L.stream())
 
     def route(self, rows_per_rank: Sequence[int], matrix: Optional[Sequence[Sequence[int]]] = None):
         """(forward, backward) callables for `ops.sharded_exchange`, as `all_to_all_route` returns them, for ONE training step.
@@ -359,6 +382,7 @@ class PeerExchange:
         matrix = [[int(v) for v in r] for r in matrix]
         if len(matrix) != W or any(len(r) != W for r in matrix) or any(v < 0 or v > rows_per_rank[s] for s, r in enumerate(matrix) for v in r):
             raise ValueError("PeerExchange.route: matrix must be W x W with 0 <= matrix[s][d] <= rows_per_rank[s]")
+        self.check()                    # a wait of an earlier step that gave up: raise before any more stale rows are used
         self._ensure(rows_per_rank)
         self.step += 1
         step, par, lay = self.step, self.step & 1, self._layout

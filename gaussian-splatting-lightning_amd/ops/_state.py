@@ -10,6 +10,7 @@ internal/viewer/client.py:114) never share a slot that belongs to another device
     STATE.pending_updates[data_ptr]                         parameter updates in flight on the colour stream (optimizers.FusedAdam)
     STATE.last_raster                                       introspection: the last compositing forward's inputs (keep_last_raster)
     STATE.consts, .identity_slots, .zero_scalars            small per-device constant tensors
+    STATE.backward_optimizers                               optimizers whose update the fused backward may apply itself (opt-in)
 
 `gspl_amd.ops` keeps the historical module-level spellings (ops.FUSED_INRIA, ops._LAST_ISECTS, ...) as properties of the package
 that read and write this object.  Container operations used on the hot path (dict get / set, list pop / append) are atomic under
@@ -23,7 +24,7 @@ from typing import Optional
 class RuntimeState:
     __slots__ = ("fused_inria", "device_side_list_length", "speculative_emit", "track_hit_pixels", "keep_last_raster", "side_low_priority",
                  "last_isects", "speculation", "events", "pinned_words", "pinned_ends", "pending_updates", "last_raster", "consts",
-                 "identity_slots", "zero_scalars", "new_event")
+                 "identity_slots", "zero_scalars", "new_event", "backward_optimizers")
 
     def __init__(self):
         env = os.environ.get
@@ -51,6 +52,9 @@ class RuntimeState:
         self.consts: dict = {}
         self.identity_slots: dict = {}
         self.zero_scalars: dict = {}
+        # optimizers constructed with fuse_into_backward=True (weak references): the fused Inria backward asks them for the moments of the
+        # parameters it is differentiating and, if every one is claimed, applies the update itself (optimizers._FusedAdamBase)
+        self.backward_optimizers: list = []
         self.new_event = _new_event      # (constructor of the events the free lists hand out; the host-only tests put a stand-in here)
 
 

@@ -77,7 +77,7 @@ class _CompositeFn(torch.autograd.Function):
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids)
         if S.keep_last_raster:
             S.last_raster = dict(mode=mode, width=width, height=height, means2d=means2d, conics=conics, opacities=opacities,
-                               colors=colors, flatten_ids=flatten_ids, offsets=offsets)
+                               colors=colors, flatten_ids=flatten_ids, offsets=offsets, last_ids=last_ids)
         ctx.cfg = (width, height, tile_size, tile_w, tile_h, bool(absgrad), mode, layout)
         ctx.means2d_ref = means2d_in      # the caller's tensor object: `.absgrad` is attached to it in backward
         return out, alphas

@@ -108,7 +108,7 @@ class _InriaRasterizeFn(torch.autograd.Function):
                               radii, means2d, conics, colors, clamped, cov3d, offsets, flat, final_Ts, last_ids, sh_jac, sh_rest)
         if S.keep_last_raster:
             S.last_raster = dict(mode=L.GSPL_MODE_INRIA, width=W, height=H, means2d=means2d, conics=conics, opacities=opac,
-                               colors=colors, flatten_ids=flat, offsets=offsets, radii=radii, depths=depths)
+                               colors=colors, flatten_ids=flat, offsets=offsets, radii=radii, depths=depths, last_ids=last_ids)
         ctx.cfg = (H, W, tile, tile_w, tile_h, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy),
                    float(s.scale_modifier), colors_precomp is not None, opacities.shape)
         ctx.set_materialize_grads(False)      # the integer `radii` output would otherwise get a zero "gradient" tensor per step
@@ -229,6 +229,9 @@ class _InriaFusedFn(torch.autograd.Function):
                 side_handle = ctypes.c_void_p(raw)
             # coefficient updates still in flight (FusedAdam(deferred=...)): on the colour stream itself stream order covers them
             _await_updates(sh, sh_rest, on_raw_stream=raw)
+            # geometry parameters are read on the CALLER's stream (also in place with raw_params): an update of theirs in flight on
+            # the colour stream has to be over first (FusedAdam(deferred=("scales", ...)): "kernels of this package wait by themselves")
+            _await_updates(means3D, scales, rotations, opac)
             try:
                 L.call("gspl_rasterize_inria_fwd", N, int(s.sh_degree), n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations),
                        L.ptr(cov3D_precomp), L.ptr(sh), L.ptr(sh_rest), L.ptr(colors_precomp), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg),
@@ -270,7 +273,8 @@ class _InriaFusedFn(torch.autograd.Function):
                                colors=_view(geom, state.colors, (N, 3), torch.float32),
                                flatten_ids=(lists[:4 * nI].view(torch.int32) if lists is not None else torch.empty(0, dtype=torch.int32, device=dev)),
                                offsets=_view(img, state.offsets, (tile_w * tile_h,), torch.int32), radii=radii,
-                               depths=_view(geom, state.depths, (N,), torch.float32))
+                               depths=_view(geom, state.depths, (N,), torch.float32),
+                               last_ids=_view(img, state.last_ids, (H, W), torch.int32))
         return out, radii
 
     @staticmethod
@@ -285,6 +289,24 @@ class _InriaFusedFn(torch.autograd.Function):
         E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         packed = E(N, 9)
         hit = torch.empty((N,), dtype=torch.uint8, device=dev) if S.track_hit_pixels else None
+        # An optimizer built with fuse_into_backward=True that owns EVERY parameter differentiated here: the kernels that end the
+        # backward apply its update themselves (gspl_rasterize_inria_bwd_adam) and no parameter gradient is written or returned
+        if S.backward_optimizers and N > 0 and not use_cov and not has_precomp_colors:
+            need = ctx.needs_input_grad
+            if need[0] and need[2] and need[4] and need[5] and need[6] and (sh_rest is None or need[9]):
+                from ..optimizers import claim_backward_update
+                plan = claim_backward_update(dict(means=means3D, scales=scales, rotations=rotations, opacities=opac, shs=sh, shs_rest=sh_rest))
+                if plan is not None:
+                    scratch, v_ndc = E(N, 3), E(N, 3)
+                    with torch.cuda.device(dev):
+                        L.call("gspl_rasterize_inria_bwd_adam", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh),
+                               L.ptr(sh_rest), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier,
+                               L.ptr(radii), ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(scratch), L.ptr(v_ndc),
+                               ctypes.byref(plan), L.stream())
+                    if hit is not None and ctx.means2D_ref is not None:
+                        ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
+                    ctx.holder = None
+                    return None, v_ndc, None, None, None, None, None, None, None, None, None
         v_means, v_ndc, v_opac = E(N, 3), E(N, 3), E(N)
         v_scales = None if use_cov else E(N, 3)
         v_quats = None if use_cov else E(N, 4)

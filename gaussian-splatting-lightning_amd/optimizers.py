@@ -27,7 +27,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
     _bias_correction = True
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 amsgrad: bool = False, maximize: bool = False, deferred=None, **unsupported):
+                 amsgrad: bool = False, maximize: bool = False, deferred=None, fuse_into_backward: bool = False, **unsupported):
         """The keyword arguments of `torch.optim.Adam` are accepted so that configurations written for it construct this
         class; the ones the kernel does not implement must keep their default values.
 
@@ -40,7 +40,20 @@ class _FusedAdamBase(torch.optim.Optimizer):
         with it: (1) the optimizer takes the gradients of the deferred parameters (`p.grad` is None after `step()`), (2) kernels of
         this package that read a deferred parameter wait for its update by themselves (`ops._await_updates`); anything else that reads
         one between `step()` and the next render — a checkpoint written right after the step, foreign torch code — calls `join()`
-        first (`state_dict()` and the next `step()` do)."""
+        first (`state_dict()` and the next `step()` do).
+
+        fuse_into_backward (extension, off by default): the update of a parameter the package's fused Inria rasterizer differentiates
+        is applied BY ITS BACKWARD — the per-Gaussian kernels that end it update the rows they have just produced the gradient of
+        (`gspl_rasterize_inria_bwd_adam`): the gradient never reaches HBM (236 B per Gaussian written and read back otherwise), the
+        moments are read and written once.  Same arithmetic, bit-identical parameters for identical gradients.  What changes for the
+        caller, and why it is opt-in (the default stays what internal/opt_strategies/vanilla.py:41-44 and internal/optimizers.py:14-22
+        expect): (1) such a parameter is updated DURING `loss.backward()` and has no `.grad` afterwards; `step()` finds nothing
+        left to do for it (it still advances nothing twice: the step counter moved when the backward claimed the update);
+        (2) exactly one backward per `step()`: a second one (gradient accumulation) raises; (3) it happens only when EVERY parameter
+        the rasterizer differentiates (means, scales, rotations, opacities, SH) belongs to optimizers built with this flag and is
+        handed to the rasterizer as it is stored (the renderer plugins do that for the reference's model) — otherwise the backward
+        writes gradients as always and `step()` applies them; (4) hyper-parameters are read when the backward runs (a scheduler that
+        stepped after the previous `step()` is seen, as with torch.optim.Adam)."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         if weight_decay != 0.0 or amsgrad or maximize:
@@ -54,6 +67,64 @@ class _FusedAdamBase(torch.optim.Optimizer):
         self._deferred_names = {d for d in (deferred or ()) if isinstance(d, str)}
         self._deferred_ids = {id(d) for d in (deferred or ()) if isinstance(d, torch.Tensor)}
         self._inflight = []      # [(event, tensors kept alive for the launch, data_ptrs registered in ops.PENDING_UPDATES)]
+        self._fuse_into_backward = bool(fuse_into_backward)
+        self._claimed = set()    # id() of the parameters a backward has updated since the last step()
+        if self._fuse_into_backward:
+            import weakref
+            from .ops._state import STATE
+            STATE.backward_optimizers[:] = [r for r in STATE.backward_optimizers if r() is not None]
+            STATE.backward_optimizers.append(weakref.ref(self))
+
+    # ---- the update applied by the rasterizer's backward (fuse_into_backward) ------------------------------------------------------
+    @property
+    def fuse_into_backward(self) -> bool:
+        return self._fuse_into_backward
+
+    @fuse_into_backward.setter
+    def fuse_into_backward(self, on: bool):
+        """Switch the in-backward update off / on again (e.g. around backward passes that no `step()` follows)."""
+        on = bool(on)
+        if on and not any(r() is self for r in __import__("gspl_amd.ops._state", fromlist=["STATE"]).STATE.backward_optimizers):
+            import weakref
+            from .ops._state import STATE
+            STATE.backward_optimizers.append(weakref.ref(self))
+        self._fuse_into_backward = on
+
+    def _owner_of(self, t: torch.Tensor):
+        """(group, parameter) of the parameter stored where `t` is (same memory, same number of elements), or None."""
+        ptr, n = t.data_ptr(), t.numel()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.data_ptr() == ptr and p.numel() == n and p.dtype == t.dtype:
+                    return group, p
+        return None
+
+    def _claimable(self, group, p) -> bool:
+        if not self._fuse_into_backward or p.grad is not None or not p.requires_grad:
+            return False          # (a gradient is already waiting: accumulate into it and let step() apply it)
+        if group.get("name") in self._deferred_names or id(p) in self._deferred_ids:
+            return False
+        return p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+
+    def _claim(self, group, p):
+        """Moments + hyper-parameters of `p` for the update the backward is about to apply; advances the step counter."""
+        if id(p) in self._claimed:
+            raise RuntimeError("fused Adam (fuse_into_backward): a second backward before optimizer.step() — the first one has already "
+                               "updated this parameter; gradient accumulation needs the default two-kernel path")
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        m, v = st["exp_avg"], st["exp_avg_sq"]
+        if m.shape != p.shape or v.shape != p.shape or not m.is_contiguous() or not v.is_contiguous() or m.dtype != torch.float32:
+            raise RuntimeError("fused Adam: exp_avg / exp_avg_sq must be contiguous fp32 tensors of the parameter's shape")
+        st["step"] = int(st["step"]) + 1
+        b1, b2 = group["betas"]
+        bc1 = 1.0 - b1 ** st["step"] if self._bias_correction else 1.0
+        bc2s = math.sqrt(1.0 - b2 ** st["step"]) if self._bias_correction else 1.0
+        self._claimed.add(id(p))
+        return L.BwdAdamTensor(m.data_ptr(), v.data_ptr(), float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(bc1), float(bc2s))
 
     def _prepare(self, p, group):
         """State of one parameter with its step counter advanced (once per optimizer step)."""
@@ -94,6 +165,7 @@ class _FusedAdamBase(torch.optim.Optimizer):
     def _launch(self, visibility: Optional[torch.Tensor]):
         L.lib()
         self.join()
+        self._claimed.clear()      # parameters a backward updated have no .grad: the loop below passes them by
         # tensors are batched per (N, betas, eps, step count): the reference has one parameter per group, all [N, ...]
         batches, later = {}, {}
         for group in self.param_groups:
@@ -190,11 +262,43 @@ class _FusedAdamBase(torch.optim.Optimizer):
         self._run({key: [item]}, None)
 
 
+def claim_backward_update(named: dict):
+    """Called by the fused Inria backward (ops/inria.py) with the tensors it is about to differentiate ({field of gspl_bwd_adam_plan:
+    tensor or None}).  If EVERY one of them is a parameter of an optimizer built with `fuse_into_backward=True` and has no gradient
+    waiting, returns the filled `BwdAdamPlan` (the step counters have then moved: the caller must apply the update); else None."""
+    from .ops._state import STATE
+    refs = [r() for r in STATE.backward_optimizers]
+    opts = [o for o in refs if o is not None]
+    if not opts:
+        return None
+    owners = {}
+    for field, t in named.items():
+        if t is None:
+            continue
+        found = None
+        for o in opts:
+            hit = o._owner_of(t)
+            if hit is not None:
+                found = (o, *hit)
+                break
+        if found is None or not found[0]._claimable(found[1], found[2]):
+            return None
+        owners[field] = found
+    if len({id(f[2]) for f in owners.values()}) != len(owners):
+        return None                                  # two inputs in one parameter's memory: not a layout the kernels update in place
+    plan = L.BwdAdamPlan()
+    for field, (o, group, p) in owners.items():
+        setattr(plan, field, o._claim(group, p))
+    return plan
+
+
 class SelectiveAdam(_FusedAdamBase):
     """`SelectiveAdam(params, eps, betas).step(visibility)`: gsplat's visibility-masked Adam (no bias correction)."""
     _bias_correction = False
 
-    def __init__(self, params, eps: float = 1e-8, betas=(0.9, 0.999), lr: float = 1e-3, deferred=None):
+    def __init__(self, params, eps: float = 1e-8, betas=(0.9, 0.999), lr: float = 1e-3, deferred=None, fuse_into_backward: bool = False):
+        if fuse_into_backward:
+            raise NotImplementedError("SelectiveAdam: fuse_into_backward is implemented for the unmasked update (FusedAdam) only")
         super().__init__(params, lr=lr, betas=betas, eps=eps, deferred=deferred)
 
     @torch.no_grad()
@@ -232,12 +336,16 @@ from typing import Tuple  # noqa: E402
 class HipFusedAdam(_OptimizerConfig):
     """Drop-in for `internal.optimizers.Adam` (internal/optimizers.py:14-22): same update, one launch per step.
     `overlap_sh_update`: run the update of the "shs_rest" group under the next frame's geometry / binning (`FusedAdam(deferred=...)`,
-    read its contract first); off by default."""
+    read its contract first); off by default.  `fuse_into_backward`: see `FusedAdam`."""
     overlap_sh_update: bool = False
+    # the rasterizer's backward applies the update (FusedAdam(fuse_into_backward=True): read its contract first); off by default
+    fuse_into_backward: bool = False
 
     def instantiate(self, params, lr: float, *args, **kwargs):
         if self.overlap_sh_update:
             kwargs.setdefault("deferred", ("shs_rest",))
+        if self.fuse_into_backward:
+            kwargs.setdefault("fuse_into_backward", True)
         return FusedAdam(params, lr, *args, **kwargs)
 
 

@@ -116,6 +116,28 @@ class HipGSplatDistributedRendererImpl(Renderer):
     def _span(self, name):
         return _Range(self.profiler, self.profile_prefix + name)
 
+    def _backward_follows(self, records) -> bool:
+        """The peer transport double-buffers on the promise of ONE backward per forward (a source may run one exchange ahead of the
+        slowest reader, never two: its next forward needs every peer's backward rows of this step).  A forward that no backward can
+        follow — no_grad, eval mode, records that carry no graph — takes the collective route."""
+        return torch.is_grad_enabled() and self.training and bool(records.requires_grad)
+
+    def close(self):
+        """Releases what the peer transport holds for the life of the process otherwise: the fine-grained IPC receive buffers and the
+        peers' mappings (`PeerExchange.close`: COLLECTIVE — every rank calls it, it waits for the device and meets the others in a
+        barrier before anything is unmapped) and the shared-memory mailboxes.  Idempotent; the renderer can be used again afterwards
+        (everything is created on first use)."""
+        peer, self._peer = self._peer, None
+        if peer is not None:
+            peer.close()
+        for name in ("_mailbox", "_count_mailbox"):
+            box = self.__dict__.pop(name, None)
+            if box is not None:
+                box.close()
+
+    def teardown(self, *args, **kwargs):      # (the name Lightning's hooks use for the end of fit / validate)
+        self.close()
+
     # ---- setup: shard the Gaussians (reference :63-118) -------------------------------------------------
     def training_setup(self, module):
         self.world_size = module.trainer.world_size
@@ -408,17 +430,16 @@ class HipGSplatDistributedRendererImpl(Renderer):
                 n = self.__dict__["_padded_steps"] = self.__dict__.get("_padded_steps", 0) + 1
                 if n % 8 == 1:
                     self._post_visible_count(vis, pairs)
-                if exchanging and c.exchange_transport == "peer" and torch.is_grad_enabled():
+                if exchanging and c.exchange_transport == "peer" and self._backward_follows(records):
                     if self._peer is None:
                         self._peer = D.PeerExchange(rank, self.group, records.device)
-                    route = self._peer.route(peer_counts)
-                    if n % 64 == 0:
-                        self._peer.check()          # (a wait that gave up; synchronises, hence seldom)
+                    route = self._peer.route(peer_counts)      # (raises first if a wait of an earlier step gave up: the error word is
+                    #                                             in pinned host memory, the check costs nothing and runs every step)
                 elif exchanging:
                     route = D.all_to_all_route(send_counts, peer_counts, self.group)
             else:
                 self._visible_permille, self._visible_pending = int(1000 * sum(send_counts) // pairs), None
-                if exchanging and c.exchange_transport == "peer" and torch.is_grad_enabled():
+                if exchanging and c.exchange_transport == "peer" and self._backward_follows(records):
                     # the whole W x W count matrix through shared host memory (every rank posts its row), then direct peer writes
                     if self.__dict__.get("_count_mailbox") is None:
                         self._count_mailbox = D.HostMailbox(rank, self.group, width=len(cameras))

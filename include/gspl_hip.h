@@ -427,6 +427,34 @@ int gspl_rasterize_inria_bwd(int degree, int n_coeffs,
                              float* v_means3D, float* v_means2D_ndc, float* v_shs, float* v_shs_rest, float* v_colors_precomp, float* v_opacities,
                              float* v_scales, float* v_rotations, float* v_cov3D, void* stream);
 
+/* The backward with the OPTIMIZER INSIDE (additive entry, round 5): the per-Gaussian kernels that end the backward apply the Adam update
+ * to the rows they have just produced the gradient of — moments read and written once, parameters written once, NO parameter gradient in
+ * HBM (236 B per Gaussian written by the backward and read back by the optimizer launch otherwise: the two-kernel form of
+ * internal/optimizers.py:14-22 / internal/models/vanilla_gaussian.py:266-300 behind gaussian_splatting.py:380-397).
+ * means3D ... opacities are the PARAMETERS, updated in place (raw parameters with GSPL_INRIA_RAW_PARAMS in the state's flags, else
+ * the activated tensors the forward was given); every row is updated, a Gaussian the frame does not see with a zero gradient
+ * (torch.optim.Adam semantics).  shs_rest == NULL: `shs` holds all n_coeffs rows and plan->shs its moments.  scratch_means [N,3] f32
+ * and packed [N,9] are scratch; v_means2D_ndc [N,3] (the screen-space gradient) is the one gradient written.
+ * Same arithmetic as gspl_rasterize_inria_bwd followed by gspl_selective_adam with no mask (bit-identical parameters and moments for
+ * identical gradients: tests/test_fused_backward_adam.py). */
+typedef struct gspl_bwd_adam_tensor {
+    float* exp_avg;              /* first / second moment, shape of the parameter, f32 contiguous */
+    float* exp_avg_sq;
+    float lr, beta1, beta2, eps;
+    float bias_correction1;      /* 1 - beta1^t   (1: gsplat's uncorrected update) */
+    float bias_correction2_sqrt; /* sqrt(1 - beta2^t)   (1: uncorrected) */
+} gspl_bwd_adam_tensor;
+typedef struct gspl_bwd_adam_plan {
+    gspl_bwd_adam_tensor means, scales, rotations, opacities, shs, shs_rest;
+} gspl_bwd_adam_plan;
+int gspl_rasterize_inria_bwd_adam(int degree, int n_coeffs,
+                                  float* means3D, float* scales, float* rotations, float* shs, float* shs_rest /*nullable*/, float* opacities,
+                                  const float* viewmatrix, const float* projmatrix, const float* campos, const float* bg,
+                                  float tanfovx, float tanfovy, float scale_modifier,
+                                  const int32_t* radii, const gspl_inria_state* state, const float* v_out_color,
+                                  float* packed, uint8_t* hit_flags /*nullable*/, float* scratch_means, float* v_means2D_ndc,
+                                  const gspl_bwd_adam_plan* plan /* host */, void* stream);
+
 /* A per-device stream of the LOWEST priority the device offers, created on first use and kept: a `side_stream` for
  * gspl_rasterize_inria_fwd whose colour kernel then yields to the kernels on the caller's stream.  NULL on failure. */
 void* gspl_low_priority_stream(void);
@@ -504,7 +532,7 @@ int gspl_peer_put_rows(int n_dst, const float* rows, const int64_t* row_begin /*
                        void* const* dst /* host, [n_dst] device pointers */, int floats_per_row /* multiple of 4 */, void* stream);
 int gspl_peer_signal(int n_dst, void* const* flags /* host, [n_dst] device pointers to 8-byte words */, uint64_t value, void* stream);
 int gspl_peer_wait(const uint64_t* flags /* device, [n_src] */, int n_src, uint64_t value, uint64_t max_polls,
-                   int32_t* error /* device word */, void* stream);
+                   int32_t* error /* device-visible word: device memory, or PINNED HOST memory the host can read without synchronising */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7. Mean squared distance to the 3 nearest neighbours ("next" row SURVEY.md §8f rank 1).

@@ -46,7 +46,122 @@ def hip_composite_bwd(mode, means2d, conics, colors, opac, bg, W, H, offsets, fl
     return dict(v_means2d=v_xy, v_means2d_abs=v_abs, v_conics=v_con, v_colors=v_col, v_opacities=v_op, hit=hit)
 
 
-def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0, rel_all=None, frac_1e2=None, outliers=0, rel_outliers=0.5):
+EPS32 = 2.0 ** -24
+
+
+def cov2d_condition(conics) -> np.ndarray:
+    """lambda_max / lambda_min of every splat's 2D covariance (= of its conic), from the oracle's fp64 conics [N,3]."""
+    c = np.asarray(conics, np.float64)
+    tr, det = c[:, 0] + c[:, 2], c[:, 0] * c[:, 2] - c[:, 1] ** 2
+    disc = np.sqrt(np.maximum(tr * tr / 4 - det, 0.0))
+    lo = np.maximum(tr / 2 - disc, 1e-300)
+    return np.where(det > 0, (tr / 2 + disc) / lo, 1.0)
+
+
+def cov_chain_slack(ref, kappa, factor=200.0) -> np.ndarray:
+    """Per-ELEMENT absolute slack for gradients that pass through conic -> cov2D -> cov3D (means, scales, rotations):
+    factor * eps32 * kappa_row * max|ref_row|.  Why: dL/dcov2D = -conic G conic with G = dL/dconic; for an elongated splat G is
+    dominated by the long axis (sum of sp dx^2 over hundreds of pixels) and conic by the short one, the two nearly annihilate, and
+    what survives carries the rounding of the products: a RELATIVE error ~ eps32 * kappa(cov2D) in fp32, in this kernel and in any
+    fp32 evaluation of the reference's formulation (diff_gaussian_rasterization and gsplat compute exactly this product in fp32).
+    Measured on `synthetic.scene_surfaces` with the compositing gradients equal to 1e-6 (profiles/r07d_locked_rows_diag.txt):
+    rows with kappa 400 ... 4100 are off by 60 ... 100 x eps32 x kappa of their own magnitude; factor 200 bounds that with a
+    margin of two.  For kappa <= 8 (the bulk of a scene) the slack is below 1e-4 of the row: the plain tolerance decides."""
+    ref = np.asarray(ref, np.float64)
+    rowmax = np.abs(ref).reshape(len(ref), -1).max(axis=1)
+    slack = factor * EPS32 * np.asarray(kappa, np.float64) * rowmax
+    return slack.reshape((len(ref),) + (1,) * (ref.ndim - 1)) * np.ones_like(ref)
+
+
+def cov_chain_bound(api, params, cam, H, W, mask, v_conics, radii, factor=8.0):
+    """Running fp32 rounding bound of the gradients that pass through conic -> cov2D -> cov3D -> (means, scales, rotations), per
+    ELEMENT, from fp64 quantities only (a first-order error analysis of the chain every implementation of the reference's
+    formulation evaluates — diff_gaussian_rasterization and gsplat in fp32 too):
+
+      1. dL/dcov2D = -conic G conic, written out on the cov2D entries (a, b, c):
+             va = (-c c vA + b c vB - b b vC) / det^2,   vb = (2 b c vA - (a c + b b) vB + 2 a b vC) / det^2,   vc likewise
+         (G = (vA, vB, vC) = dL/dconic, det = a c - b b).  For an elongated splat G is dominated by the long axis and conic by the
+         short one: the three products are ~ kappa^2 times their sum.  Rounding error <= eps32 * Tx, Tx = sum of |products| / det^2.
+      2. dL/dSigma_ij = sum_x vx dx/dSigma_ij (x in a, b, c; dx/dSigma_ij = T_ai T_bj) and dL/dtheta = sum_ij dL/dSigma_ij dSigma_ij/dtheta
+         (theta = scales, rotations), dL/dmean = sum_x vx dx/dmean: sums of products of mixed sign again; what an error of stage 1 — and
+         the rounding of these sums themselves — can amount to is the same chain run on absolute values:
+             A_theta = sum_ij |dSigma_ij/dtheta| sum_x |dx/dSigma_ij| Tx,        A_mean = sum_x |dx/dmean| Tx.
+      3. G itself is an fp32 sum over the splat's footprint: each of its entries carries factor * eps32 * sqrt(pixels) of its size
+         (footprint_slack: what the compositing kernel's own gradients are held to), and an error of G goes through the same chain.
+      bound = factor * eps32 * (1 + sqrt(pi) r) * A  (`factor`: the handful of roundings per product and stage, with a margin of two;
+      r = the splat's radius in pixels).  Not tight — a first-order worst case — but it scales with what makes the chain
+      ill-conditioned and vanishes (below 1e-4 of the row) for the round splats that make up the bulk of a scene.
+
+    The Jacobians come from torch.autograd on the oracle's own stages (cov3d_from_scale_rot, ewa_cov2d), one unit cotangent each.
+    api "vanilla": Inria conventions (near plane 0.2, clamped coordinates constant in the backward); "gsplat": near 0.01.
+    v_conics [N,3] = the oracle's dL/dconic.  Returns {"means": [N,3], "scales": [N,3], "quats": [N,4]}."""
+    import torch
+    from oracle import gsplat_oracle as O
+    m, s, q = [t.detach().double().clone().requires_grad_(True) for t in params[:3]]
+    V = cam["world_to_camera"].double()
+    pv = m @ V[:3, :3] + V[3, :3]
+    front = pv[:, 2].detach() >= (0.2 if api == "vanilla" else 0.01)
+    pv_safe = torch.where(front[:, None], pv, torch.ones_like(pv))
+    sigma = O.cov3d_from_scale_rot(s, 1.0, q)
+    sigma_leaf = sigma.detach().clone().requires_grad_(True)
+    if api == "vanilla":
+        fx, fy = W / (2.0 * cam["tanfovx"]), H / (2.0 * cam["tanfovy"])
+        cov2d = O.ewa_cov2d(pv_safe, sigma_leaf, V[:3, :3].T, fx, fy, 1.3 * cam["tanfovx"], 1.3 * cam["tanfovy"], inria_clamp_grad=True)
+    else:
+        fx, fy = float(cam["fx"]), float(cam["fy"])
+        cov2d = O.ewa_cov2d(pv_safe, sigma_leaf, V[:3, :3].T, fx, fy, 1.3 * (0.5 * W / fx), 1.3 * (0.5 * H / fy))
+    a, b, c = cov2d[:, 0, 0] + 0.3, cov2d[:, 0, 1], cov2d[:, 1, 1] + 0.3
+    an, bn, cn = (np.abs(t.detach().numpy()) for t in (a, b, c))
+    vA, vB, vC = (np.abs(np.asarray(v_conics, np.float64)[:, k]) for k in range(3))
+    det2 = np.maximum((a.detach().numpy() * c.detach().numpy() - b.detach().numpy() ** 2) ** 2, 1e-300)
+    T = {"a": (cn * cn * vA + bn * cn * vB + bn * bn * vC) / det2,
+         "b": (2 * bn * cn * vA + (an * cn + bn * bn) * vB + 2 * an * bn * vC) / det2,
+         "c": (bn * bn * vA + an * bn * vB + an * an * vC) / det2}
+    A_sigma, A_m = np.zeros((len(an), 3, 3)), np.zeros((len(an), 3))
+    for x, key in ((a, "a"), (b, "b"), (c, "c")):
+        g_sigma, g_m = torch.autograd.grad(x.sum(), [sigma_leaf, m], retain_graph=True)
+        A_sigma += np.abs(g_sigma.numpy()) * T[key][:, None, None]
+        A_m += np.abs(g_m.numpy()) * T[key][:, None]
+    A_s, A_q = np.zeros((len(an), 3)), np.zeros((len(an), 4))
+    for i in range(3):
+        for j in range(3):
+            g_s, g_q = torch.autograd.grad(sigma[:, i, j].sum(), [s, q], retain_graph=True)
+            A_s += np.abs(g_s.numpy()) * A_sigma[:, i, j, None]
+            A_q += np.abs(g_q.numpy()) * A_sigma[:, i, j, None]
+    keep = (np.asarray(mask, bool) & front.numpy())[:, None]
+    scale = (factor * EPS32 * (1.0 + np.sqrt(np.pi) * np.maximum(np.asarray(radii, np.float64), 1.0)))[:, None]
+    return {n: scale * np.where(keep, A, 0.0) for n, A in (("means", A_m), ("scales", A_s), ("quats", A_q))}
+
+
+def footprint_slack(ref, radii, factor=8.0) -> np.ndarray:
+    """Per-element absolute slack for the compositing kernel's per-splat sums: factor * eps32 * sqrt(pixels of the splat's footprint) *
+    max|ref_row|.  A per-splat gradient is an fp32 sum of one signed term per covered pixel; over n terms of mixed sign it carries
+    ~ eps32 sqrt(n) of the terms' magnitude, and for the moments of a long splat (sum of sp dx, sp dx^2 over a footprint hundreds of
+    pixels wide) that magnitude is several times the result.  Radius 10 px: 1e-5 of the row — the plain 1e-4 decides; radius 600 px (the
+    longest needles of `scene_surfaces`, 1e6 pixels): 5e-4 of the row."""
+    ref = np.asarray(ref, np.float64)
+    rowmax = np.abs(ref).reshape(len(ref), -1).max(axis=1)
+    r = np.maximum(np.asarray(radii, np.float64), 1.0)
+    slack = factor * EPS32 * np.sqrt(np.pi) * r * rowmax
+    return slack.reshape((len(ref),) + (1,) * (ref.ndim - 1)) * np.ones_like(ref)
+
+
+def means2d_slack(v_xy, conics, radii, factor=8.0) -> np.ndarray:
+    """footprint_slack for the screen-space gradient, with the cancellation of its last step: dL/dx = A Sx + B Sy, dL/dy = B Sx + C Sy
+    ((A, B, C) the conic, (Sx, Sy) the first moments of dL/dsigma over the footprint).  Along a needle the two products are each far
+    larger than their sum; the moments carry the rounding of a sum over the footprint (eps32 sqrt(pixels)), so the result carries
+    factor * eps32 * sqrt(pixels) * (|A Sx| + |B Sy|) — the moments are recovered from the oracle's gradient as cov2D (vx, vy)."""
+    v, c = np.asarray(v_xy, np.float64), np.asarray(conics, np.float64)
+    A, B, C = c[:, 0], c[:, 1], c[:, 2]
+    det = np.where(A * C - B * B > 0, A * C - B * B, 1.0)
+    a, b, cc = C / det, -B / det, A / det
+    sx, sy = a * v[:, 0] + b * v[:, 1], b * v[:, 0] + cc * v[:, 1]
+    terms = np.stack([np.abs(A * sx) + np.abs(B * sy), np.abs(B * sx) + np.abs(C * sy)], axis=1)
+    r = np.maximum(np.asarray(radii, np.float64), 1.0)
+    return factor * EPS32 * np.sqrt(np.pi) * r[:, None] * terms
+
+
+def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0, rel_all=None, frac_1e2=None, outliers=0, rel_outliers=0.5, slack=None):
     """ratio = |got - ref| / (|ref| + rms(ref)) elementwise, with three tiers:
          ratio <= rel       for at least `frac_ok` of the elements (the claimed tolerance);
          ratio <= 1e-2      for at least `frac_1e2` of them (default: all when rel_all <= 1e-2, else 1 - 5e-5; measured up to 3e-5);
@@ -62,7 +177,9 @@ def assert_close_scaled(got, ref, rel, name="", frac_ok=1.0, rel_all=None, frac_
         return
     assert np.isfinite(got).all(), f"{name}: non-finite values"
     rms = float(np.sqrt(np.mean(ref * ref))) + 1e-30
-    ratio = np.abs(got - ref) / (np.abs(ref) + rms)
+    # `slack` (cov_chain_slack): an absolute, per-element allowance on top of rel * (|ref| + rms) — the error is judged against
+    # rel * (|ref| + rms) + slack, expressed here as a larger denominator so that the tiers below apply unchanged
+    ratio = np.abs(got - ref) / (np.abs(ref) + rms + (0.0 if slack is None else np.asarray(slack, np.float64) / rel))
     bad = ratio > rel
     worst = float(ratio.max())
     n2 = int((ratio > 1e-2).sum())

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import gsplat_oracle as O
-from hip_helpers import assert_close_scaled, assert_pixels_close
+from hip_helpers import assert_close_scaled, assert_pixels_close, cov2d_condition, cov_chain_slack, footprint_slack
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -58,9 +58,12 @@ def _compare_grads(leaves, dl):
         assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
 
 
-def _vanilla_against_the_oracle(params, cam, W, H, wimg, bg, radii_frac=0.9995):
+def _vanilla_against_the_oracle(params, cam, W, H, wimg, bg, radii_frac=0.9995, conditioned=False):
     """Inria API (`ops.GaussianRasterizer`, as vanilla_renderer.py:25-129 calls it), SH degree 3: image, the five parameter
-    gradients and `viewspace_points.grad` (NDC units) against `O.render_inria`."""
+    gradients and `viewspace_points.grad` (NDC units) against `O.render_inria`.
+    conditioned: the per-row allowances of tests/test_locked_parity.py (hip_helpers.cov_chain_slack / footprint_slack: the fp32
+    conditioning of conic -> cov2D -> cov3D and of a sum over a large footprint) under the tiers — for scenes with long anisotropic
+    splats, where the tiers alone would be measuring that conditioning instead of flipped decisions."""
     from gspl_amd import ops
     leaves = [t.to(DEV).requires_grad_(True) for t in params]
     m, s, q, o, c = leaves
@@ -82,9 +85,12 @@ def _vanilla_against_the_oracle(params, cam, W, H, wimg, bg, radii_frac=0.9995):
     assert np.mean(got["radii"] == r["radii"].numpy()) > radii_frac
     assert_pixels_close(got["render"], r["render"].detach().numpy())
     ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * W, 0.5 * H])
-    assert_close_scaled(got["screen"], ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
+    kappa, extent = cov2d_condition(r["conics"].detach().numpy()), r["radii"].numpy().astype(np.float64)
+    slack = lambda ref, cov: (footprint_slack(ref, extent) + (cov_chain_slack(ref, kappa) if cov else 0.0)) if conditioned else None
+    assert_close_scaled(got["screen"], ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS, slack=slack(ref_ndc, False))
     for g, ref, name in zip(got["grads"], dl, ("means", "scales", "quats", "opacities", "shs")):
-        assert_close_scaled(g, ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS)
+        rf = ref.grad.numpy()
+        assert_close_scaled(g, rf, 1e-4, name, frac_ok=0.995, rel_all=TAIL, outliers=OUTLIERS, slack=slack(rf, name in ("means", "scales", "quats")))
 
 
 def test_config2_proxy_S_1080p_6M_inria_api_gradients():
@@ -112,7 +118,7 @@ def test_trained_scene_shaped_workload_S_1080p_1M_surfaces_against_the_oracle():
     params = synthetic.workload_scene(wl, seed=42)
     cam = O.synthetic_camera(W, H, wl["fx"])
     wimg = torch.randn(3, H, W, generator=torch.Generator().manual_seed(6))
-    _vanilla_against_the_oracle(params, cam, W, H, wimg, torch.tensor([0.1, 0.2, 0.3]))
+    _vanilla_against_the_oracle(params, cam, W, H, wimg, torch.tensor([0.1, 0.2, 0.3]), conditioned=True)
 
 
 @pytest.mark.parametrize("api", ["vanilla", "gsplat"])
