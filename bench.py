@@ -353,6 +353,13 @@ def cpu_baseline(workload_name, api):
         ref = {"kind": "reference", "failed": repr(e)}
     return {
         "value": 1.0 / total, "unit": "images/s", "cores": cores, "kind": "port", "reference_projection_sh": ref,
+        # The number north_star names — the reference's OWN project_gaussians + eval_sh on host cores — cannot be measured on the GPU
+        # box (no reference tree there: `reference_projection_sh` is null in the driver's line).  What was measured where the tree
+        # exists, as a labelled CONSTANT beside the live port figure: the 8-vCPU build container, S-1080p-1M,
+        # profiles/r02a_cpu_baseline_reference_container.json.
+        "reference_projection_sh_build_container": (
+            {"kind": "reference", "fwd_ms": 136.92, "bwd_ms": 648.66, "cores": 8, "workload": "S-1080p-1M", "measured": "constant, not this run",
+             "source": "profiles/r02a_cpu_baseline_reference_container.json"} if workload_name == "S-1080p-1M" else None),
         "value_with_numpy_binning": 1.0 / (total + binning_s),
         "binning_note": "ms.binning is the oracle's numpy restatement of the (tile | depth) key sort — test infrastructure, not a baseline; excluded from value",
         "sample": f"one fwd+bwd pass of {workload_name} (N={wl['n']}, {W}x{H}, I={int(flat.shape[0])}), fp32, "

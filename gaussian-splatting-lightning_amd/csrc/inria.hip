@@ -213,6 +213,35 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
 // (`adam`: parameter, moments, hyper-parameters; every row, the invisible ones with a zero gradient, as torch.optim.Adam does).
 // The parameters are read and written through `adam.*.p` (no __restrict__ promise on memory this kernel writes).
 struct PreAdam { AdamTarget means, scales, quats, opac; };
+// Adam over `total` consecutive floats of one parameter starting at float `base` (a block's rows), gradients in LDS: 16-byte chunks
+// per lane, coalesced; a slice that is not 16-byte aligned, and the last partial chunk, go element by element.
+__device__ __forceinline__ void pre_adam_pass(const AdamTarget& T, int64_t base, int total, const float* grad) {
+    const int t = threadIdx.x;
+    float* gp = T.p + base;
+    float* gm = T.m + base;
+    float* gv = T.v + base;
+    int done = 0;
+    if ((((uintptr_t)gp | (uintptr_t)gm | (uintptr_t)gv) & 15u) == 0) {
+        const int n4 = total >> 2;
+        for (int e4 = t; e4 < n4; e4 += 256) {
+            float4 p = reinterpret_cast<const float4*>(gp)[e4], m = reinterpret_cast<const float4*>(gm)[e4], v = reinterpret_cast<const float4*>(gv)[e4];
+            const float4 g = reinterpret_cast<const float4*>(grad)[e4];
+            adam_elem(p.x, g.x, m.x, v.x, T.h);
+            adam_elem(p.y, g.y, m.y, v.y, T.h);
+            adam_elem(p.z, g.z, m.z, v.z, T.h);
+            adam_elem(p.w, g.w, m.w, v.w, T.h);
+            reinterpret_cast<float4*>(gp)[e4] = p;
+            reinterpret_cast<float4*>(gm)[e4] = m;
+            reinterpret_cast<float4*>(gv)[e4] = v;
+        }
+        done = n4 << 2;
+    }
+    for (int e = done + t; e < total; e += 256) {
+        float p = gp[e], m = gm[e], v = gv[e];
+        adam_elem(p, grad[e], m, v, T.h);
+        gp[e] = p; gm[e] = m; gv[e] = v;
+    }
+}
 template <bool ACCUM, bool RAW, bool ADAM = false>
 __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     int N,
@@ -225,23 +254,23 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
     float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc,
     const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst, const float* __restrict__ opac_act, PreAdam adam) {
+    // ADAM: the block's 256 rows of gradients meet in LDS and the update runs as FLAT, coalesced 16-byte passes over the block's
+    // slice of every array (pre_adam_pass) — a lane-per-row update reads and writes 33 strided dwords per Gaussian three times over
+    // (95 us at 1 M, 527 us at 6 M: 3 TB/s); every thread of the block stays for the barrier, rows past N carry nothing.
+    __shared__ __attribute__((aligned(16))) float s_grad[ADAM ? 256 * 11 : 4];      // means 768 | scales 768 | quats 1024 | opacities 256
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= N) return;
+    if (!ADAM && g >= N) return;
+    const bool row = g < N;
     if (ADAM || v_opac_dst) {
-        float v = v_opac_src[(int64_t)g * gs2];
-        if constexpr (RAW) { const float o = opac_act[g]; v *= o * (1.f - o); }
-        if constexpr (ADAM) {
-            float p = adam.opac.p[g], m = adam.opac.m[g], w = adam.opac.v[g];
-            adam_elem(p, v, m, w, adam.opac.h);
-            adam.opac.p[g] = p; adam.opac.m[g] = m; adam.opac.v[g] = w;
-        } else {
-            v_opac_dst[g] = v;
-        }
+        float v = row ? v_opac_src[(int64_t)g * gs2] : 0.f;
+        if constexpr (RAW) { const float o = row ? opac_act[g] : 0.f; v *= o * (1.f - o); }
+        if constexpr (ADAM) s_grad[256 * 10 + threadIdx.x] = v;
+        else v_opac_dst[g] = v;
     }
     float vp[3] = {0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
     float G6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ndc[2] = {0.f, 0.f};
-    if (radii[g] > 0) {
+    if (row && radii[g] > 0) {
         InriaCam cam;
         load_inria_cam(viewmatrix, projmatrix, cam);
         const float p[3] = {means[g * 3 + 0], means[g * 3 + 1], means[g * 3 + 2]};
@@ -296,19 +325,20 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     if constexpr (ADAM) {
         // the gradient rows never reach HBM: parameter + moments are read, updated, written (same sums, in the same order, as the
         // gradient-writing form below: bit-identical parameters for identical inputs)
-        auto apply = [&](const AdamTarget& T, int row, int j, float grad) {
-            const int64_t e = (int64_t)g * row + j;
-            float p = T.p[e], m = T.m[e], w = T.v[e];
-            adam_elem(p, grad, m, w, T.h);
-            T.p[e] = p; T.m[e] = m; T.v[e] = w;
-        };
+        const int t = threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) apply(adam.means, 3, j, ACCUM ? v_means[g * 3 + j] + vp[j] : vp[j]);
+        for (int j = 0; j < 3; ++j) s_grad[t * 3 + j] = row ? (ACCUM ? v_means[g * 3 + j] + vp[j] : vp[j]) : 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) apply(adam.scales, 3, j, vs[j]);
+        for (int j = 0; j < 3; ++j) s_grad[256 * 3 + t * 3 + j] = vs[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) apply(adam.quats, 4, j, vq[j]);
-        v_means2d_ndc[g * 3 + 0] = ndc[0]; v_means2d_ndc[g * 3 + 1] = ndc[1]; v_means2d_ndc[g * 3 + 2] = 0.f;
+        for (int j = 0; j < 4; ++j) s_grad[256 * 6 + t * 4 + j] = vq[j];
+        if (row) { v_means2d_ndc[g * 3 + 0] = ndc[0]; v_means2d_ndc[g * 3 + 1] = ndc[1]; v_means2d_ndc[g * 3 + 2] = 0.f; }
+        __syncthreads();
+        const int n0 = blockIdx.x * 256, rows = min(256, N - n0);
+        pre_adam_pass(adam.means, (int64_t)n0 * 3, rows * 3, s_grad);
+        pre_adam_pass(adam.scales, (int64_t)n0 * 3, rows * 3, s_grad + 256 * 3);
+        pre_adam_pass(adam.quats, (int64_t)n0 * 4, rows * 4, s_grad + 256 * 6);
+        pre_adam_pass(adam.opac, (int64_t)n0, rows, s_grad + 256 * 10);
         return;
     }
 #pragma unroll

@@ -28,6 +28,9 @@ namespace gspl {
 #ifndef GSPL_SH_BLOCK
 #define GSPL_SH_BLOCK 256
 #endif
+#ifndef GSPL_SH_ADAM_U
+#define GSPL_SH_ADAM_U 2
+#endif
 static constexpr int SH_BLOCK = GSPL_SH_BLOCK;      // rows (= threads) per workgroup
 static constexpr int SH_MAX_K = 25;
 
@@ -190,7 +193,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ g, int rows, int 
 
 // The Adam-applying counterpart of tile_store (backward kernels of the "update inside the backward" form): the rows of
 // LDS hold the GRADIENT of `rows` rows x `rs` floats; parameter and moments are streamed through once, flat and coalesced, 16 bytes
-// per lane (two chunks = six loads in flight per lane), updated and written back — the gradient never reaches HBM.
+// per lane (GSPL_SH_ADAM_U chunks = 3 U loads in flight per lane), updated and written back — the gradient never reaches HBM.
 __device__ __forceinline__ void tile_adam(const AdamTarget& T, int64_t base, int rows, int rs, int ls, float inv_rs, const float* lds, bool vec_ok) {
     const int total = rows * rs;
     const int t = threadIdx.x;
@@ -203,15 +206,16 @@ __device__ __forceinline__ void tile_adam(const AdamTarget& T, int64_t base, int
         float4* p4 = reinterpret_cast<float4*>(gp);
         float4* m4 = reinterpret_cast<float4*>(gm);
         float4* v4 = reinterpret_cast<float4*>(gv);
-        for (int b4 = t; b4 < n4; b4 += 2 * SH_BLOCK) {
-            float4 p[2], m[2], v[2];
+        constexpr int U = GSPL_SH_ADAM_U;      // 16-byte chunks per lane and iteration: 3 U loads in flight
+        for (int b4 = t; b4 < n4; b4 += U * SH_BLOCK) {
+            float4 p[U], m[U], v[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int e4 = b4 + u * SH_BLOCK;
                 if (e4 < n4) { p[u] = sh_load16(p4 + e4); m[u] = sh_load16(m4 + e4); v[u] = sh_load16(v4 + e4); }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int e4 = b4 + u * SH_BLOCK;
                 if (e4 >= n4) continue;
                 float g[4];
