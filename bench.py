@@ -801,6 +801,20 @@ def main():
                          "fwd_ms": round(sum(m2[i].elapsed_time(m2[i + 1]) for i in range(0, len(m2), 3)) / args.steps, 4),
                          "bwd_ms": round(sum(m2[i + 1].elapsed_time(m2[i + 2]) for i in range(0, len(m2), 3)) / args.steps, 4)}
 
+    # third timed region of the same run: the same step with the optimizer INSIDE the backward (FusedAdam(fuse_into_backward=True),
+    # gspl_rasterize_inria_bwd_adam) — opt-in in the product, so it is not `value`; reported beside it
+    fused_bwd_adam = None
+    if world == 1 and mode == "single" and api == "vanilla" and args.optimizer == "fused-adam" and not args.no_renderer_only:
+        try:
+            opt2 = make_optimizer("fused-bwd-adam", [{"params": [t], "lr": lr * 1e-3, "name": n} for t, lr, n in zip(tensors, lrs, GROUP_NAMES)])
+            e3, _, _ = timed_region(make_full_step(opt2, "fused-bwd-adam"), args.steps, 3)
+            fused_bwd_adam = {"images_per_s": round(args.steps / e3, 3), "ms_per_step": round(e3 / args.steps * 1e3, 4),
+                              "what": "optimizer = FusedAdam(fuse_into_backward=True): the per-Gaussian kernels that end the backward apply the Adam "
+                                      "update (no parameter gradient in HBM); bit-identical parameters, opt-in (tests/test_fused_backward_adam.py)"}
+            del opt2
+        except Exception as e:      # an extra: it must never take the bench line down
+            fused_bwd_adam = {"failed": repr(e)}
+
     # ---- the workload the byte / flop models are evaluated on: per camera of the set, averaged --------------------------------
     # I = every tile-rect intersection of the API benched, I' = list entries the kernels walk after the lossless
     # tile culling, V = visible splats, valid pairs = (pixel, splat) pairs the compositing blends (COUNTED on the device).
@@ -952,6 +966,7 @@ def main():
             "images_per_s_renderer_only": (renderer_only["images_per_s"] if renderer_only else
                                            (round(world * args.steps / elapsed, 3) if args.optimizer == "none" else None)),
             "renderer_only": renderer_only,
+            "with_fused_bwd_adam": fused_bwd_adam,
             "stages_ms": stages,
             # device time between the events at the start of the step, before loss.backward() and after it
             "fwd_ms": round(phase_fwd, 4),

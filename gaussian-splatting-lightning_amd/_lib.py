@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -28,6 +28,8 @@ GSPL_LAYOUT_CHW = 1
 GSPL_SH_ADD_HALF_CLAMP = 1
 GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
 GSPL_INRIA_RAW_PARAMS = 1      # gspl_inria_state.flags: scales / rotations / opacities are the model's raw parameters
+GSPL_INRIA_NO_SEGMENTS = 2     # ... never segment the backward (the plain one-workgroup-per-tile walk)
+GSPL_INRIA_FORCE_SEGMENTS = 4  # ... always (default: adaptively, while walks longer than a segment are being met)
 GSPL_BIN_SPAN_BYTES = 64
 GSPL_ADAM_MAX_TENSORS = 16
 
@@ -54,7 +56,7 @@ class HipLibraryError(RuntimeError):
 
 
 # `gspl_alloc_fn` / `gspl_inria_state` of include/gspl_hip.h (the fused Inria entry points)
-GSPL_BUF_GEOMETRY, GSPL_BUF_BINNING, GSPL_BUF_IMAGE, GSPL_BUF_LISTS_WORK, GSPL_BUF_LISTS = 1, 2, 3, 4, 5
+GSPL_BUF_GEOMETRY, GSPL_BUF_BINNING, GSPL_BUF_IMAGE, GSPL_BUF_LISTS_WORK, GSPL_BUF_LISTS, GSPL_BUF_CHECKPOINTS = 1, 2, 3, 4, 5, 6
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t)
 
 
@@ -63,7 +65,8 @@ class InriaState(ctypes.Structure):
                 ("means2d", ctypes.c_void_p), ("depths", ctypes.c_void_p), ("conics", ctypes.c_void_p), ("colors", ctypes.c_void_p),
                 ("clamped", ctypes.c_void_p), ("cov3d", ctypes.c_void_p), ("sh_jac", ctypes.c_void_p),
                 ("alphas", ctypes.c_void_p), ("final_Ts", ctypes.c_void_p), ("last_ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p),
-                ("flatten_ids", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("flags", ctypes.c_int)]
+                ("flatten_ids", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("flags", ctypes.c_int),
+                ("seg_ckpt", ctypes.c_void_p), ("seg_words", ctypes.c_void_p), ("seg_slots", ctypes.c_uint32), ("seg_reserved", ctypes.c_uint32)]
 
 
 _P = c_void_p

@@ -9,5 +9,5 @@ void set_error(const char* where, const char* what) {
 }
 }  // namespace gspl
 
-extern "C" int gspl_abi_version(void) { return 32; }
+extern "C" int gspl_abi_version(void) { return 33; }
 extern "C" const char* gspl_last_error(void) { return gspl::g_err; }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     const float* __restrict__ opacities, const float* __restrict__ backgrounds,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ flatten_ids,
     float* __restrict__ out_colors, float* __restrict__ out_alphas, float* __restrict__ final_Ts,
-    int32_t* __restrict__ last_ids, uint8_t* __restrict__ hit_flags, ListTiles lt) {
+    int32_t* __restrict__ last_ids, uint8_t* __restrict__ hit_flags, ListTiles lt, SegState seg) {
     using TR = ModeTraits<MODE>;
     __shared__ __attribute__((aligned(16))) float s_x[FLIST];
     __shared__ __attribute__((aligned(16))) float s_y[FLIST];
@@ -70,10 +70,19 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     for (int c = 0; c < D; ++c) acc[c] = 0.f;
     int last = start;            // one past the last contributing index
     bool done = !inside;
+    int n_ckpt = 0;              // checkpoints this wave has left (boundaries start + k SEG, k = 1 .. n_ckpt)
 
     if (!__all(done)) {
         int g_next = (start + l < end) ? flatten_ids[start + l] : 0;
         for (int base = start; base < end; base += FCHUNK) {
+            if constexpr (D == 3) {
+                // segmented backward: every pixel's state in front of list position `base`, each SEG entries (gspl_composite.h)
+                if (seg.ckpt && base > start && (((base - start) & (SEG - 1)) == 0)) {
+                    seg.ckpt[(size_t)((unsigned)base >> SEG_LOG2) * 256u + (unsigned)(w * 64 + l)] = make_float4(T, acc[0], acc[1], acc[2]);
+                    acc[0] = acc[1] = acc[2] = 0.f;      // the colour restarts with every segment (see below)
+                    ++n_ckpt;
+                }
+            }
             const int i = base + l;
             const int g = g_next;
             if (base + FCHUNK + l < end) g_next = flatten_ids[base + FCHUNK + l];     // prefetch next round's id
@@ -145,6 +154,19 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
         }
     }
 
+    if constexpr (D == 3) {
+        if (seg.ckpt) {
+            if (blockIdx.x == 0 && l < 2) seg.words[l] = 0u;      // the backward's item counter is zero when the backward starts
+            // checkpoint k holds the colour of segment k - 1 and `acc` that of the last one: suffix sums from the back (every lane
+            // rewrites its own pixel's entries), and the image = the sum of all segments
+            for (int k = n_ckpt; k >= 1; --k) {
+                float4* c = seg.ckpt + (size_t)((unsigned)(start + k * SEG) >> SEG_LOG2) * 256u + (unsigned)(w * 64 + l);
+                const float4 v = *c;
+                *c = make_float4(v.x, acc[0], acc[1], acc[2]);
+                acc[0] += v.y; acc[1] += v.z; acc[2] += v.w;
+            }
+        }
+    }
     if (inside) {
         const int64_t pix = (int64_t)py * width + px;
 #pragma unroll
@@ -164,15 +186,18 @@ template <int D, int MODE, bool CHW>
 static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_isects,
                       const float* means2d, const float* conics, const float* colors, const float* opacities,
                       const float* backgrounds, const int32_t* offsets, const int32_t* flatten_ids,
-                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, uint8_t* hit_flags, hipStream_t s, ListTiles lt) {
+                      float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids, uint8_t* hit_flags, hipStream_t s, ListTiles lt,
+                      const SegState* seg_in) {
+    SegState seg = {};
+    if (seg_in && D == 3 && lt.log2 == 4) seg = *seg_in;      // checkpoints: 16-pixel list tiles, three channels
     if (hit_flags)
         hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, true>), dim3(4 * n_tiles), dim3(64), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, lt);
+                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, lt, seg);
     else
         hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, false>), dim3(4 * n_tiles), dim3(64), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,
-                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, lt);
+                           offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, lt, seg);
     return check_launch("composite_fwd");
 }
 
@@ -284,6 +309,18 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
                                   const int32_t* offsets, const int32_t* flatten_ids,
                                   float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids,
                                   uint8_t* hit_flags, void* stream) {
+    return gspl::composite_fwd_impl(N, n_isects, D, mode, layout, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, tile_w, tile_h,
+                                    offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, stream, nullptr);
+}
+
+// (seg: the fused Inria call's checkpoint state for the segmented backward, gspl_composite.h; NULL = off)
+int gspl::composite_fwd_impl(int N, int64_t n_isects, int D, int mode, int layout,
+                                  const float* means2d, const float* conics, const float* colors,
+                                  const float* opacities, const float* backgrounds,
+                                  int width, int height, int tile_size, int tile_w, int tile_h,
+                                  const int32_t* offsets, const int32_t* flatten_ids,
+                                  float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids,
+                                  uint8_t* hit_flags, void* stream, const SegState* seg) {
     using namespace gspl;
     int rc = check_composite_args(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_fwd: bad argument");
     if (rc != GSPL_OK) return rc;
@@ -294,7 +331,7 @@ extern "C" int gspl_composite_fwd(int N, int64_t n_isects, int D, int mode, int 
     const int ctw = (width + TILE - 1) / TILE, n_tiles = ctw * ((height + TILE - 1) / TILE);
     hipStream_t s = (hipStream_t)stream;
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, s, lt)
+#define CALL_FWD(kD, M, C) rc = launch_fwd<kD, M, C>(n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, out_colors, out_alphas, final_Ts, last_ids, hit_flags, s, lt, seg)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_FWD) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_FWD) }

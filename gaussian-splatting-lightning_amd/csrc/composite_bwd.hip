@@ -40,7 +40,11 @@ static constexpr int B2_NT = 64 * B2_NW;
 static_assert(B2CHUNK <= B2_NT || B2_NW == 2, "a round is staged by one pass of the workgroup's threads");
 
 
-template <int D, int MODE, bool CHW, bool ABS, bool PACKED>
+// SEGM (gspl_composite.h, SegState) — 0: the plain walk, one workgroup per tile, whole list (it raises the host's flag when it meets
+// a walk longer than SEG: the next frames then run segmented).  1: the workgroup walks segment 0 of its tile — the whole walk when it
+// is at most SEG entries — and publishes the other segments of a longer walk as work items.  2: the launch behind it: one workgroup
+// per item slot, the published items are served, the other workgroups leave at once.
+template <int D, int MODE, bool CHW, bool ABS, bool PACKED, int SEGM = 0>
 __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     int n_tiles, int tile_w, int width, int height, int64_t n_isects,
     const float* __restrict__ means2d, const float* __restrict__ conics, const float* __restrict__ colors,
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     const float* __restrict__ v_out_colors, const float* __restrict__ v_out_alphas,
     float* __restrict__ v_means2d, float* __restrict__ v_means2d_abs,
     float* __restrict__ v_conics, float* __restrict__ v_colors, float* __restrict__ v_opacities, int packed_stride,
-    uint8_t* __restrict__ hit_flags) {
+    uint8_t* __restrict__ hit_flags, SegState seg) {
     using TR = ModeTraits<MODE>;
     constexpr int NV = BwdVals<D, ABS>::N;
     constexpr int RS = BwdRec<D>::STRIDE;
@@ -69,9 +73,19 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     float* s_vo = VO_REGS ? s_slab : s_vo_keep;       // [wave][column 0..15][channel][row]
     __shared__ int s_last;
 
-    const int tile = xcd_remap(blockIdx.x, n_tiles);
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const int ws = w;
+    // (SEGM == 2: one workgroup per work-item SLOT — the host knows how many there can be, not how many there are; the surplus
+    // leaves at once.  A loop over items instead keeps every kernel argument alive across the walk: 106 scalar registers, spills.)
+    int tile = 0, segidx = 0;
+    if constexpr (SEGM == 2) {
+        if (blockIdx.x >= min(*seg.count(), seg.slots)) return;
+        const uint32_t item = seg.work()[blockIdx.x];
+        tile = (int)(item >> 8); segidx = (int)(item & 255u);
+    } else {
+        tile = xcd_remap(blockIdx.x, n_tiles);
+    }
+    {
     const int tx = (tile % tile_w) * TILE, ty = (tile / tile_w) * TILE;
     const int pxA = tx + (l & 7), pxB = pxA + 8;
     const int py = ty + w * 8 + (l >> 3);
@@ -126,6 +140,52 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     __syncthreads();
     const int block_last = s_last;
     const int wave_last = wl;
+    // the list range [seg_lo, seg_hi) this workgroup walks: the whole walk [start, block_last), or one segment of a long one
+    int seg_lo = start, seg_hi = block_last;
+    if constexpr (SEGM == 0) {
+        // a walk longer than a segment: tell the host (a word of pinned memory it looks at before the next frames) — it switches the
+        // segmented form on.  A frame of short walks never gets here.
+        if (seg.host_flag && t == 0 && block_last - start > SEG_TRIGGER) *(volatile uint32_t*)seg.host_flag = 1u;
+    }
+    if constexpr (SEGM != 0) {
+        const int walked = block_last - start;
+        const int nseg = walked > 0 ? min((walked + SEG - 1) >> SEG_LOG2, SEG_MAX) : 0;
+        if constexpr (SEGM == 1) {
+            if (nseg > 1 && t == 0) {
+                // segments 1.. of this walk: work items of the launch that follows (plain stores: read after this kernel has ended)
+                const uint32_t pos = atomicAdd(seg.count(), (uint32_t)(nseg - 1));
+                for (int sgm = 1; sgm < nseg; ++sgm)
+                    if (pos + (uint32_t)(sgm - 1) < seg.slots) seg.work()[pos + (uint32_t)(sgm - 1)] = ((uint32_t)tile << 8) | (uint32_t)sgm;
+                if (seg.host_flag && walked > SEG_TRIGGER) *(volatile uint32_t*)seg.host_flag = 1u;      // (keeps the segmented form on)
+            }
+        }
+        if (nseg > 1) {
+            seg_lo = start + segidx * SEG;
+            seg_hi = (segidx + 1 < nseg) ? start + (segidx + 1) * SEG : block_last;
+            if (seg_hi < block_last) {
+                // a pixel that goes on beyond the far end of the segment starts from the forward's checkpoint there: T in front of
+                // entry seg_hi, and R = T_final (v_alpha - bg.vo) - vo . (colour accumulated behind that entry)
+                const size_t slot = (size_t)((unsigned)seg_hi >> SEG_LOG2) * 256u;
+                const int lasts[2] = {lastA, lastB};
+                float Tn[2] = {T2.x, T2.y}, Rn[2] = {R2.x, R2.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (lasts[e] > seg_hi) {
+                        const float4 ck = seg.ckpt[slot + (unsigned)((2 * w + e) * 64 + l)];
+                        const float ckc[3] = {ck.y, ck.z, ck.w};
+                        float behind = 0.f;
+#pragma unroll
+                        for (int c = 0; c < D; ++c) behind = fmaf(e == 0 ? vo[c].x : vo[c].y, ckc[c < 3 ? c : 0], behind);
+                        Tn[e] = ck.x;
+                        Rn[e] = Rn[e] - behind;
+                    }
+                }
+                T2 = (v2f){Tn[0], Tn[1]}; R2 = (v2f){Rn[0], Rn[1]};
+            }
+        } else if (segidx > 0) {
+            seg_lo = seg_hi = start;      // (a work item for a walk that is not long: nothing to do — cannot happen, the forward lists none)
+        }
+    }
 
     int nb = 0;                              // splats waiting in the phase-2 batch (wave-uniform)
     int batch_j = 0;                         // lane b holds the staged slot index of batch entry b
@@ -213,14 +273,14 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     };
 
     // the staged Gaussian ids are fetched one round ahead, so that a round's gather does not wait for them
-    int g_next = (block_last - 1 - t >= start && t < B2CHUNK) ? flatten_ids[block_last - 1 - t] : 0;
-    for (int hi = block_last; hi > start; hi -= B2CHUNK) {
-        const int lo = max(start, hi - B2CHUNK);
+    int g_next = (seg_hi - 1 - t >= seg_lo && t < B2CHUNK) ? flatten_ids[seg_hi - 1 - t] : 0;
+    for (int hi = seg_hi; hi > seg_lo; hi -= B2CHUNK) {
+        const int lo = max(seg_lo, hi - B2CHUNK);
         const int cnt = hi - lo;
         const int g = g_next;
         {
             const int i_next = hi - B2CHUNK - 1 - t;
-            if (i_next >= start && t < B2CHUNK) g_next = flatten_ids[i_next];
+            if (i_next >= seg_lo && t < B2CHUNK) g_next = flatten_ids[i_next];
         }
         if (t < cnt) {
             s_id[t] = g;
@@ -336,6 +396,7 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
         }
         if (hit_flags && t < cnt && s_id[t] < 0) hit_flags[s_id[t] & 0x7fffffff] = 1;      // one store per (tile, splat) that was composited
         __syncthreads();
+    }
     }
 }
 
@@ -481,7 +542,7 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
                       const float* final_Ts, const int32_t* last_ids,
                       const float* v_out_colors, const float* v_out_alphas,
                       float* v_means2d, float* v_means2d_abs, float* v_conics, float* v_colors, float* v_opacities,
-                      hipStream_t s, int packed_stride, uint8_t* hit_flags, ListTiles lt) {
+                      hipStream_t s, int packed_stride, uint8_t* hit_flags, ListTiles lt, const SegState* seg_in = nullptr) {
 #define GSPL_BWD_ARGS n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, \
                       final_Ts, last_ids, v_out_colors, v_out_alphas, v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities,   \
                       packed_stride, hit_flags
@@ -490,8 +551,19 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
         else hipLaunchKernelGGL((composite_bwd_block_kernel<D, MODE, CHW, false, PACKED>), dim3(4 * n_tiles), dim3(64), 0, s, GSPL_BWD_ARGS, lt);
         return check_launch("composite_bwd");
     }
-    if (absgrad) hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS);
-    else hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS);
+    SegState plain = {};
+    if (seg_in) plain.host_flag = seg_in->host_flag;
+    if constexpr (D == 3 && CHW && PACKED) {
+        // the segmented form (the fused Inria call with checkpoints from its forward): regular gradients only — the deterministic mode
+        // and absgrad keep the one-workgroup-per-tile walk
+        if (seg_in && seg_in->ckpt && !absgrad && packed_stride > 0) {
+            hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED, 1>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS, *seg_in);
+            hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED, 2>), dim3(seg_in->slots), dim3(B2_NT), 0, s, GSPL_BWD_ARGS, *seg_in);
+            return check_launch("composite_bwd(segmented)");
+        }
+    }
+    if (absgrad) hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, true, PACKED>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS, plain);
+    else hipLaunchKernelGGL((composite_bwd2_kernel<D, MODE, CHW, false, PACKED>), dim3(n_tiles), dim3(B2_NT), 0, s, GSPL_BWD_ARGS, plain);
 #undef GSPL_BWD_ARGS
     return check_launch("composite_bwd");
 }
@@ -584,6 +656,19 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
                                          const float* final_Ts, const int32_t* last_ids,
                                          const float* v_out_colors, const float* v_out_alphas,
                                          float* v_packed, int packed_stride, int absgrad, uint8_t* hit_flags, void* stream) {
+    return gspl::composite_bwd_packed_impl(N, n_isects, D, mode, layout, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, tile_w,
+                                           tile_h, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, packed_stride, absgrad,
+                                           hit_flags, stream, nullptr);
+}
+
+int gspl::composite_bwd_packed_impl(int N, int64_t n_isects, int D, int mode, int layout,
+                                         const float* means2d, const float* conics, const float* colors,
+                                         const float* opacities, const float* backgrounds,
+                                         int width, int height, int tile_size, int tile_w, int tile_h,
+                                         const int32_t* offsets, const int32_t* flatten_ids,
+                                         const float* final_Ts, const int32_t* last_ids,
+                                         const float* v_out_colors, const float* v_out_alphas,
+                                         float* v_packed, int packed_stride, int absgrad, uint8_t* hit_flags, void* stream, const SegState* seg) {
     using namespace gspl;
     int rc = check_composite_args(N, n_isects, D, mode, layout, width, height, tile_size, tile_w, tile_h, "composite_bwd_packed: bad argument");
     if (rc != GSPL_OK) return rc;
@@ -619,7 +704,8 @@ extern "C" int gspl_composite_bwd_packed(int N, int64_t n_isects, int D, int mod
         packed_stride = -nv;
     }
     rc = GSPL_ERR_UNSUPPORTED;
-#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride, hit_flags, lt)
+    if (ordered) seg = nullptr;      // (rows per list entry, one writer each: the plain walk)
+#define CALL_BWDP(kD, M, C) rc = launch_bwd<kD, M, C, true>(ag, n_tiles, ctw, width, height, n_isects, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, final_Ts, last_ids, v_out_colors, v_out_alphas, v_packed, nullptr, nullptr, nullptr, nullptr, s, packed_stride, hit_flags, lt, seg)
     if (mode == GSPL_MODE_GSPLAT) {
         if (layout == GSPL_LAYOUT_HWC) { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, false, CALL_BWDP) }
         else { GSPL_DISPATCH_D(D, GSPL_MODE_GSPLAT, true, CALL_BWDP) }

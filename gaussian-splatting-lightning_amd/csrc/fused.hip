@@ -14,8 +14,8 @@
 #include <mutex>
 #include <utility>
 #include <vector>
-#include "gspl_device.h"
-#include "gspl_host.h"
+#include "gspl_composite.h"
+#include "gspl_sort.h"
 
 namespace gspl {
 
@@ -73,6 +73,38 @@ static bool wait_for_ticket(const int64_t* host, unsigned long long ticket, hipS
         }
     }
 }
+// Segmented backward, adaptive (gspl_composite.h): one word of pinned host memory per device that the backward kernels raise when a
+// tile's walk is longer than a segment (written from the device, read by the host WITHOUT a synchronisation before a later forward —
+// whenever it lands), and the number of frames the segmented form stays on after the word was last seen raised.  Process-wide:
+// autograd runs the backward on a thread of its own.
+static std::mutex g_seg_mu;
+static uint32_t* g_seg_flag[64] = {};
+static int g_seg_sticky[64] = {};
+static uint32_t* seg_flag_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    if (!g_seg_flag[dev]) {
+        void* q = nullptr;
+        if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_seg_flag[dev] = (uint32_t*)q;
+        *g_seg_flag[dev] = 0u;
+    }
+    return g_seg_flag[dev];
+}
+// the forward's decision for this frame: `force` (GSPL_INRIA_FORCE_SEGMENTS) or a long walk seen within the last 64 frames
+static bool seg_wanted(bool force) {
+    uint32_t* flag = seg_flag_word();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return force;
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    if (flag && __atomic_load_n(flag, __ATOMIC_RELAXED) != 0u) { __atomic_store_n(flag, 0u, __ATOMIC_RELAXED); g_seg_sticky[dev] = 64; }
+    const bool on = force || g_seg_sticky[dev] > 0;
+    if (g_seg_sticky[dev] > 0) --g_seg_sticky[dev];
+    return on;
+}
+
 static unsigned long long next_ticket() {
     static thread_local unsigned long long t = 0ull;
     return ++t;
@@ -185,7 +217,7 @@ extern "C" int gspl_rasterize_inria_fwd(
     const int tile = 16, tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream, ss = (hipStream_t)side_stream;
     const int flags = st->flags;
-    if (flags & ~GSPL_INRIA_RAW_PARAMS) return fail_arg("rasterize_inria_fwd: unknown state->flags (zero the struct before the call)");
+    if (flags & ~(GSPL_INRIA_RAW_PARAMS | GSPL_INRIA_NO_SEGMENTS | GSPL_INRIA_FORCE_SEGMENTS)) return fail_arg("rasterize_inria_fwd: unknown state->flags (zero the struct before the call)");
     const bool raw = (flags & GSPL_INRIA_RAW_PARAMS) != 0;
     if (raw && (cov3D_precomp || (N > 0 && (!scales || !rotations)))) return fail_arg("rasterize_inria_fwd: raw parameters need scales and rotations");
     memset(st, 0, sizeof(*st));
@@ -205,6 +237,26 @@ extern "C" int gspl_rasterize_inria_fwd(
     st->opacities = const_cast<float*>(opacities);
     st->alphas = (float*)(img + im.alphas); st->final_Ts = (float*)(img + im.final_Ts); st->last_ids = (int32_t*)(img + im.last_ids);
     st->offsets = (int32_t*)(img + im.offsets);
+    // Segmented backward (gspl_composite.h): checkpoints + the frame's counters, sized by the list CAPACITY (known before the lists
+    // are: the guess, or the real length), from one allocation kept until the backward.  Off with GSPL_INRIA_NO_SEGMENTS, in the
+    // deterministic mode (its backward writes one row per list entry) and when the caller's allocator says no.
+    SegState seg = {};
+    const bool want_seg = !(flags & GSPL_INRIA_NO_SEGMENTS) && gspl_get_deterministic() == 0 && seg_wanted((flags & GSPL_INRIA_FORCE_SEGMENTS) != 0);
+    auto make_seg = [&](int64_t cap) -> const SegState* {
+        seg = SegState{};
+        st->seg_ckpt = nullptr; st->seg_words = nullptr; st->seg_slots = 0u;
+        if (!want_seg || cap <= SEG) return nullptr;
+        const uint32_t slots = (uint32_t)(cap >> SEG_LOG2) + 2u;
+        const size_t words = 2 + (size_t)slots;
+        const size_t head = up256(words * sizeof(uint32_t));
+        char* blk = (char*)alloc(alloc_ctx, GSPL_BUF_CHECKPOINTS, head + (size_t)slots * 256 * sizeof(float4));
+        if (!blk) return nullptr;
+        uint32_t* wds = (uint32_t*)blk;
+        seg.words = wds; seg.slots = slots;      // (the item counter is cleared by the forward kernel itself)
+        seg.ckpt = (float4*)(blk + head);
+        st->seg_ckpt = seg.ckpt; st->seg_words = wds; st->seg_slots = slots;
+        return &seg;
+    };
     int32_t* order = (int32_t*)(geom + g.order);
     int64_t* cum = (int64_t*)(geom + g.cum);
     int32_t* big_list = (int32_t*)(geom + g.big_list);
@@ -267,13 +319,14 @@ extern "C" int gspl_rasterize_inria_fwd(
                 // enqueued — by then the scan has long finished — and only a guess that turns out too low costs a second round.
                 st->flatten_ids = (int32_t*)alloc(alloc_ctx, GSPL_BUF_LISTS, 4 * (size_t)capacity);
                 if (!st->flatten_ids) { (void)wait_count(); return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL"); }
+                const SegState* sg = make_seg(capacity);
                 rc = gspl_bin_sort_device_count(N, tile_w, tile_h, cum + (N - 1), capacity, st->flatten_ids, st->offsets, ws2, ws2_bytes, s);
                 if (rc != GSPL_OK) { (void)wait_count(); return rc; }
                 if (ev_col) (void)hipStreamWaitEvent(s, ev_col, 0);      // colours are ready before compositing reads them
                 {
                     ProfScope prof(0, s);
-                    rc = gspl_composite_fwd(N, -1, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height,
-                                            tile, tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
+                    rc = composite_fwd_impl(N, -1, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height,
+                                            tile, tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s, sg);
                 }
                 const bool arrived = wait_count();
                 n_isects = host[0];
@@ -300,6 +353,7 @@ extern "C" int gspl_rasterize_inria_fwd(
             }
             st->flatten_ids = n_isects > 0 ? (int32_t*)alloc(alloc_ctx, GSPL_BUF_LISTS, 4 * (size_t)n_isects) : nullptr;
             if (n_isects > 0 && !st->flatten_ids) return fail_arg("rasterize_inria_fwd: allocation call-back returned NULL");
+            if (n_isects > 0) (void)make_seg(n_isects); else (void)make_seg(0);
             rc = gspl_bin_sort(N, tile_w, tile_h, n_isects, capacity > n_isects ? capacity : n_isects, st->flatten_ids, st->offsets, ws2, ws2_bytes, s);
             if (rc != GSPL_OK) return rc;
         }
@@ -310,8 +364,9 @@ extern "C" int gspl_rasterize_inria_fwd(
     }
     st->n_isects = n_isects;
     ProfScope prof(0, s);
-    return gspl_composite_fwd(N, n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height, tile,
-                              tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s);
+    return composite_fwd_impl(N, n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height, tile,
+                              tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s,
+                              seg.ckpt ? &seg : nullptr);
 }
 
 namespace gspl {
@@ -387,10 +442,16 @@ static int gspl::rasterize_inria_bwd_impl(
         opacities = st->opacities;         // the activated values the forward composited with
     }
     if (st->n_isects > 0) {
+        SegState seg = {};
+        if (st->seg_ckpt && st->seg_words) {      // the forward left checkpoints: long walks are cut into segments (gspl_composite.h)
+            seg.ckpt = (float4*)st->seg_ckpt;
+            seg.words = st->seg_words; seg.slots = st->seg_slots;
+        }
+        if (!(st->flags & GSPL_INRIA_NO_SEGMENTS)) seg.host_flag = seg_flag_word();      // plain or segmented: long walks are reported
         ProfScope prof(1, s);
-        rc = gspl_composite_bwd_packed(N, st->n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width,
+        rc = composite_bwd_packed_impl(N, st->n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width,
                                        height, tile, tile_w, tile_h, st->offsets, st->flatten_ids, st->final_Ts, st->last_ids, v_out_color, nullptr,
-                                       packed, 9, 0, hit_flags, s);
+                                       packed, 9, 0, hit_flags, s, &seg);
         if (rc != GSPL_OK) return rc;
     }
     return inria_preprocess_bwd_impl(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,

@@ -120,6 +120,41 @@ __device__ __forceinline__ unsigned band_half_mask(float mx, float my, float a, 
     return m;
 }
 
+// ---- segmented backward (round 5) -------------------------------------------------------------------------------------------------
+// The backward walks a tile's list back to front with one workgroup: in a scene whose lists are heavy-tailed (a trained model: a few
+// tiles walk thousands of entries where the median walks a few hundred) the launch lasts as long as its longest tile
+// (`synthetic.scene_surfaces`: 0.57 ms against ~0.40 for the same work spread evenly).  The forward therefore leaves a CHECKPOINT of
+// every pixel's running state each SEG list entries, and the backward cuts a walk longer than SEG into segments that ANY workgroup
+// may process: a pixel that continues beyond a segment's far end starts from the checkpoint there (its transmittance in front of
+// that entry, and the colour accumulated from that entry on) instead of from its final state.
+//   forward   accumulates the colour PER SEGMENT (the sum restarts at every boundary; the image is the sum of the segment sums) and,
+//             when it is done, turns the stored segment sums into suffix sums from the back — small deep contributions are added to
+//             each other first, as the backward's own running sum does (a difference "final - prefix" would cancel).
+//             ckpt[(p >> SEG_LOG2) * 256 + quadrant * 64 + lane] = (T in front of entry p, colour accumulated from entry p on),
+//             p = tile start + k SEG, k >= 1: boundaries of different tiles are more than SEG apart (each lies at least SEG behind
+//             its tile's start), so p >> SEG_LOG2 is a collision-free slot index.  It also clears the frame's item counter.
+//   backward  two launches: the first is the plain kernel cut to segment 0 of every tile (a walk of at most SEG entries: all of it);
+//             a tile with a longer walk PUBLISHES its segments 1.. as work items, and the second launch — one workgroup per item
+//             slot (list capacity / SEG: what the host knows) — serves them.  No workgroup waits for another; nothing depends on
+//             dispatch order.
+//   ADAPTIVE  a frame is segmented only while long walks are being seen: the plain backward raises a word of pinned host memory when
+//             it meets a walk longer than SEG_TRIGGER (the segmented one likewise), the host looks at it — no synchronisation —
+//             before the next forward and keeps the segmented form on for the following 64 frames.  A scene without long walks
+//             (every tile of the metric workload) never leaves the plain kernels: no checkpoint, no second launch.
+// D == 3 only (a checkpoint is one float4); off (ckpt == nullptr) everywhere else.
+static constexpr int SEG_LOG2 = 9;
+static constexpr int SEG = 1 << SEG_LOG2;
+static constexpr int SEG_TRIGGER = 3 * SEG;    // a walk longer than this switches the segmented form on (a tile of two segments is not worth a second launch)
+static constexpr int SEG_MAX = 255;            // segments per tile (8 bits in a work item); the last one takes whatever is left
+struct SegState {
+    float4* ckpt;
+    uint32_t* words;      // [0]: published work items (zero before the backward); [2 .. 2 + slots): the items, (tile << 8) | segment
+    uint32_t* host_flag;  // pinned host word: "a walk longer than SEG was met" (nullable)
+    uint32_t slots;
+    __host__ __device__ uint32_t* count() const { return words; }
+    __host__ __device__ uint32_t* work() const { return words + 2; }
+};
+
 __device__ __forceinline__ void tile_range(int tile, int n_tiles, int64_t n_isects,
                                            const int32_t* __restrict__ offsets, int& start, int& end) {
     start = offsets[tile];
@@ -154,6 +189,17 @@ template <int D, bool ABS> struct BwdVals { static constexpr int N = 6 + D + (AB
 
 int check_composite_args(int N, int64_t n_isects, int D, int mode, int layout, int width, int height,
                          int tile_size, int tile_w, int tile_h, const char* who);
+
+// gspl_composite_fwd / gspl_composite_bwd_packed with the segmentation state of the fused Inria call (fused.hip); seg == NULL: off
+int composite_fwd_impl(int N, int64_t n_isects, int D, int mode, int layout, const float* means2d, const float* conics, const float* colors,
+                       const float* opacities, const float* backgrounds, int width, int height, int tile_size, int tile_w, int tile_h,
+                       const int32_t* offsets, const int32_t* flatten_ids, float* out_colors, float* out_alphas, float* final_Ts, int32_t* last_ids,
+                       uint8_t* hit_flags, void* stream, const SegState* seg);
+int composite_bwd_packed_impl(int N, int64_t n_isects, int D, int mode, int layout, const float* means2d, const float* conics, const float* colors,
+                              const float* opacities, const float* backgrounds, int width, int height, int tile_size, int tile_w, int tile_h,
+                              const int32_t* offsets, const int32_t* flatten_ids, const float* final_Ts, const int32_t* last_ids,
+                              const float* v_out_colors, const float* v_out_alphas, float* v_packed, int packed_stride, int absgrad, uint8_t* hit_flags,
+                              void* stream, const SegState* seg);
 
 }  // namespace gspl
 

@@ -48,6 +48,7 @@ class _OpsPackage(_types.ModuleType):
     TRACK_HIT_PIXELS = _forward("track_hit_pixels")
     KEEP_LAST_RASTER = _forward("keep_last_raster")
     SIDE_LOW_PRIORITY = _forward("side_low_priority")
+    SEGMENTED_BACKWARD = _forward("segmented_backward")
     LAST_RASTER = _forward("last_raster")
     SPECULATION = _forward("speculation")
     PENDING_UPDATES = _forward("pending_updates")

@@ -3,7 +3,8 @@ the process-wide switches (tests and bench flip them), and everything that is ke
 where it matters), so that several devices in one process and the viewer's threads (one renderer call per client thread,
 internal/viewer/client.py:114) never share a slot that belongs to another device.
 
-    STATE.fused_inria, .device_side_list_length, .speculative_emit, .track_hit_pixels, .keep_last_raster, .side_low_priority
+    STATE.fused_inria, .device_side_list_length, .speculative_emit, .track_hit_pixels, .keep_last_raster, .side_low_priority,
+          .segmented_backward
     STATE.last_isects[(device index, tiles x, tiles y)]    list length of the last frame = the guess of the next speculative emission
     STATE.speculation                                       how the guesses fared (frames / cold / misses; bench.py reports them)
     STATE.events[device index], .pinned_words, .pinned_ends[C]    free lists (an event / a pinned word costs ~15 us to construct)
@@ -23,6 +24,7 @@ from typing import Optional
 
 class RuntimeState:
     __slots__ = ("fused_inria", "device_side_list_length", "speculative_emit", "track_hit_pixels", "keep_last_raster", "side_low_priority",
+                 "segmented_backward",
                  "last_isects", "speculation", "events", "pinned_words", "pinned_ends", "pending_updates", "last_raster", "consts",
                  "identity_slots", "zero_scalars", "new_event", "backward_optimizers")
 
@@ -42,6 +44,12 @@ class RuntimeState:
         self.keep_last_raster: bool = False
         # the colour kernel on the library's lowest-priority stream instead of a default-priority torch stream (measured: no gain)
         self.side_low_priority: bool = env("GSPL_SIDE_LOW_PRIORITY", "0") != "0"
+        # segmented backward of the fused Inria call (csrc/gspl_composite.h): while tiles whose walk is longer than 512 list entries
+        # are being met — the heavy-tailed lists of a trained scene — the forward leaves per-pixel checkpoints and the backward cuts
+        # such a walk into segments for independent workgroups.  True (GSPL_SEGMENTED_BWD=1, default): adaptive, a scene without long
+        # walks never leaves the plain kernels; "always": every frame (tests); False (=0): never.
+        _seg = env("GSPL_SEGMENTED_BWD", "1")
+        self.segmented_backward = False if _seg == "0" else ("always" if _seg == "always" else True)
         self.last_isects: dict = {}
         self.speculation: dict = {"frames": 0, "cold": 0, "misses": 0}
         self.events: dict = {}

@@ -213,7 +213,8 @@ class _InriaFusedFn(torch.autograd.Function):
         guess = S.last_isects.get(key, 0)
         hint = min(int(guess * 1.25) + 65536, MAX_ISECTS) if (S.speculative_emit and guess > 0) else 0
         state = L.InriaState()
-        state.flags = L.GSPL_INRIA_RAW_PARAMS if raw_params else 0
+        state.flags = (L.GSPL_INRIA_RAW_PARAMS if raw_params else 0) | ((L.GSPL_INRIA_FORCE_SEGMENTS if S.segmented_backward == "always" else 0)
+                       if (S.segmented_backward and any(ctx.needs_input_grad)) else L.GSPL_INRIA_NO_SEGMENTS)      # (only a frame that can have a backward)
         holder = {"device": dev}
         _ALLOC_TLS.holder = holder
         side = _side_stream(dev)
@@ -274,7 +275,10 @@ class _InriaFusedFn(torch.autograd.Function):
                                flatten_ids=(lists[:4 * nI].view(torch.int32) if lists is not None else torch.empty(0, dtype=torch.int32, device=dev)),
                                offsets=_view(img, state.offsets, (tile_w * tile_h,), torch.int32), radii=radii,
                                depths=_view(geom, state.depths, (N,), torch.float32),
-                               last_ids=_view(img, state.last_ids, (H, W), torch.int32))
+                               last_ids=_view(img, state.last_ids, (H, W), torch.int32),
+                               # segmented backward: the word in which the backward counts the segments it published (beyond each tile's
+                               # first; 0 after a backward: every walk was short; None: no checkpoints were taken)
+                               segment_count=(_view(holder[L.GSPL_BUF_CHECKPOINTS][-1], state.seg_words, (1,), torch.int32) if state.seg_ckpt else None))
         return out, radii
 
     @staticmethod

@@ -385,7 +385,8 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
  *    out_color [3,H,W], radii [N] are caller-allocated outputs; `state` receives the pointers the backward needs and
  *    n_isects (the list length — feed it back as the next frame's hint); its `flags` field is read BEFORE it is filled.
  * ---------------------------------------------------------------------------------------- */
-enum { GSPL_BUF_GEOMETRY = 1, GSPL_BUF_BINNING = 2, GSPL_BUF_IMAGE = 3, GSPL_BUF_LISTS_WORK = 4, GSPL_BUF_LISTS = 5 };
+enum { GSPL_BUF_GEOMETRY = 1, GSPL_BUF_BINNING = 2, GSPL_BUF_IMAGE = 3, GSPL_BUF_LISTS_WORK = 4, GSPL_BUF_LISTS = 5,
+       GSPL_BUF_CHECKPOINTS = 6 /* segmented backward: 4 KB per 512 list entries of capacity; kept until the backward like IMAGE / LISTS */ };
 typedef void* (*gspl_alloc_fn)(void* ctx, int tag, size_t bytes);      /* device memory, 256-byte aligned; NULL = failure */
 typedef struct gspl_inria_state {
     int N, width, height;
@@ -395,14 +396,19 @@ typedef struct gspl_inria_state {
     int32_t* flatten_ids;                                                                              /* GSPL_BUF_LISTS */
     float* opacities;      /* GSPL_BUF_GEOMETRY: the opacities compositing read — the caller's tensor, or with GSPL_INRIA_RAW_PARAMS
                               sigmoid(raw) [N] as the forward stored it */
-    int flags;             /* IN (forward; the backward reads it back): 0 — a zeroed struct — or GSPL_INRIA_RAW_PARAMS */
+    int flags;             /* IN (forward; the backward reads it back): 0 — a zeroed struct — or GSPL_INRIA_RAW_PARAMS | GSPL_INRIA_NO_SEGMENTS */
+    /* segmented backward (ABI 33): per-pixel checkpoints the forward left every 512 list entries and the words
+     * [count | - | work items seg_slots] in front of them (one GSPL_BUF_CHECKPOINTS block); seg_ckpt == NULL: this frame is not segmented */
+    void* seg_ckpt; uint32_t* seg_words; uint32_t seg_slots; uint32_t seg_reserved;
 } gspl_inria_state;
 /* GSPL_INRIA_RAW_PARAMS: `scales`, `rotations`, `opacities` are the model's RAW parameters and the activations of the reference's
  *    model — scale_activation = exp, rotation_activation = F.normalize (x / max(|x|, 1e-12)), opacity_activation = sigmoid
  *    (internal/models/vanilla_gaussian.py:345-358, applied by `get_scaling` / `get_rotation` / `get_opacity` in
  *    vanilla_renderer.py:62-77 before every render, differentiated by autograd after every backward) — run inside the preprocess
  *    kernels; the backward returns the gradients of the raw parameters.  Needs scales + rotations (no cov3D_precomp). */
-enum { GSPL_INRIA_RAW_PARAMS = 1 };
+enum { GSPL_INRIA_RAW_PARAMS = 1,
+       GSPL_INRIA_NO_SEGMENTS = 2 /* never: the backward walks every tile's list with one workgroup, however long */,
+       GSPL_INRIA_FORCE_SEGMENTS = 4 /* always take checkpoints (default: only while walks longer than a segment are being met) */ };
 size_t gspl_rasterize_inria_geometry_bytes(int N);
 size_t gspl_rasterize_inria_image_bytes(int width, int height);
 int gspl_rasterize_inria_fwd(int N, int degree, int n_coeffs,

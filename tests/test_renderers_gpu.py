@@ -153,7 +153,7 @@ def test_raw_parameters_need_a_zeroed_state_and_the_scale_rotation_pair():
         ops.GaussianRasterizer(settings)(m, torch.zeros_like(m), o, shs=sh, cov3D_precomp=cov, raw_parameters=True)
     # the C boundary itself: unknown flag bits are refused before anything is launched
     state = L.InriaState()
-    state.flags = 6
+    state.flags = 64
     out, radii = torch.empty(3, cam["height"], cam["width"], device=DEV), torch.empty(500, dtype=torch.int32, device=DEV)
     cb = L.ALLOC_FN(lambda ctx, tag, n: 0)
     with pytest.raises(Exception, match="flags"):
