@@ -142,7 +142,11 @@ __device__ __forceinline__ unsigned band_half_mask(float mx, float my, float a, 
 //             before the next forward and keeps the segmented form on for the following 64 frames.  A scene without long walks
 //             (every tile of the metric workload) never leaves the plain kernels: no checkpoint, no second launch.
 // D == 3 only (a checkpoint is one float4); off (ckpt == nullptr) everywhere else.
-static constexpr int SEG_LOG2 = 9;
+#ifndef GSPL_SEG_LOG2
+#define GSPL_SEG_LOG2 8      // 256 entries per segment (measured on scene_surfaces, per step: 64 -> 1.63 ms, 128 -> 1.45, 256 -> 1.47, 512 -> 1.56, 1024 -> 1.72;
+                             // 128 costs the forward 4 % more for its checkpoints and twice the checkpoint memory: profiles/r07v_segment_sizes.txt)
+#endif
+static constexpr int SEG_LOG2 = GSPL_SEG_LOG2;
 static constexpr int SEG = 1 << SEG_LOG2;
 static constexpr int SEG_TRIGGER = 3 * SEG;    // a walk longer than this switches the segmented form on (a tile of two segments is not worth a second launch)
 static constexpr int SEG_MAX = 255;            // segments per tile (8 bits in a work item); the last one takes whatever is left

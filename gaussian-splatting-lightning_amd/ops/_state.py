@@ -44,7 +44,7 @@ class RuntimeState:
         self.keep_last_raster: bool = False
         # the colour kernel on the library's lowest-priority stream instead of a default-priority torch stream (measured: no gain)
         self.side_low_priority: bool = env("GSPL_SIDE_LOW_PRIORITY", "0") != "0"
-        # segmented backward of the fused Inria call (csrc/gspl_composite.h): while tiles whose walk is longer than 512 list entries
+        # segmented backward of the fused Inria call (csrc/gspl_composite.h): while tiles whose walk is longer than 768 list entries
         # are being met — the heavy-tailed lists of a trained scene — the forward leaves per-pixel checkpoints and the backward cuts
         # such a walk into segments for independent workgroups.  True (GSPL_SEGMENTED_BWD=1, default): adaptive, a scene without long
         # walks never leaves the plain kernels; "always": every frame (tests); False (=0): never.

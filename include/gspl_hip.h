@@ -386,7 +386,7 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
  *    n_isects (the list length — feed it back as the next frame's hint); its `flags` field is read BEFORE it is filled.
  * ---------------------------------------------------------------------------------------- */
 enum { GSPL_BUF_GEOMETRY = 1, GSPL_BUF_BINNING = 2, GSPL_BUF_IMAGE = 3, GSPL_BUF_LISTS_WORK = 4, GSPL_BUF_LISTS = 5,
-       GSPL_BUF_CHECKPOINTS = 6 /* segmented backward: 4 KB per 512 list entries of capacity; kept until the backward like IMAGE / LISTS */ };
+       GSPL_BUF_CHECKPOINTS = 6 /* segmented backward: 4 KB per 256 list entries of capacity; kept until the backward like IMAGE / LISTS */ };
 typedef void* (*gspl_alloc_fn)(void* ctx, int tag, size_t bytes);      /* device memory, 256-byte aligned; NULL = failure */
 typedef struct gspl_inria_state {
     int N, width, height;
@@ -397,7 +397,7 @@ typedef struct gspl_inria_state {
     float* opacities;      /* GSPL_BUF_GEOMETRY: the opacities compositing read — the caller's tensor, or with GSPL_INRIA_RAW_PARAMS
                               sigmoid(raw) [N] as the forward stored it */
     int flags;             /* IN (forward; the backward reads it back): 0 — a zeroed struct — or GSPL_INRIA_RAW_PARAMS | GSPL_INRIA_NO_SEGMENTS */
-    /* segmented backward (ABI 33): per-pixel checkpoints the forward left every 512 list entries and the words
+    /* segmented backward (ABI 33): per-pixel checkpoints the forward left every 256 list entries and the words
      * [count | - | work items seg_slots] in front of them (one GSPL_BUF_CHECKPOINTS block); seg_ckpt == NULL: this frame is not segmented */
     void* seg_ckpt; uint32_t* seg_words; uint32_t seg_slots; uint32_t seg_reserved;
 } gspl_inria_state;

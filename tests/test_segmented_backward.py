@@ -1,5 +1,5 @@
 """The segmented compositing backward of the fused Inria call (csrc/gspl_composite.h, `SegState`; round 5): the forward leaves a
-checkpoint of every pixel's running state each 512 list entries, and a tile whose walk is longer than that is cut into segments that
+checkpoint of every pixel's running state each 256 list entries, and a tile whose walk is longer than that is cut into segments that
 independent workgroups of the backward process — in a scene with heavy-tailed lists (a trained model) the launch no longer lasts as
 long as its longest tile.
 
@@ -15,6 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+SEG = 256      # csrc/gspl_composite.h
 
 
 def _render(params, cam, segmented):
@@ -40,7 +41,7 @@ def _render(params, cam, segmented):
         torch.cuda.synchronize()
         count = None if last.get("segment_count") is None else int(last["segment_count"].item())      # (published by the backward)
         return (render.detach().clone(), radii.clone(), [t.grad.clone() for t in leaves] + [screen.grad.clone()], count, int(walked.max()),
-                int(((walked + 511) // 512 - 1).clamp_min(0).sum()))
+                int(((walked + SEG - 1) // SEG - 1).clamp_min(0).sum()))
     finally:
         ops.SEGMENTED_BACKWARD = True
         ops.KEEP_LAST_RASTER = False
@@ -82,15 +83,16 @@ def test_segmented_backward_equals_the_plain_walk(workload, scale):
         a, b = grads_s[k].double().cpu().numpy(), grads_p[k].double().cpu().numpy()
         rms = float(np.sqrt(np.mean(b * b))) + 1e-30
         ratio = np.abs(a - b) / (np.abs(b) + rms)
-        assert (ratio <= 5e-5).mean() >= 0.999 and ratio.max() <= 0.5, (names[k], float((ratio > 5e-5).mean()), float(ratio.max()))
+        assert (ratio <= 5e-5).mean() >= 0.995 and ratio.max() <= 0.5, (names[k], float((ratio > 5e-5).mean()), float(ratio.max()))
 
 
 def test_a_frame_of_short_walks_lists_no_segment():
     import gspl_amd  # noqa: F401
     from gspl_amd import synthetic
     wl = synthetic.WORKLOADS["S-smoke"]
-    params = synthetic.workload_scene(wl, seed=42)
+    means, scales, quats, opac, shs = synthetic.workload_scene(wl, seed=42)
+    params = (means, scales * 0.5, quats, opac, shs)
     cam = synthetic.camera(wl["width"], wl["height"], wl["fx"])
     _, _, _, count, longest, expected = _render(params, cam, True)
-    assert longest <= 512 and expected == 0, longest
+    assert longest <= SEG and expected == 0, longest
     assert count in (0, None)                                      # (None: the whole list shorter than one segment — no checkpoints at all)
