@@ -1,6 +1,6 @@
 #!/bin/bash
 # The ONE scratch script of a gpurun call (rewritten per call; outputs under gpurun_out/<tag>/, the keepers are copied to profiles/).
-tag=${1:-r08}
+tag=${1:-r09}
 cd /root/repo
 bash tools/collect_profiles_r06.sh $tag 2>&1 | tail -3
 python - <<PY
