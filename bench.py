@@ -131,7 +131,7 @@ def _mark():
     return e
 
 
-def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prewarm=False):
+def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prewarm=False, fuse_optimizer=False):
     """`--loop reference-shaped` (images/s of the Lightning loop, not of a static-N step on activated leaves): the
     consumer side restated in bench_loop.py drives `HipVanillaRenderer` through what `GaussianSplatting.training_step` does
     (internal/gaussian_splatting.py:329-397) — raw parameters behind exp / normalize / sigmoid getters (fuse_activations: evaluated
@@ -158,7 +158,9 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
         model = BL.RawGaussians(*[t.to(dev) for t in BL.perturbed(clean)], active_sh_degree=1, max_sh_degree=3)
         controller = BL.DensityController(model.n_gaussians, dev, cameras_extent=2.6, densify_from_iter=from_iter, densification_interval=interval,
                                           opacity_reset_interval=reset)
-        return targets, model, model.make_optimizers(1.0, FusedAdam), controller
+        # fuse_optimizer: both optimizers built with fuse_into_backward=True — the rasterizer's backward applies their updates (the
+        # parameters of the two optimizers are claimed together, the densification surgery's new Parameters are found by address)
+        return targets, model, model.make_optimizers(1.0, FusedAdam, **({"fuse_into_backward": True} if fuse_optimizer else {})), controller
 
     if prewarm:
         # the torch kernels of a densification event (mask gathers, cats, multinomial-free split sampling ...) are loaded on first use
@@ -995,6 +997,11 @@ def main():
                     other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False)
                     line["reference_shaped_loop"]["with_torch_activations"] = {
                         k: other[k] for k in ("activations", "images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end")}
+                    # ... and with the optimizers' updates applied by the rasterizer's backward (opt-in; on a densification step the
+                    # reference drops the step's gradients — the surgery replaces the Parameters before step() — here they were applied)
+                    fused = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_optimizer=True)
+                    line["reference_shaped_loop"]["with_fused_bwd_adam"] = {
+                        k: fused[k] for k in ("images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end", "loss_first_last")}
             except Exception as e:  # an extra: it must never take the bench line down
                 line["reference_shaped_loop"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

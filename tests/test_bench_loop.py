@@ -105,3 +105,43 @@ def test_bench_loop_controller_decisions_equal_the_oracle_controller_cpu():
     assert a["means"].shape[0] != 3000
     for k in a:
         assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_bench_loop_with_the_optimizers_inside_the_backward():
+    """The same loop with both optimizers built with fuse_into_backward=True (tests/test_fused_backward_adam.py has the bit-level
+    equality on a static model): raw parameters of TWO optimizers claimed together by the rasterizer's backward, N changing through
+    densification / pruning (the surgery's new Parameters and moments are found by address on the next backward), an opacity reset, SH
+    degree raises.  No parameter ever carries a gradient; every step counter advances once per step; the run trains as the two-kernel
+    path does — not splat for splat: on a densification step the reference drops the step's gradients (the surgery replaces the
+    Parameters before `step()`), here they have already been applied."""
+    from gspl_amd.optimizers import FusedAdam
+    dev = torch.device("cuda:0")
+    BL, renderer, cams, targets, bg, start = _setup(dev)
+    steps = 260
+    cfg = dict(densify_from_iter=40, densification_interval=40, opacity_reset_interval=120)
+    loss = lambda img, gt: (img - gt).abs().mean()
+
+    def run(fuse):
+        torch.manual_seed(11)
+        model = BL.RawGaussians(*[t.to(dev) for t in start], active_sh_degree=1)
+        ctl = BL.DensityController(model.n_gaussians, dev, 2.6, **cfg)
+        opts = model.make_optimizers(1.0, FusedAdam, **({"fuse_into_backward": True} if fuse else {}))
+        seen = []
+
+        def on_step(step, outputs):
+            if fuse:
+                seen.append(all(p.grad is None for o in opts for g in o.param_groups for p in g["params"]))
+        res = BL.run(renderer, model, ctl, opts, cams, targets, steps, bg, loss, sh_degree_up_interval=100, on_step=on_step)
+        counters = {int(o.state[p]["step"]) for o in opts for g in o.param_groups for p in g["params"] if p in o.state}
+        return res, model, ctl, seen, counters
+
+    plain, _, _, _, _ = run(False)
+    fused, model, ctl, seen, counters = run(True)
+    assert seen and all(seen), "a parameter carried a gradient although the backward applies the updates"
+    assert sum(1 for a, b in zip(fused["n"], fused["n"][1:]) if a != b) >= 4 and any(e.get("opacity_reset") for e in ctl.events)
+    assert model.active_sh_degree == 3
+    assert fused["loss"][-1] < fused["loss"][0] and abs(fused["loss"][-1] - plain["loss"][-1]) <= 0.15 * plain["loss"][-1]
+    for i, (a, b) in enumerate(zip(fused["n"], plain["n"]), start=1):
+        assert abs(a - b) <= max(50, 0.03 * b), f"step {i}: N = {a} (optimizers inside the backward) vs {b} (two-kernel path)"
+    assert max(counters) <= steps      # (moments of split / cloned rows keep their parameter's counter; nothing advanced twice)
