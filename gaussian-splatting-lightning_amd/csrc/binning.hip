@@ -541,7 +541,8 @@ int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii
                               const float* conics, const float* opacities,
                               int tile_size, int tile_w, int tile_h,
                               int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
-                              void* workspace, size_t workspace_bytes, void* stream, unsigned long long ticket) {
+                              void* workspace, size_t workspace_bytes, void* stream, unsigned long long ticket,
+                              bool depth_header_zeroed, ZeroJob then_zero) {
     if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_count: bad sizes");
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_count: bad mode");
     if (N == 0) return GSPL_OK;
@@ -565,8 +566,10 @@ int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii
     const RadixPlan& dp = w.depth;
     RadixProducer hdr;
     radix_producer_args(dp, ws + w.sort1_off, hdr);
-    rc = radix_zero(ws + w.sort1_off, dp.header_bytes, s);
-    if (rc != GSPL_OK) return rc;
+    if (!depth_header_zeroed) {
+        rc = radix_zero(ws + w.sort1_off, dp.header_bytes, s);
+        if (rc != GSPL_OK) return rc;
+    }
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL((bin_keys_kernel<GSPL_MODE_GSPLAT, true>), dim3(grid), dim3(256), 0, s, N, means2d, radii, depths, conics, opacities, tile_size, tile_w, tile_h, keys, (uint32_t*)order, counts, (SpanRecord*)spans, hdr);
     else
@@ -581,7 +584,25 @@ int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii
     // the scan also ranks the tagged (big) splats: big_list[rank] = depth index, cum_tiles[N] = how many — one 16-byte read-back
     // gives the host both numbers
     return scan_gathered_counts(nullptr, (const int32_t*)kbuf[dp.passes & 1], cum_tiles, (size_t)N, ws + w.sort1_off + w.scan_states_off, big_list, s, host_counts,
-                                host_counts ? ticket : 0ull);
+                                host_counts ? ticket : 0ull, then_zero);
+}
+
+// The two tables a frame clears, as jobs for whichever earlier kernel of the stream has threads to spare
+int bin_depth_header(int N, int n_tiles, void* count_workspace, ZeroJob& job) {
+    BinWorkspace w;
+    int rc = plan_bin(N, 0, n_tiles, w);
+    if (rc != GSPL_OK) return rc;
+    job.p = (uint4*)((char*)count_workspace + w.sort1_off);
+    job.n16 = (uint32_t)(w.depth.header_bytes / 16);
+    return (w.depth.header_bytes % 16 || ((uintptr_t)job.p & 15u)) ? fail_arg("bin_depth_header: not 16-byte aligned") : GSPL_OK;
+}
+int bin_tile_header(int N, int64_t capacity, int n_tiles, void* workspace, ZeroJob& job) {
+    BinWorkspace w;
+    int rc = plan_bin(N, capacity, n_tiles, w);
+    if (rc != GSPL_OK) return rc;
+    job.p = (uint4*)((char*)workspace + w.sort2_off);
+    job.n16 = (uint32_t)(w.tile.header_bytes / 16);
+    return (w.tile.header_bytes % 16 || ((uintptr_t)job.p & 15u)) ? fail_arg("bin_tile_header: not 16-byte aligned") : GSPL_OK;
 }
 }  // namespace gspl
 
@@ -603,7 +624,15 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
                              const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
                              int tile_size, int tile_w, int tile_h, int64_t capacity,
                              void* workspace, size_t workspace_bytes, void* stream) {
-    using namespace gspl;
+    return gspl::bin_emit_impl(N, mode, means2d, radii, conics, opacities, order, cum_tiles, big_list, spans, tile_size, tile_w, tile_h, capacity,
+                               workspace, workspace_bytes, stream, false);
+}
+
+namespace gspl {
+int bin_emit_impl(int N, int mode, const float* means2d, const int32_t* radii, const float* conics, const float* opacities,
+                  const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
+                  int tile_size, int tile_w, int tile_h, int64_t capacity, void* workspace, size_t workspace_bytes, void* stream,
+                  bool tile_header_zeroed) {
     if (N < 0 || capacity < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return fail_arg("bin_emit: bad sizes");
     if (mode != GSPL_MODE_GSPLAT && mode != GSPL_MODE_INRIA) return fail_arg("bin_emit: bad mode");
     if (N == 0 || capacity == 0) return GSPL_OK;
@@ -621,14 +650,17 @@ extern "C" int gspl_bin_emit(int N, int mode, const float* means2d, const int32_
     // list is not longer, else the emission is repeated; gspl_bin_sort keeps the spans)
     RadixProducer hdr;
     radix_producer_args(w.tile, ws + w.sort2_off, hdr);
-    rc = radix_zero(ws + w.sort2_off, w.tile.header_bytes, s);
-    if (rc != GSPL_OK) return rc;
+    if (!tile_header_zeroed) {
+        rc = radix_zero(ws + w.sort2_off, w.tile.header_bytes, s);
+        if (rc != GSPL_OK) return rc;
+    }
     if (mode == GSPL_MODE_GSPLAT)
         hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_GSPLAT>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity, hdr);
     else
         hipLaunchKernelGGL(bin_emit_lb_kernel<GSPL_MODE_INRIA>, dim3(grid), dim3(256), 0, s, N, means2d, radii, (const uint32_t*)order, conics, opacities, cum_tiles, (const SpanRecord*)spans, big_list, tile_size, tile_w, tile_h, tkeys, capacity, hdr);
     return check_launch("bin_emit");
 }
+}  // namespace gspl
 
 // Sort half: the first n_isects (<= capacity) records of the workspace gspl_bin_emit filled -> flatten_ids, offsets.
 // Two (for more than 65536 tiles: three) passes on the tile id; the last one writes the splat ids alone and counts

@@ -284,8 +284,14 @@ extern "C" int gspl_rasterize_inria_fwd(
         // binning on the caller's stream; the host meanwhile waits for the one number that sizes the tile sort
         if (!viewmatrix || !projmatrix) return fail_arg("rasterize_inria_fwd: NULL required pointer");
         if (!cov3D_precomp && (!scales || !rotations)) return fail_arg("rasterize_inria_fwd: need scales+rotations or cov3D_precomp");
+        // the geometry kernel clears the depth sort's tables, the scan kernel the tile sort's (when its workspace exists by then):
+        // two launches fewer in front of the kernels that fill those tables
+        ZeroJob zero_depth, zero_tile;
+        rc = bin_depth_header(N, tile_w * tile_h, ws1, zero_depth);
+        if (rc == GSPL_OK && ws2) rc = bin_tile_header(N, capacity, tile_w * tile_h, ws2, zero_tile);
+        if (rc != GSPL_OK) return rc;
         rc = inria_geometry_launch(N, means3D, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, width, height, tile, tanfovx, tanfovy, scale_modifier,
-                                   radii, st->means2d, st->depths, st->conics, st->cov3d, raw_opacities, st->opacities, s);
+                                   radii, st->means2d, st->depths, st->conics, st->cov3d, raw_opacities, st->opacities, s, zero_depth);
         if (rc != GSPL_OK) return rc;
         FrameEvents& fe = frame_events();
         if (!fe.ok) return check_hip(hipGetLastError(), "rasterize_inria_fwd: event");
@@ -304,13 +310,13 @@ extern "C" int gspl_rasterize_inria_fwd(
         {
             const unsigned long long ticket = next_ticket();
             rc = bin_count_ticket(N, GSPL_MODE_INRIA, st->means2d, radii, st->depths, st->conics, opacities, tile, tile_w, tile_h, order, cum, big_list,
-                                  spans, host, ws1, ws1_bytes, s, ticket);      // the scan kernel stores the two numbers, then the ticket, into `host`
+                                  spans, host, ws1, ws1_bytes, s, ticket, true, zero_tile);      // the scan kernel stores the two numbers, then the ticket, into `host`
             if (rc != GSPL_OK) return rc;
             auto wait_count = [&]() -> bool { return wait_for_ticket(host, ticket, s); };
             // speculative emission with the caller's guess of the list length, while the host waits for the real one
             if (ws2) {
-                rc = gspl_bin_emit(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
-                                   capacity, ws2, ws2_bytes, s);
+                rc = bin_emit_impl(N, GSPL_MODE_INRIA, st->means2d, radii, st->conics, opacities, order, cum, big_list, spans, tile, tile_w, tile_h,
+                                   capacity, ws2, ws2_bytes, s, true);
                 if (rc != GSPL_OK) { (void)wait_count(); return rc; }
             }
             if (ws2) {

@@ -388,6 +388,12 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// ZeroJob of gspl_host.h, run by every thread of the calling kernel (grid-stride; the tables are a few hundred KB)
+__device__ __forceinline__ void zero_table(uint4* __restrict__ p, uint32_t n16) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // a c - b^2 without the cancellation of its two products (Kahan): w = fl(b b), e = w - b b exactly, f = fl(a c - w); det = f + e
 __device__ __forceinline__ float conic_det(float a, float b, float c) {
     const float w = b * b;

@@ -49,16 +49,29 @@ int sh_bwd_launch(int N, int C, int degree, int n_coeffs, const float* dirs, con
                   const float* v_colors, int vc_stride, float* v_dc, float* v_rest, float* v_dirs, void* stream,
                   const float* jac /* nullable: the forward's Jacobian; v_dirs then needs no coefficient read */,
                   const ShAdamHost* adam /* nullable; not NULL: v_dc / v_rest are the PARAMETERS, updated in place, no gradient is written */);
-// binning.hip -> fused.hip: gspl_bin_count whose scan stores `ticket` into host_counts[2] after the two numbers
+// A table that one kernel clears on behalf of a LATER kernel of the same stream (the tables of a prepared sort): the ~5 us
+// radix_zero launch in front of that kernel goes away (profiles/r09_sequence.txt has the two of a frame).  16-byte units.
+struct ZeroJob { uint4* p = nullptr; uint32_t n16 = 0; };
+// binning.hip -> fused.hip: gspl_bin_count whose scan stores `ticket` into host_counts[2] after the two numbers.
+// depth_header_zeroed: the caller's earlier kernel ran bin_depth_header()'s job.  `then_zero`: the last scan kernel runs this job
+// (bin_tile_header(): the tables of the emission that follows).
 int bin_count_ticket(int N, int mode, const float* means2d, const int32_t* radii, const float* depths, const float* conics, const float* opacities,
                      int tile_size, int tile_w, int tile_h, int32_t* order, int64_t* cum_tiles, int32_t* big_list, void* spans, int64_t* host_counts,
-                     void* workspace, size_t workspace_bytes, void* stream, unsigned long long ticket);
+                     void* workspace, size_t workspace_bytes, void* stream, unsigned long long ticket,
+                     bool depth_header_zeroed = false, ZeroJob then_zero = ZeroJob());
+int bin_depth_header(int N, int n_tiles, void* count_workspace, ZeroJob& job);                       // what bin_count would clear first
+int bin_tile_header(int N, int64_t capacity, int n_tiles, void* workspace, ZeroJob& job);            // what gspl_bin_emit would clear first
+int bin_emit_impl(int N, int mode, const float* means2d, const int32_t* radii, const float* conics, const float* opacities,
+                  const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
+                  int tile_size, int tile_w, int tile_h, int64_t capacity, void* workspace, size_t workspace_bytes, void* stream,
+                  bool tile_header_zeroed);
 // inria.hip -> fused.hip: the geometry phase and the preprocess backward with the model's RAW parameters (GSPL_INRIA_RAW_PARAMS)
 int inria_geometry_launch(int N, const float* means, const float* scales, const float* quats, const float* cov3d_precomp,
                           const float* viewmatrix, const float* projmatrix, int width, int height, int tile_size,
                           float tanfovx, float tanfovy, float scale_modifier,
                           int32_t* radii, float* means2d, float* depths, float* conics, float* cov3d,
-                          const float* raw_opacities /* nullable: activated parameters */, float* opacities_out, hipStream_t s);
+                          const float* raw_opacities /* nullable: activated parameters */, float* opacities_out, hipStream_t s,
+                          ZeroJob zero = ZeroJob() /* cleared by the same kernel, for the binning that follows */);
 int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs, const float* means, const float* scales, const float* quats,
                               const float* cov3d, const float* shs, const float* shs_rest,
                               const float* viewmatrix, const float* projmatrix, const float* campos,

@@ -12,6 +12,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include "gspl_host.h"
 
 namespace gspl {
 
@@ -81,10 +82,13 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* worksp
 // the positions i of the tagged items in order to tagged_list[0..) and their number to cum[n] (cum then has n + 1 entries).
 // host_words (nullable): device-accessible HOST memory (pinned) for two int64 — the kernel itself stores the total and the tagged
 // count there, so a host that waits for an event after the scan reads them without a copy launch.
+// Up to SCAN_RAW_SUMS_BLOCKS block sums (2M items) the middle launch is folded into the last one: two launches.
+// then_zero: a table the last kernel also clears (ZeroJob of gspl_host.h), for the kernel that follows on the stream.
 static constexpr int SCAN_TILE = 2048;
+static constexpr unsigned SCAN_RAW_SUMS_BLOCKS = 1024;
 size_t scan_workspace_bytes(size_t n);
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* workspace, int32_t* tagged_list, void* stream,
                          int64_t* host_words = nullptr /* pinned: [0] total, [1] tagged count, and with a ticket [2] = ticket, stored last */,
-                         unsigned long long ticket = 0);
+                         unsigned long long ticket = 0, ZeroJob then_zero = ZeroJob());
 
 }  // namespace gspl

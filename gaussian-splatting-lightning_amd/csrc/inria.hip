@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void inria_preprocess_fwd_kernel(
     int width, int height, int tile_size, float tanfovx, float tanfovy, float scale_modifier,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
     float* __restrict__ conics, float* __restrict__ cov3d,
-    const float* __restrict__ raw_opacities, float* __restrict__ opacities_out) {
+    const float* __restrict__ raw_opacities, float* __restrict__ opacities_out, uint4* __restrict__ zero_p, uint32_t zero_n16) {
+    zero_table(zero_p, zero_n16);      // tables of the depth sort that follows (ZeroJob; nothing to do with this kernel's rows)
     // rows of this block in LDS: inputs means[3] | scales[3] quats[4] (or cov3d_precomp[6]); then, over the same memory, the outputs
     // cov3d[6] | means2d[2] | conics[3]
     __shared__ __attribute__((aligned(16))) float s_buf[256 * 11];
@@ -377,17 +378,17 @@ int inria_geometry_launch(int N, const float* means, const float* scales, const 
                           const float* viewmatrix, const float* projmatrix, int width, int height, int tile_size,
                           float tanfovx, float tanfovy, float scale_modifier,
                           int32_t* radii, float* means2d, float* depths, float* conics, float* cov3d,
-                          const float* raw_opacities, float* opacities_out, hipStream_t s) {
+                          const float* raw_opacities, float* opacities_out, hipStream_t s, ZeroJob zero) {
     const int grid = (N + 255) / 256;
     if (raw_opacities) {
         if (cov3d_precomp || !opacities_out) return fail_arg("inria_preprocess_fwd: raw parameters need scales + rotations and room for the opacities");
         hipLaunchKernelGGL(inria_preprocess_fwd_kernel<true>, dim3(grid), dim3(256), 0, s,
                            N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
-                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d, raw_opacities, opacities_out);
+                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d, raw_opacities, opacities_out, zero.p, zero.n16);
     } else {
         hipLaunchKernelGGL(inria_preprocess_fwd_kernel<false>, dim3(grid), dim3(256), 0, s,
                            N, means, scales, quats, cov3d_precomp, viewmatrix, projmatrix, width, height, tile_size,
-                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d, (const float*)nullptr, (float*)nullptr);
+                           tanfovx, tanfovy, scale_modifier, radii, means2d, depths, conics, cov3d, (const float*)nullptr, (float*)nullptr, zero.p, zero.n16);
     }
     return check_launch("inria_preprocess_fwd");
 }

@@ -621,12 +621,26 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(unsigned long long* __r
     }
 }
 
+// RAW_SUMS: `bases` holds the block sums as scan_gather_sums_kernel left them, and every workgroup adds up the ones in front of
+// it itself (integer sums: the same numbers whichever way they are added) — for a few hundred workgroups that is cheaper than a
+// one-workgroup scan launch in between.
+template <bool RAW_SUMS>
 __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ counts,
                                                                  int64_t* __restrict__ cum, uint32_t n, const unsigned long long* __restrict__ bases,
                                                                  int32_t* __restrict__ tagged_list, int64_t* __restrict__ host_words,
-                                                                 unsigned long long ticket) {
+                                                                 unsigned long long ticket, uint4* __restrict__ zero_p, uint32_t zero_n16) {
     __shared__ unsigned long long s_wave[RS_WAVES];
+    __shared__ unsigned long long s_front[RS_WAVES];
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    zero_table(zero_p, zero_n16);          // ZeroJob: the tables of the sort whose keys the NEXT kernel of the stream produces
+    unsigned long long base;
+    if (RAW_SUMS) {
+        unsigned long long part = 0ull;
+        for (uint32_t j = (uint32_t)t; j < blockIdx.x; j += (uint32_t)RS_THREADS) part += bases[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+        if (l == 0) s_front[w] = part;
+    }
     const uint32_t first = blockIdx.x * (uint32_t)SCAN_TILE + (uint32_t)t * SC_IPT;       // SC_IPT consecutive items per thread
     unsigned long long v[SC_IPT], mine = 0ull;
 #pragma unroll
@@ -639,7 +653,14 @@ __global__ __launch_bounds__(RS_THREADS) void scan_gather_kernel(const uint32_t*
     unsigned long long wave_off = 0ull;
 #pragma unroll
     for (int k = 0; k < RS_WAVES; ++k) if (k < w) wave_off += s_wave[k];
-    unsigned long long run = bases[blockIdx.x] + wave_off + (incl - mine);
+    if (RAW_SUMS) {
+        base = 0ull;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) base += s_front[k];      // written before the __syncthreads above
+    } else {
+        base = bases[blockIdx.x];
+    }
+    unsigned long long run = base + wave_off + (incl - mine);
 #pragma unroll
     for (int k = 0; k < SC_IPT; ++k) {
         run += v[k];
@@ -668,14 +689,21 @@ size_t scan_workspace_bytes(size_t n) {
 }
 
 int scan_gathered_counts(const uint32_t* order, const int32_t* counts, int64_t* cum, size_t n, void* workspace, int32_t* tagged_list, void* stream,
-                         int64_t* host_words, unsigned long long ticket) {
-    if (n == 0) return GSPL_OK;
+                         int64_t* host_words, unsigned long long ticket, ZeroJob then_zero) {
+    if (n == 0) return then_zero.n16 ? radix_zero(then_zero.p, (size_t)then_zero.n16 * 16, stream) : GSPL_OK;
     const unsigned blocks = (unsigned)((n + SCAN_TILE - 1) / SCAN_TILE);
     unsigned long long* sums = (unsigned long long*)workspace;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(scan_gather_sums_kernel, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, (uint32_t)n, sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, blocks);
-    hipLaunchKernelGGL(scan_gather_kernel, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, cum, (uint32_t)n, (const unsigned long long*)sums, tagged_list, host_words, ticket);
+    if (blocks <= SCAN_RAW_SUMS_BLOCKS) {
+        // two launches: every workgroup reads the (at most 1024) sums in front of it from L2
+        hipLaunchKernelGGL(scan_gather_kernel<true>, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, cum, (uint32_t)n, (const unsigned long long*)sums,
+                           tagged_list, host_words, ticket, then_zero.p, then_zero.n16);
+    } else {
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, blocks);
+        hipLaunchKernelGGL(scan_gather_kernel<false>, dim3(blocks), dim3(RS_THREADS), 0, s, order, counts, cum, (uint32_t)n, (const unsigned long long*)sums,
+                           tagged_list, host_words, ticket, then_zero.p, then_zero.n16);
+    }
     return check_launch("scan_gathered_counts");
 }
 

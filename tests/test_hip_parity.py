@@ -365,13 +365,14 @@ def test_binning_big_splats(hip, mode):
         assert np.all(np.diff(dn[seg]) >= 0)
 
 
-def test_binning_above_one_million_splats(hip):
+@pytest.mark.parametrize("n", [1_200_000, 2_500_000])
+def test_binning_above_one_million_splats(hip, n):
     """1.2 M splats (several sort workgroups per pass, multi-block scans) with a few screen-filling ones dealt out to the emit
     kernel's workgroups: the two-level lists must equal those of the independent 64-bit (tile | depth) sort behind `isect_tiles`
-    (itself checked against the oracle at small sizes)."""
+    (itself checked against the oracle at small sizes).  2.5 M: more than SCAN_RAW_SUMS_BLOCKS (1024) block sums, i.e. the
+    three-launch form of the count scan (gspl_sort.h); below that the middle launch is folded into the last one."""
     d = _dev()
     W, H = 640, 400
-    n = 1_200_000
     g = torch.Generator().manual_seed(8)
     xy = (torch.rand(n, 2, generator=g) * torch.tensor([W, H])).to(d)
     radii = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
