@@ -76,8 +76,8 @@ int tile_offsets_from_counts(uint32_t* counts, uint32_t n, void* stream);      /
 size_t exclusive_scan_u32_workspace_bytes(size_t n);
 int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* workspace, void* stream);
 
-// Inclusive scan of counts[order[i]] (int32 -> int64; order may be nullptr = identity) in three launches (block sums, scan of
-// the sums, per-block scan).  workspace: scan_workspace_bytes(n), 8-byte aligned, no initialisation needed.
+// Inclusive scan of counts[order[i]] (int32 -> int64; order may be nullptr = identity): block sums, then the per-block scan whose
+// workgroups add up the sums in front of them (two launches), or with a one-workgroup scan of the sums in between (three).  workspace: scan_workspace_bytes(n), 8-byte aligned, no initialisation needed.
 // Counts with bit 31 set are TAGGED: the bit is not part of the count, and with `tagged_list` (nullable) the scan also writes
 // the positions i of the tagged items in order to tagged_list[0..) and their number to cum[n] (cum then has n + 1 entries).
 // host_words (nullable): device-accessible HOST memory (pinned) for two int64 — the kernel itself stores the total and the tagged

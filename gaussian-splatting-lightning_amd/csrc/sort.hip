@@ -572,7 +572,7 @@ int exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* worksp
 }
 
 // ---- scan of the tile counts in depth order -----------------------------------------------------------------------------------
-// Inclusive scan of counts[order[i]] (int32 -> int64), three launches: block sums, one-workgroup scan of the sums, per-block scan.
+// Inclusive scan of counts[order[i]] (int32 -> int64): block sums, [one-workgroup scan of the sums,] per-block scan (gspl_sort.h).
 // Bit 31 of a count tags the item: the tagged items are ranked along the way (their number rides in bits 40.. of the scanned
 // value; the counts themselves add up to < 2^31).
 static constexpr int SC_IPT = SCAN_TILE / RS_THREADS;
