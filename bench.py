@@ -684,9 +684,11 @@ def main():
         # Host hygiene: a full (generation-2) pass of Python's cyclic GC walks every object torch has imported — 30-40 ms during
         # which no kernel is launched, once every ~130 steps.  Freezing what exists once the first warm-up steps have created their
         # lazily-built objects keeps later collections to the objects of the steps themselves.  The collection sits INSIDE the
-        # warm-up (before its last steps), not between warm-up and timed region: tens of milliseconds of idle device right before the
-        # timed steps is what a training loop never has.
-        import gc
+        # warm-up (before its last steps), not between warm-up and timed region, and it is the SECOND one of the process (the first,
+        # before the per-camera pass, froze the imported world): with the driver's five warm-up steps a 35 ms walk three steps ahead
+        # of the timed region cost it 1.8 % (profiles/r11a_warmup_length.txt: 1.287 ms per step with 5 warm-up steps, 1.263 with 50,
+        # the per-step percentiles of the pass that follows identical) — tens of milliseconds of idle device right before the timed
+        # steps is what a training loop never has.
         early = min(warmup, 2) if os.environ.get("GSPL_BENCH_GC_LATE") is None else warmup
         for _ in range(int(os.environ.get("GSPL_BENCH_PREHEAT", "0"))):      # diagnostic: extra untimed steps ahead of the warm-up
             full_step(force_reduce=True)
@@ -743,6 +745,13 @@ def main():
     # camera's list sizes and the device is at its clocks — the state of a training run past its first epoch, which is what
     # `value` is about.  (Measured with the driver's `--steps 20 --warmup 5`: 1.306-1.313 ms per step straight after start-up — three
     # hipMallocs inside the timed region — against 1.26-1.29 ms after 21 or more warm-up steps; profiles/r04e.)
+    # Host hygiene, part 1 (see timed_region): the one expensive walk of Python's cyclic GC over everything torch has imported
+    # (30-40 ms) happens HERE, a whole pass over the camera set away from the timed steps; the collection inside the warm-up then
+    # only sees the objects the first steps created (well under a millisecond) and leaves the device no time to drop its clocks.
+    import gc
+    if os.environ.get("GSPL_BENCH_GC_EARLY", "1") != "0":      # "0": diagnostic, the one walk inside the warm-up as before
+        gc.collect()
+        gc.freeze()
     ops.KEEP_LAST_RASTER = True
     per_cam_before = []
     if mode != "sharded" and not args.no_workload_stats:
