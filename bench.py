@@ -225,6 +225,7 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
         state["camera"] = i
         return i
     if api == "vanilla":
+        from gspl_amd.density import request_stats_in_backward
         rasts = [ops.GaussianRasterizer(ops.GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
             viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=sh_degree,
@@ -240,6 +241,10 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
             screen = torch.empty_like(m).requires_grad_(True)      # gradient carrier, as HipVanillaRenderer creates it (values unused)
             render, radii = rast(means3D=m, means2D=screen, opacities=o, shs=dc, shs_rest=rest, scales=s, rotations=q)
             loss = loss_fn(render)
+            # HipDensityStatsMixin.before_backward: the statistics' buffers go to the frame's backward (density.py), which applies the
+            # update of densification_stats() below itself; `state["stats_buffers"]` is set by the steps that keep statistics
+            bufs = state.get("stats_buffers")
+            state["stats_request"] = request_stats_in_backward(radii, *bufs) if bufs is not None else None
             if marks is not None:
                 marks.append(_mark())
             loss.backward()
@@ -288,7 +293,11 @@ def densification_stats(state, accum, denom, max_radii):
     """What VanillaDensityControllerImpl.update_states accumulates
     (internal/density_controllers/vanilla_density_controller.py:101-123), on the fused kernel the package ships for it
     (gspl_amd.density.HipDensityStatsMixin): masked max of the radii, masked sum of the scaled gradient norms, masked count."""
-    from gspl_amd.density import update_densification_stats
+    from gspl_amd.density import update_densification_stats, withdraw_stats_request
+    req = state.pop("stats_request", None)
+    withdraw_stats_request(req)
+    if req is not None and req.applied:       # HipDensityStatsMixin.update_states: this frame's backward has applied them
+        return
     update_densification_stats(state["vs_grad"], None, state["radii"], accum, denom, max_radii, scale=state["grad_scale"])
 
 
@@ -631,6 +640,8 @@ def main():
     accum = torch.zeros(N, device=dev)
     denom = torch.zeros(N, device=dev)
     max_radii = torch.zeros(N, device=dev)                       # float, as the reference's buffer (vanilla_density_controller.py:61)
+    if mode != "sharded" and api == "vanilla":
+        step.state["stats_buffers"] = (accum, denom, max_radii)
 
     def make_full_step(optimizer, opt_kind):
         def full_step(force_reduce=False):

@@ -126,8 +126,14 @@ class DensityController:
         self.denom = torch.zeros((n, 1), device=device)
 
     def before_backward(self, outputs, step):                                       # :69-76
+        self._stats_request = None
         if step < self.c["densify_until_iter"]:
             outputs["viewspace_points"].retain_grad()
+            if self.fused_stats and outputs.get("viewspace_points_grad_scale", None) is None \
+                    and getattr(outputs["visibility_filter"], "_gspl_radii_positive", False):
+                # HipDensityStatsMixin.before_backward: the frame's backward applies the statistics itself
+                from gspl_amd.density import request_stats_in_backward
+                self._stats_request = request_stats_in_backward(outputs["radii"], self.xyz_gradient_accum, self.denom, self.max_radii2D)
 
     @torch.no_grad()
     def after_backward(self, outputs, model, optimizers, step):                     # :78-99
@@ -147,8 +153,12 @@ class DensityController:
     def update_states(self, outputs):                                               # :101-123
         vp, vis, radii = outputs["viewspace_points"], outputs["visibility_filter"], outputs["radii"]
         scale = outputs.get("viewspace_points_grad_scale", None)
-        if self.fused_stats:                                                        # HipDensityStatsMixin: one launch
-            from gspl_amd.density import update_densification_stats
+        if self.fused_stats:                                                        # HipDensityStatsMixin: one launch, or none
+            from gspl_amd.density import update_densification_stats, withdraw_stats_request
+            req, self._stats_request = getattr(self, "_stats_request", None), None
+            withdraw_stats_request(req)
+            if req is not None and req.applied:
+                return
             update_densification_stats(vp.grad, vis, radii, self.xyz_gradient_accum, self.denom, self.max_radii2D, scale=scale)
             return
         self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis].float())

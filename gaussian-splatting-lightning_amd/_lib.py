@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -66,7 +66,8 @@ class InriaState(ctypes.Structure):
                 ("clamped", ctypes.c_void_p), ("cov3d", ctypes.c_void_p), ("sh_jac", ctypes.c_void_p),
                 ("alphas", ctypes.c_void_p), ("final_Ts", ctypes.c_void_p), ("last_ids", ctypes.c_void_p), ("offsets", ctypes.c_void_p),
                 ("flatten_ids", ctypes.c_void_p), ("opacities", ctypes.c_void_p), ("flags", ctypes.c_int),
-                ("seg_ckpt", ctypes.c_void_p), ("seg_words", ctypes.c_void_p), ("seg_slots", ctypes.c_uint32), ("seg_reserved", ctypes.c_uint32)]
+                ("seg_ckpt", ctypes.c_void_p), ("seg_words", ctypes.c_void_p), ("seg_slots", ctypes.c_uint32), ("seg_reserved", ctypes.c_uint32),
+                ("stats_accum", ctypes.c_void_p), ("stats_denom", ctypes.c_void_p), ("stats_max_radii", ctypes.c_void_p)]
 
 
 _P = c_void_p
@@ -146,6 +147,7 @@ _SIGNATURES = {
     "gspl_profile_read": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float)]),
     "gspl_rasterize_inria_geometry_bytes": (c_size_t, [c_int]),
     "gspl_rasterize_inria_image_bytes": (c_size_t, [c_int, c_int]),
+    "gspl_inria_state_bytes": (c_size_t, []),
     "gspl_inria_preprocess_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                           c_int, c_int, c_float, c_float, c_float,
                                           _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -194,6 +196,10 @@ def lib():
     got = handle.gspl_abi_version()
     if got != ABI_VERSION:
         raise HipLibraryError(f"ABI mismatch: library {got}, python binding {ABI_VERSION}; rebuild the extension")
+    handle.gspl_inria_state_bytes.restype = c_size_t
+    if handle.gspl_inria_state_bytes() != ctypes.sizeof(InriaState):
+        raise HipLibraryError(f"gspl_inria_state: the library's struct has {handle.gspl_inria_state_bytes()} bytes, the binding's "
+                              f"{ctypes.sizeof(InriaState)}; rebuild the extension")
     _LIB = handle
     return _LIB
 

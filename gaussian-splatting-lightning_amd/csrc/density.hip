@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int N, const float* 
     if (!vis) return;
     if (scale_dev) { sx = scale_dev[0]; sy = scale_dev[1]; }
     const float gx = grad[(size_t)g * grad_stride + 0] * sx, gy = grad[(size_t)g * grad_stride + 1] * sy;
-    accum[g] += sqrtf(gx * gx + gy * gy);
+    accum[g] += sqrtf(fmaf(gx, gx, gy * gy));      // spelled out: inria_preprocess_bwd_kernel applies the same update (BwdStats)
     denom[g] += 1.f;
     if (max_radii) max_radii[g] = fmaxf(max_radii[g], r);
 }

@@ -463,5 +463,5 @@ static int gspl::rasterize_inria_bwd_impl(
     return inria_preprocess_bwd_impl(N, degree, n_coeffs, means3D, scales, rotations, st->cov3d, shs, shs_rest, viewmatrix, projmatrix, campos, width, height,
                                      tanfovx, tanfovy, scale_modifier, radii, st->clamped, packed, packed + 2, packed + 6, 9, v_means3D, v_scales,
                                      v_rotations, v_cov3D, v_shs, v_shs_rest, v_colors_precomp, v_means2D_ndc, packed + 5, v_opacities, st->sh_jac,
-                                     raw ? st->opacities : nullptr, s, plan);
+                                     raw ? st->opacities : nullptr, s, plan, BwdStats{st->stats_accum, st->stats_denom, st->stats_max_radii});
 }

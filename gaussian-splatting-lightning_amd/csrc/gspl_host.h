@@ -65,6 +65,8 @@ int bin_emit_impl(int N, int mode, const float* means2d, const int32_t* radii, c
                   const int32_t* order, const int64_t* cum_tiles, const int32_t* big_list, const void* spans,
                   int tile_size, int tile_w, int tile_h, int64_t capacity, void* workspace, size_t workspace_bytes, void* stream,
                   bool tile_header_zeroed);
+// the density controller's statistics (gspl_densify_stats) applied by the preprocess backward itself; accum == NULL: not asked for
+struct BwdStats { float* accum = nullptr; float* denom = nullptr; float* max_radii = nullptr; };
 // inria.hip -> fused.hip: the geometry phase and the preprocess backward with the model's RAW parameters (GSPL_INRIA_RAW_PARAMS)
 int inria_geometry_launch(int N, const float* means, const float* scales, const float* quats, const float* cov3d_precomp,
                           const float* viewmatrix, const float* projmatrix, int width, int height, int tile_size,
@@ -83,5 +85,6 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs, const float* mean
                               float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac,
                               const float* opac_act /* nullable: activated parameters */, void* stream,
                               const gspl_bwd_adam_plan* adam = nullptr /* not NULL: v_shs / v_shs_rest / v_scales / v_quats / v_opacities are
-                              the PARAMETERS (as means, scales, quats are), updated in place; v_means is scratch [N,3] */);
+                              the PARAMETERS (as means, scales, quats are), updated in place; v_means is scratch [N,3] */,
+                              BwdStats stats = BwdStats());
 }  // namespace gspl

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
     const float* __restrict__ v_means2d, const float* __restrict__ v_conics, int gs2, int gs3,
     float* __restrict__ v_means, float* __restrict__ v_scales, float* __restrict__ v_quats,
     float* __restrict__ v_cov3d_precomp, float* __restrict__ v_means2d_ndc,
-    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst, const float* __restrict__ opac_act, PreAdam adam) {
+    const float* __restrict__ v_opac_src, float* __restrict__ v_opac_dst, const float* __restrict__ opac_act, PreAdam adam, BwdStats stats) {
     // ADAM: the block's 256 rows of gradients meet in LDS and the update runs as FLAT, coalesced 16-byte passes over the block's
     // slice of every array (pre_adam_pass) — a lane-per-row update reads and writes 33 strided dwords per Gaussian three times over
     // (95 us at 1 M, 527 us at 6 M: 3 TB/s); every thread of the block stays for the barrier, rows past N carry nothing.
@@ -284,6 +284,13 @@ __global__ __launch_bounds__(256) void inria_preprocess_bwd_kernel(
         // 2D mean (pixels) -> clip space
         ndc[0] = v_means2d[(int64_t)g * gs2 + 0] * 0.5f * (float)width;
         ndc[1] = v_means2d[(int64_t)g * gs2 + 1] * 0.5f * (float)height;
+        // the density controller's statistics of this row (gspl_densify_stats with radii > 0 as the mask, no scale, this gradient as
+        // `grad`: the same three lines, the same arithmetic — density.hip) when the caller handed its buffers to the backward
+        if (stats.accum) {
+            stats.accum[g] += sqrtf(fmaf(ndc[0], ndc[0], ndc[1] * ndc[1]));
+            stats.denom[g] += 1.f;
+            if (stats.max_radii) stats.max_radii[g] = fmaxf(stats.max_radii[g], (float)radii[g]);
+        }
         const float mw = 1.f / (G.hom[3] + 1e-7f);
         const float vh0 = ndc[0] * mw, vh1 = ndc[1] * mw;
         const float vh3 = -(ndc[0] * G.hom[0] + ndc[1] * G.hom[1]) * mw * mw;
@@ -446,8 +453,10 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs,
                                          float* v_means, float* v_scales, float* v_quats,
                                          float* v_cov3d_precomp, float* v_shs, float* v_shs_rest, float* v_colors_precomp,
                                          float* v_means2d_ndc, const float* v_opacities_packed, float* v_opacities, const float* sh_jac,
-                                         const float* opac_act, void* stream, const gspl_bwd_adam_plan* plan) {
+                                         const float* opac_act, void* stream, const gspl_bwd_adam_plan* plan, BwdStats stats) {
     if (N < 0 || width <= 0 || height <= 0) return fail_arg("inria_preprocess_bwd: bad sizes");
+    if ((stats.accum == nullptr) != (stats.denom == nullptr) || (stats.max_radii && !stats.accum))
+        return fail_arg("inria_preprocess_bwd: the statistics' accum and denom go together (max_radii is optional beside them)");
     if (plan) {
         // Adam inside the backward: v_shs / v_shs_rest / v_scales / v_quats / v_opacities ARE the parameters (means, scales, quats too)
         if (!v_shs || !v_scales || !v_quats || !v_opacities || v_cov3d_precomp || v_colors_precomp || grad_stride <= 0)
@@ -508,7 +517,7 @@ int inria_preprocess_bwd_impl(int N, int degree, int n_coeffs,
     }
 #define GSPL_LAUNCH_PRE_BWD(A, R, AD) hipLaunchKernelGGL((inria_preprocess_bwd_kernel<A, R, AD>), dim3(grid), dim3(256), 0, s, \
         N, means, scales, quats, cov3d, viewmatrix, projmatrix, width, height, tanfovx, tanfovy, scale_modifier, \
-        radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities, opac_act, pre)
+        radii, v_means2d, v_conics, gs2, gs3, v_means, v_scales, v_quats, v_cov3d_precomp, v_means2d_ndc, v_opacities_packed, v_opacities, opac_act, pre, stats)
     if (plan) { if (opac_act) GSPL_LAUNCH_PRE_BWD(true, true, true); else GSPL_LAUNCH_PRE_BWD(true, false, true); }
     else if (accum) { if (opac_act) GSPL_LAUNCH_PRE_BWD(true, true, false); else GSPL_LAUNCH_PRE_BWD(true, false, false); }
     else { if (opac_act) GSPL_LAUNCH_PRE_BWD(false, true, false); else GSPL_LAUNCH_PRE_BWD(false, false, false); }

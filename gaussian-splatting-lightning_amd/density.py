@@ -57,11 +57,79 @@ def update_densification_stats(grad: Tensor, visibility_filter: Optional[Tensor]
                L.ptr(xyz_gradient_accum), L.ptr(denom), L.ptr(max_radii2D), L.stream())
 
 
+class StatsRequest:
+    """A frame's statistics handed to that frame's backward: `applied` turns True once the fused Inria backward that owns `radii`
+    has run the update of `update_densification_stats(viewspace.grad, None, radii, ...)` inside its last kernel."""
+    __slots__ = ("radii_ptr", "n", "accum", "denom", "max_radii", "applied")
+
+    def __init__(self, radii, accum, denom, max_radii):
+        self.radii_ptr, self.n = radii.data_ptr(), radii.numel()
+        self.accum, self.denom, self.max_radii = accum, denom, max_radii
+        self.applied = False
+
+
+def request_stats_in_backward(radii: Tensor, xyz_gradient_accum: Tensor, denom: Tensor,
+                              max_radii2D: Optional[Tensor]) -> Optional[StatsRequest]:
+    """Ask the backward of the frame that returned `radii` (ops.GaussianRasterizer, the fused call) to apply this frame's
+    statistics itself: for every Gaussian with radii > 0, max_radii2D = max(max_radii2D, radii), xyz_gradient_accum += |the
+    screen-space gradient the backward hands to `means2D` (first two columns)|, denom += 1 — what
+    `update_densification_stats(means2D.grad, None, radii, ...)` does after the backward, with the same arithmetic, minus its launch
+    (the preprocess-backward kernel has the row's gradient in registers).  Call it between the render and `loss.backward()`;
+    afterwards `request.applied` says whether that backward ran and did it (it does so once) — if not, call
+    `update_densification_stats` as before.  None: not possible here (switched off, not the fused call's radii, unfit buffers).
+    One request is pending at a time; a newer one replaces it, `withdraw_stats_request` drops it."""
+    from .ops._state import STATE
+    if not (STATE.stats_in_backward and STATE.fused_inria):
+        return None
+    if not (isinstance(radii, Tensor) and radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous() and radii.dim() == 1):
+        return None
+    if not getattr(radii, "_gspl_fused_inria", False):       # set by the fused call on the radii it returns
+        return None
+    n = radii.numel()
+    for t in (xyz_gradient_accum, denom, max_radii2D):
+        if t is None:
+            continue
+        if not (t.is_cuda and t.device == radii.device and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            return None
+    if n == 0 or xyz_gradient_accum is None or denom is None:
+        return None
+    req = StatsRequest(radii, xyz_gradient_accum, denom, max_radii2D)
+    STATE.backward_stats = req
+    return req
+
+
+def withdraw_stats_request(req: Optional[StatsRequest]) -> None:
+    from .ops._state import STATE
+    if req is not None and STATE.backward_stats is req:
+        STATE.backward_stats = None
+
+
 class HipDensityStatsMixin:
     """`update_states` of the reference's density controllers on the fused kernel (same reads of `outputs`, same state
-    buffers: `max_radii2D`, `xyz_gradient_accum`, `denom`; `config.absgrad` selects `.absgrad`)."""
+    buffers: `max_radii2D`, `xyz_gradient_accum`, `denom`; `config.absgrad` selects `.absgrad`).  With the package's vanilla renderer
+    in front (its `visibility_filter` is `radii > 0`, no gradient scale, no absgrad) `before_backward` hands the buffers to the
+    frame's backward, which applies the update itself; `update_states` then has nothing left to launch."""
+
+    def before_backward(self, outputs, *args, **kwargs):
+        super().before_backward(outputs, *args, **kwargs)
+        withdraw_stats_request(getattr(self, "_stats_request", None))
+        self._stats_request = None
+        # global_step is the reference's fourth positional argument after `outputs` (density_controller.py:13)
+        global_step = kwargs.get("global_step", args[3] if len(args) > 3 else None)
+        if global_step is not None and global_step >= self.config.densify_until_iter:
+            return                                        # after_backward will not update the statistics either
+        if getattr(self.config, "absgrad", False) is True or outputs.get("viewspace_points_grad_scale", None) is not None:
+            return
+        radii, vis = outputs.get("radii"), outputs.get("visibility_filter")
+        if not getattr(vis, "_gspl_radii_positive", False):   # the package's vanilla renderer marks its `radii > 0`
+            return
+        self._stats_request = request_stats_in_backward(radii, self.xyz_gradient_accum, self.denom, self.max_radii2D)
 
     def update_states(self, outputs):
+        req, self._stats_request = getattr(self, "_stats_request", None), None
+        withdraw_stats_request(req)
+        if req is not None and req.applied and isinstance(outputs.get("radii"), Tensor) and outputs["radii"].data_ptr() == req.radii_ptr:
+            return                                        # this frame's backward has applied them
         vp = outputs["viewspace_points"]
         grad = vp.absgrad if getattr(self.config, "absgrad", False) is True else vp.grad
         update_densification_stats(grad, outputs["visibility_filter"], outputs["radii"], self.xyz_gradient_accum, self.denom,

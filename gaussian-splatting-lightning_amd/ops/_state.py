@@ -12,6 +12,7 @@ internal/viewer/client.py:114) never share a slot that belongs to another device
     STATE.last_raster                                       introspection: the last compositing forward's inputs (keep_last_raster)
     STATE.consts, .identity_slots, .zero_scalars            small per-device constant tensors
     STATE.backward_optimizers                               optimizers whose update the fused backward may apply itself (opt-in)
+    STATE.stats_in_backward, .backward_stats                the density controller's statistics applied by the fused backward (density.py)
 
 `gspl_amd.ops` keeps the historical module-level spellings (ops.FUSED_INRIA, ops._LAST_ISECTS, ...) as properties of the package
 that read and write this object.  Container operations used on the hot path (dict get / set, list pop / append) are atomic under
@@ -26,7 +27,7 @@ class RuntimeState:
     __slots__ = ("fused_inria", "device_side_list_length", "speculative_emit", "track_hit_pixels", "keep_last_raster", "side_low_priority",
                  "segmented_backward",
                  "last_isects", "speculation", "events", "pinned_words", "pinned_ends", "pending_updates", "last_raster", "consts",
-                 "identity_slots", "zero_scalars", "new_event", "backward_optimizers")
+                 "identity_slots", "zero_scalars", "new_event", "backward_optimizers", "stats_in_backward", "backward_stats")
 
     def __init__(self):
         env = os.environ.get
@@ -63,6 +64,12 @@ class RuntimeState:
         # optimizers constructed with fuse_into_backward=True (weak references): the fused Inria backward asks them for the moments of the
         # parameters it is differentiating and, if every one is claimed, applies the update itself (optimizers._FusedAdamBase)
         self.backward_optimizers: list = []
+        # the density controller's statistics of a frame (density.update_densification_stats) applied by that frame's fused Inria
+        # backward instead of by a launch of their own after it: `backward_stats` is the ONE pending request (density.StatsRequest:
+        # the frame's radii tensor + the three state buffers), taken by the backward that owns those radii.  GSPL_STATS_IN_BACKWARD=0:
+        # requests are refused and the controller's own launch runs, as before.
+        self.stats_in_backward: bool = env("GSPL_STATS_IN_BACKWARD", "1") != "0"
+        self.backward_stats = None
         self.new_event = _new_event      # (constructor of the events the free lists hand out; the host-only tests put a stand-in here)
 
 

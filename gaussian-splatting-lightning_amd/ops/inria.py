@@ -289,10 +289,23 @@ class _InriaFusedFn(torch.autograd.Function):
         H, W, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, use_cov, opac_shape = ctx.cfg
         N = means3D.shape[0]
         dev = means3D.device
+        if ctx.holder is None:
+            # the frame's device buffers (projected splats, tile lists, per-pixel state) were handed back after the first backward
+            raise RuntimeError("GaussianRasterizer: this frame's backward has run already and its buffers are released "
+                               "(a second backward through the same render — retain_graph — is not supported; render again)")
         v_out = _grad_or_zeros(v_out, (3, H, W), dev)
         E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         packed = E(N, 9)
         hit = torch.empty((N,), dtype=torch.uint8, device=dev) if S.track_hit_pixels else None
+        # the density controller's statistics of THIS frame (density.request_stats_in_backward: the request names the radii this
+        # forward returned): the preprocess-backward kernel applies them, once
+        stats = S.backward_stats
+        if stats is not None and N > 0 and stats.radii_ptr == radii.data_ptr() and stats.n == N and not stats.applied:
+            S.backward_stats = None
+            ctx.state.stats_accum, ctx.state.stats_denom = stats.accum.data_ptr(), stats.denom.data_ptr()
+            ctx.state.stats_max_radii = stats.max_radii.data_ptr() if stats.max_radii is not None else None
+        else:
+            stats = None
         # An optimizer built with fuse_into_backward=True that owns EVERY parameter differentiated here: the kernels that end the
         # backward apply its update themselves (gspl_rasterize_inria_bwd_adam) and no parameter gradient is written or returned
         if S.backward_optimizers and N > 0 and not use_cov and not has_precomp_colors:
@@ -307,6 +320,9 @@ class _InriaFusedFn(torch.autograd.Function):
                                L.ptr(sh_rest), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier,
                                L.ptr(radii), ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(scratch), L.ptr(v_ndc),
                                ctypes.byref(plan), L.stream())
+                    if stats is not None:
+                        stats.applied = True
+                        ctx.state.stats_accum = ctx.state.stats_denom = ctx.state.stats_max_radii = None
                     if hit is not None and ctx.means2D_ref is not None:
                         ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
                     ctx.holder = None
@@ -324,6 +340,9 @@ class _InriaFusedFn(torch.autograd.Function):
                        L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
                        ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_sh_rest),
                        L.ptr(v_cp), L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
+            if stats is not None:
+                stats.applied = True
+                ctx.state.stats_accum = ctx.state.stats_denom = ctx.state.stats_max_radii = None
             if hit is not None and ctx.means2D_ref is not None:
                 ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
         else:
@@ -331,6 +350,12 @@ class _InriaFusedFn(torch.autograd.Function):
                 t.zero_()
         ctx.holder = None
         return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest, None
+
+
+def _mark_fused(out):
+    """The radii of a fused call say so: its backward can take the frame's densification statistics along (density.py)."""
+    out[1]._gspl_fused_inria = True
+    return out
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -364,7 +389,8 @@ class GaussianRasterizer(torch.nn.Module):
             if cov3D_precomp is not None:
                 raise Exception("raw_parameters needs the scale/rotation pair")
             if S.fused_inria:
-                return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, None, self.raster_settings, shs_rest, True)
+                return _mark_fused(fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, None, self.raster_settings, shs_rest, True))
             # the stage-by-stage orchestration takes activated values: the same three activations through torch
             opacities, scales, rotations = torch.sigmoid(opacities), torch.exp(scales), torch.nn.functional.normalize(rotations)
-        return fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings, shs_rest)
+        out = fn.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, self.raster_settings, shs_rest)
+        return _mark_fused(out) if fn is _InriaFusedFn else out

@@ -93,10 +93,12 @@ class HipVanillaRenderer(Renderer):
             means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
             opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp, shs_rest=shs_rest,
             raw_parameters=raw is not None)
+        visibility_filter = radii > 0
+        visibility_filter._gspl_radii_positive = True      # density.HipDensityStatsMixin: the mask the fused backward applies itself
         return {
             rendered_image_key: rendered_image,
             "viewspace_points": screenspace_points,
-            "visibility_filter": radii > 0,
+            "visibility_filter": visibility_filter,
             "radii": radii,
         }
 
@@ -113,8 +115,10 @@ class HipVanillaRenderer(Renderer):
         rendered_image, radii = ops.GaussianRasterizer(raster_settings=settings)(
             means3D=means3D, means2D=screenspace_points, shs=features, colors_precomp=colors_precomp,
             opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        visibility_filter = radii > 0
+        visibility_filter._gspl_radii_positive = True
         return {"render": rendered_image, "depth": None, "viewspace_points": screenspace_points,
-                "visibility_filter": radii > 0, "radii": radii}
+                "visibility_filter": visibility_filter, "radii": radii}
 
     def get_available_outputs(self) -> Dict:
         return {"rgb": RendererOutputInfo("render"), "depth": RendererOutputInfo("depth", RendererOutputTypes.GRAY)}

@@ -400,6 +400,11 @@ typedef struct gspl_inria_state {
     /* segmented backward (ABI 33): per-pixel checkpoints the forward left every 256 list entries and the words
      * [count | - | work items seg_slots] in front of them (one GSPL_BUF_CHECKPOINTS block); seg_ckpt == NULL: this frame is not segmented */
     void* seg_ckpt; uint32_t* seg_words; uint32_t seg_slots; uint32_t seg_reserved;
+    /* densification statistics inside the backward (ABI 34; IN, read by gspl_rasterize_inria_bwd / _bwd_adam only — the forward clears
+     * them, the caller sets them between the two calls): not NULL = the preprocess-backward kernel applies section 11's update to the
+     * rows it has just produced the screen-space gradient of (visible = radii > 0, no scale, v_means2D_ndc as `grad`), with the same
+     * arithmetic as gspl_densify_stats — the density controller's launch after the backward goes away.  accum and denom go together. */
+    float* stats_accum; float* stats_denom; float* stats_max_radii;
 } gspl_inria_state;
 /* GSPL_INRIA_RAW_PARAMS: `scales`, `rotations`, `opacities` are the model's RAW parameters and the activations of the reference's
  *    model — scale_activation = exp, rotation_activation = F.normalize (x / max(|x|, 1e-12)), opacity_activation = sigmoid
@@ -411,6 +416,7 @@ enum { GSPL_INRIA_RAW_PARAMS = 1,
        GSPL_INRIA_FORCE_SEGMENTS = 4 /* always take checkpoints (default: only while walks longer than a segment are being met) */ };
 size_t gspl_rasterize_inria_geometry_bytes(int N);
 size_t gspl_rasterize_inria_image_bytes(int width, int height);
+size_t gspl_inria_state_bytes(void);      /* sizeof(gspl_inria_state) as the library was built: a binding checks its own layout against it */
 int gspl_rasterize_inria_fwd(int N, int degree, int n_coeffs,
                              const float* means3D, const float* scales /*nullable*/, const float* rotations /*nullable*/,
                              const float* cov3D_precomp /*nullable*/, const float* shs /*nullable*/,
