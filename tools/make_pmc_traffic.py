@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/<tag>_pmc_traffic.json from the PMC summaries of one collection (tools/collect_profiles_r03.sh):
+"""profiles/<tag>_pmc_traffic.json from the PMC summaries of one collection (tools/collect_profiles_r06.sh):
 
     python tools/make_pmc_traffic.py <dir with <tag>_pmc_FETCH_SIZE.csv, <tag>_pmc_WRITE_SIZE.csv[, <tag>_pmc_SQ.csv]> <tag> <workload/api> [out.json]
 
@@ -32,7 +32,7 @@ def main():
     from gspl_amd import _lib
     fetch, write, sq = (table(os.path.join(d, f"{tag}_pmc_{n}.csv")) for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ"))
     doc = {"_comment": "HBM traffic per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE / SQ runs of bench.py; "
-                       "tools/collect_profiles_r03.sh + tools/make_pmc_traffic.py): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 "
+                       "tools/collect_profiles_r06.sh + tools/make_pmc_traffic.py): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 "
                        "being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md; WRITE_SIZE uncalibrated (atomics are counted as writes); "
                        "means over the launches of the run (the steps cycle through the camera set).",
            "_measured_on": {"abi_version": _lib.ABI_VERSION, "kernel_source_sha16": bench.kernel_source_sha16(),
