@@ -3,9 +3,10 @@
 
   python tools/prof_summary.py stats  <kernel_stats.csv> <n_launches_per_kernel> [out.csv]
   python tools/prof_summary.py pmc    <counter_collection.csv> [out.csv]
-  python tools/prof_summary.py seq    <kernel_trace.csv> <anchor kernel substring> [out.txt]
-      time-ordered kernel sequence of the LAST step (between the last two launches of the anchor kernel):
-      start offset, duration, idle gap before the launch (us)
+  python tools/prof_summary.py seq    <kernel_trace.csv> <anchor kernel substring> [out.txt] [k]
+      time-ordered kernel sequence of one step (from the k-th launch of the anchor kernel to the next; default: the last full step —
+      in a bench.py run that is a step of the INSTRUMENTED pass, with its three event records; give k = warm-up + steps / 2 for a step
+      of the timed region): start offset, duration, idle gap before the launch (us)
 """
 import collections
 import csv
@@ -43,10 +44,10 @@ def stats(path, launches, out=None):
     print("\n".join(lines[:34] + lines[-1:]))
 
 
-def seq(path, anchor, out=None):
+def seq(path, anchor, out=None, k=None):
     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
-    a, b = idx[-2], idx[-1]
+    a, b = (idx[-2], idx[-1]) if k is None else (idx[k], idx[k + 1])
     t0 = int(rows[a]["Start_Timestamp"])
     lines, prev_end, busy = [], None, 0
     for r in rows[a:b]:
@@ -56,7 +57,8 @@ def seq(path, anchor, out=None):
         prev_end = en
         busy += en - st
     span = (int(rows[b]["Start_Timestamp"]) - t0) / 1e3
-    lines.append("step span %.1f us, kernels busy %.1f us, %d launches" % (span, busy / 1e3, b - a))
+    lines.append("step span %.1f us, kernels busy %.1f us, %d launches%s" % (span, busy / 1e3, b - a,
+                 "" if k is None else " (step %d of %d in the trace)" % (k, len(idx))))
     text = "start_us   dur_us  gap_us  kernel\n" + "\n".join(lines) + "\n"
     if out:
         open(out, "w").write(text)
@@ -81,7 +83,7 @@ def pmc(path, out=None):
 
 if __name__ == "__main__":
     if sys.argv[1] == "seq":
-        seq(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        seq(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, int(sys.argv[5]) if len(sys.argv) > 5 else None)
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else None)
     else:
