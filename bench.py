@@ -573,16 +573,25 @@ def main():
                 # one validation frame over each transport: the forward is deterministic, so the peer route must reproduce the
                 # collective route's image bit for bit on EVERY rank; a set-up failure or a mismatch anywhere keeps the collective
                 ok, why = 1, "validated: one frame over the peer transport equals the collective route's image bit for bit on every rank"
+                # the validation frame waits ~5 s for a peer's records, not a collective's patience (120 s by default): between GPUs whose
+                # writes never become visible to each other it must cost seconds before the collective route is kept (the class
+                # attribute is what every wait reads: the timed steps have the full budget again; GSPL_PEER_MAX_POLLS set = left alone)
+                full_budget = gdist.PeerExchange.MAX_POLLS
+                if "GSPL_PEER_MAX_POLLS" not in os.environ:
+                    gdist.PeerExchange.MAX_POLLS = min(full_budget, 5_000_000)
                 try:
                     ref_img = make_renderer("collective")(cams[rank % len(cams)], model, bg)["render"].detach()
                     candidate = make_renderer("peer")
                     img = candidate(cams[rank % len(cams)], model, bg)["render"].detach()
-                    if candidate._peer is None or not torch.equal(img, ref_img):
-                        ok, why = 0, "the peer route's validation frame differed from the collective route's (or the route was not taken)"
+                    torch.cuda.synchronize()             # a wait that gave up has raised its error word by now
                     if candidate._peer is not None:
                         candidate._peer.check()
-                except Exception as e:      # IPC mapping refused, shared memory unavailable, ...
+                    if candidate._peer is None or not torch.equal(img, ref_img):
+                        ok, why = 0, "the peer route's validation frame differed from the collective route's (or the route was not taken)"
+                except Exception as e:      # IPC mapping refused, shared memory unavailable, a peer's records never arrived, ...
                     ok, why = 0, f"peer transport set-up failed on rank {rank}: {e!r}"
+                finally:
+                    gdist.PeerExchange.MAX_POLLS = full_budget
                 flag = torch.tensor([ok], device=dev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 1:
