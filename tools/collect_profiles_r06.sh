@@ -21,7 +21,7 @@ one() {   # name, bench args...
   local name=$1; shift
   rm -rf /tmp/prof_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python /root/repo/bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-renderer-only --no-stage-rooflines --no-workload-stats --loop none "$@" > /tmp/log_$name.txt 2>&1
-  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); python /root/repo/tools/prof_summary.py stats $f 64 /root/repo/$O/${tag}_${name}kernel_stats.csv > /dev/null
+  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1); python /root/repo/tools/prof_summary.py stats $f 112 /root/repo/$O/${tag}_${name}kernel_stats.csv > /dev/null
   # step 41 of the run: inside the 48 timed steps (16 warm-up steps before them; the steps past 64 are the instrumented pass, three event
   # records each), and not one of the every-fourth steps whose graded launch the roofline brackets with an event pair (40, 44, ...)
   f=$(find /tmp/prof_$name -name "*kernel_trace.csv" | head -1); python /root/repo/tools/prof_summary.py seq $f composite_fwd /root/repo/$O/${tag}_${name}sequence.txt 41 > /dev/null
