@@ -60,9 +60,10 @@ def update_densification_stats(grad: Tensor, visibility_filter: Optional[Tensor]
 class StatsRequest:
     """A frame's statistics handed to that frame's backward: `applied` turns True once the fused Inria backward that owns `radii`
     has run the update of `update_densification_stats(viewspace.grad, None, radii, ...)` inside its last kernel."""
-    __slots__ = ("radii_ptr", "n", "accum", "denom", "max_radii", "applied")
+    __slots__ = ("radii", "radii_ptr", "n", "accum", "denom", "max_radii", "applied")
 
     def __init__(self, radii, accum, denom, max_radii):
+        self.radii = radii      # kept: while the request is pending no later frame's radii can be allocated at this address
         self.radii_ptr, self.n = radii.data_ptr(), radii.numel()
         self.accum, self.denom, self.max_radii = accum, denom, max_radii
         self.applied = False
