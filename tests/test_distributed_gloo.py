@@ -26,7 +26,8 @@ def _worker(rank, world, port, tmpdir):
     try:
         import gspl_amd  # noqa: F401
         from gspl_amd import distributed as D
-        counts = [[3, 5], [0, 4]]                      # counts[src][dst]; rank 1 sends nothing to rank 0's camera
+        # counts[src][dst]; rank 1 sends nothing to rank 0's camera.  World 8: ragged, with zeros off and on the diagonal
+        counts = [[3, 5], [0, 4]] if world == 2 else [[(3 * s_ + 5 * d_ + 1) % 7 for d_ in range(world)] for s_ in range(world)]
         mine = _records(rank, counts[rank], seed=5)
         leaves, packed = [], []
         for radii, p in mine:
@@ -77,20 +78,24 @@ def _worker(rank, world, port, tmpdir):
         # replicated mode: densification statistics agree on every rank afterwards
         accum = torch.tensor([1.0, 2.0, 3.0]) * (rank + 1)
         denom = torch.tensor([1.0, 0.0, 1.0])
-        maxr = torch.tensor([5.0, 1.0, 0.0]) if rank == 0 else torch.tensor([2.0, 7.0, 0.0])
+        maxr = torch.tensor([5.0, 1.0, 0.0]) if rank == 0 else torch.tensor([2.0, 7.0, 0.0]) if rank == 1 else torch.tensor([float(rank), 0.0, 0.0])
         D.reduce_densification_stats(accum, denom, maxr)
-        assert torch.equal(accum, torch.tensor([3.0, 6.0, 9.0])) and torch.equal(denom, torch.tensor([2.0, 0.0, 2.0]))
-        assert torch.equal(maxr, torch.tensor([5.0, 7.0, 0.0]))
+        tri = world * (world + 1) / 2.0
+        assert torch.equal(accum, torch.tensor([1.0, 2.0, 3.0]) * tri) and torch.equal(denom, torch.tensor([1.0, 0.0, 1.0]) * world)
+        assert torch.equal(maxr, torch.tensor([max(5.0, world - 1.0), 7.0, 0.0]))
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
 
 
-def test_world2_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_world2_gloo(tmp_path, world):
+    """World 2, and world 8 (BASELINE configs[3] / [4]; VERDICT r5 #1c): the same bookkeeping — split sizes of the packed all-to-all,
+    the reverse route of its gradients, shard bounds, row redistribution, SUM / SUM / MAX of the statistics — over eight ranks."""
     from conftest import free_port
     port = free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
 def _mailbox_worker(rank, world, port, tmpdir):
@@ -120,7 +125,7 @@ def _mailbox_worker(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_host_mailbox_rows_agree_under_drift(tmp_path, world):
     """distributed.HostMailbox (the per-step camera ids / Gaussian counts / votes of the peer transport, through shared host memory):
     every rank sees every rank's row of the SAME call, also when the ranks drift by a call."""

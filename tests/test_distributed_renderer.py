@@ -29,7 +29,9 @@ N_SPLATS, W_IMG, H_IMG = 3000, 208, 144
 def _cameras(world=2):
     from oracle import gsplat_oracle as O
     cams = []
-    poses = (((0.0, 0.0, 4.0), 190.0), ((0.35, -0.2, 3.4), 205.0), ((-0.3, 0.25, 4.6), 180.0), ((0.1, 0.3, 3.8), 198.0))
+    poses = (((0.0, 0.0, 4.0), 190.0), ((0.35, -0.2, 3.4), 205.0), ((-0.3, 0.25, 4.6), 180.0), ((0.1, 0.3, 3.8), 198.0),
+             ((-0.45, -0.3, 4.2), 186.0), ((0.5, 0.15, 5.0), 214.0), ((0.0, -0.4, 3.2), 176.0), ((-0.2, 0.1, 5.6), 222.0))
+    assert world <= len(poses)
     for i, (t, f) in enumerate(poses[:world]):
         cam = O.synthetic_camera(W_IMG, H_IMG, f, f + 3.0)
         w2c = cam["world_to_camera"].clone()
@@ -163,6 +165,9 @@ def _close(got, ref, rel, name, tiered=False):
 
 
 def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
+    if world > 2:          # the ranks share the host's cores (and the OpenMP oracle would start a team per process)
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 2) // world))
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
     parts = exchange.split("-")                           # "padded-staged": the stage-by-stage formulation of the step;
     exchange, form = parts[0], ("staged" if "staged" in parts else "")      # "padded-peer": direct peer writes instead of the collective
     transport = "peer" if "peer" in parts else "collective"
@@ -377,6 +382,25 @@ def test_world3_sharded_renderer_cpu_oracle_ops(tmp_path):
     """Three ranks: uneven shards (3000 = 1000 + 1000 + 1000 here, but the random redistribution leaves uneven ones), three
     cameras per projection batch, three-way all-to-all."""
     _run(tmp_path, False, world=3, exchange="padded")
+
+
+@pytest.mark.parametrize("exchange", ["auto", "padded"])
+def test_world8_sharded_renderer_cpu_oracle_ops(tmp_path, exchange):
+    """World size 8 — the size of BASELINE configs[3] / [4] and of `configs/distributed.yaml` on an 8-GPU node
+    (gsplat_distributed_renderer.py:141-202,252-311,435-510): eight gloo ranks, 375-row shards, eight cameras per projection batch, an
+    eight-way all-to-all in both directions, a redistribution with Adam rows over eight destinations.  Same bar as W = 2: every
+    rank's image and every gradient row of its shard equal the one-process result on the full model."""
+    _run(tmp_path, False, world=8, exchange=exchange)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["auto", "padded-peer", "counted-peer"])
+def test_world8_sharded_renderer_shared_gpu(tmp_path, exchange):
+    """Eight processes on cuda:0: the 8 x 8 flag matrix of csrc/peer.hip, eight IPC-mapped receive buffers per
+    process, the 8-row mailboxes and count matrix, the 8-camera batched projection / SH launch — at the size they exist for.  Same
+    bar as the two-process test: the peer transports' image bit-equal to the collective route's, gradients home to their owners
+    (against the fp64 oracle and the one-process HIP renderer), one forced redistribution with Adam rows."""
+    _run(tmp_path, True, world=8, exchange=exchange)
 
 
 @pytest.mark.gpu

@@ -135,14 +135,16 @@ def test_a_set_up_failure_on_one_rank_is_raised_on_every_rank(tmp_path, fail_at)
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
 
 
-def _lost_peer_worker(rank, world, port, tmpdir):
+def _lost_peer_worker(rank, world, port, tmpdir, dying=1):
     import os
     import sys
     import time
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ["GSPL_PEER_MAX_POLLS"] = "300000"          # a fraction of a second instead of the collective-scale default
+    # a fraction of a second instead of the collective-scale default (eight processes time-share one GPU's queues: a few seconds)
+    polls = 300000 if world <= 2 else 3000000
+    os.environ["GSPL_PEER_MAX_POLLS"] = str(polls)
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (here, os.path.dirname(here)):
         if p not in sys.path:
@@ -152,48 +154,54 @@ def _lost_peer_worker(rank, world, port, tmpdir):
     from gspl_amd import distributed as D
     dev = torch.device("cuda:0")
     px = D.PeerExchange(rank, None, dev)
-    assert px.MAX_POLLS == 300000
-    rows = torch.full((200, D.RECORD_FLOATS), float(rank + 1), device=dev)
-    fwd, _ = px.route([100, 100])              # step 1: both ranks take part
+    assert px.MAX_POLLS == polls
+    rows = torch.full((100 * world, D.RECORD_FLOATS), float(rank + 1), device=dev)
+    fwd, _ = px.route([100] * world)           # step 1: every rank takes part
     got = fwd(rows)
     torch.cuda.synchronize()
-    assert torch.equal(got[:100], torch.full_like(got[:100], 1.0)) and torch.equal(got[100:], torch.full_like(got[100:], 2.0))
+    for s_ in range(world):
+        assert torch.equal(got[100 * s_:100 * (s_ + 1)], torch.full_like(got[:100], float(s_ + 1)))
     dist.barrier()
-    if rank == 1:                              # ... then rank 1 is gone (no signal, no clean-up, no collective)
-        open(os.path.join(tmpdir, "ok1"), "w").write("gone")
+    if rank == dying:                          # ... then one rank is gone (no signal, no clean-up, no collective)
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("gone")
         os._exit(0)
-    fwd, _ = px.route([100, 100])              # step 2 on the survivor: its wait for rank 1's rows can only give up
+    fwd, _ = px.route([100] * world)           # step 2 on the survivors: their wait for the lost rank's rows can only give up
     t0 = time.monotonic()
     got = fwd(rows)
     torch.cuda.synchronize()                   # the stream DRAINS: the wait kernel is bounded, the GPU is not left spinning
     waited = time.monotonic() - t0
-    assert waited < 30.0, waited
+    assert waited < 60.0, waited
+    for s_ in range(world):                    # the rows of the ranks that ARE there arrived (the other receive area of the double buffer)
+        if s_ != dying:
+            assert torch.equal(got[100 * s_:100 * (s_ + 1)], torch.full_like(got[:100], float(s_ + 1)))
     try:                                       # ... and the very next use raises, naming the rank that never signalled
-        px.route([100, 100])
+        px.route([100] * world)
         outcome = "no error"
     except RuntimeError as e:
         outcome = str(e)
-    assert "gave up waiting for the records of rank 1" in outcome, outcome
+    assert f"gave up waiting for the records of rank {dying}" in outcome, outcome
     assert int(px._err_host[0]) == 0           # cleared by the raise: the object can be torn down (or used with a new peer set)
-    open(os.path.join(tmpdir, "ok0"), "w").write(f"{waited:.3f}")
+    open(os.path.join(tmpdir, f"ok{rank}"), "w").write(f"{waited:.3f}")
     os._exit(0)                                # (no barrier with a dead peer: leave without the collective tear-down)
 
 
 @pytest.mark.gpu
-def test_a_rank_that_dies_mid_run_makes_the_survivor_raise_within_the_poll_budget(tmp_path):
+@pytest.mark.parametrize("world,dying", [(2, 1), (8, 5)])
+def test_a_rank_that_dies_mid_run_makes_the_survivor_raise_within_the_poll_budget(tmp_path, world, dying):
     """ADVICE r4 / VERDICT r4 #7: the peer transport's device-side wait is bounded (GSPL_PEER_MAX_POLLS) and its error word lives in
     pinned host memory that `route()` reads before every step — a peer that is lost mid-run turns into a RuntimeError on the next step
     of the survivor (a collective would block for the process group's timeout), never into a hang or a silent run over stale rows.
-    Two processes on one GPU."""
+    Two processes on one GPU; and eight with rank 5 dying (VERDICT r5 #1d): seven survivors each give up on exactly that rank."""
     import torch.multiprocessing as mp
     from conftest import free_port
-    ctx = mp.spawn(_lost_peer_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=False)
+    ctx = mp.spawn(_lost_peer_worker, args=(world, free_port(), str(tmp_path), dying), nprocs=world, join=False)
     import time
-    deadline = time.monotonic() + 120
-    while time.monotonic() < deadline and not all((tmp_path / f"ok{r}").exists() for r in range(2)):
+    deadline = time.monotonic() + 240
+    while time.monotonic() < deadline and not all((tmp_path / f"ok{r}").exists() for r in range(world)):
         time.sleep(0.2)
     for p in ctx.processes:
         p.join(timeout=10)
         if p.is_alive():
             p.kill()
-    assert (tmp_path / "ok1").exists() and (tmp_path / "ok0").exists(), "the surviving rank never finished (hung in the wait?)"
+    missing = [r for r in range(world) if not (tmp_path / f"ok{r}").exists()]
+    assert not missing, f"ranks {missing} never finished (hung in the wait?)"
