@@ -59,6 +59,21 @@ static const double T_STOP = (double)1e-4f;
 static const double MARGIN = 2e-5;   /* relative margin that flags a decision as fragile */
 
 static int near_rel(double v, double thr) { return fabs(v - thr) <= MARGIN * fabs(thr); }
+/* A FREE-RUNNING comparison (an fp32 pipeline against this oracle on its own fp64 per-splat values, not on the pipeline's) also has to
+ * allow for the rounding of the compositing's INPUTS: the projected mean carries a few ulps of its own magnitude (up to the image
+ * width: 1e-4 pixels at x ~ 1900), the conic and the opacity a few ulps each.  With input_eps = k 2^-24 set, a decision is fragile
+ * within MARGIN + the first-order effect of such an error on the quantity decided:
+ *     d(alpha)/alpha = d(sigma) + d(o)/o,   d(sigma) <= eps (|a dx + b dy| |x| + |b dx + c dy| |y| + |a dx^2|/2 + |c dy^2|/2 + |b dx dy|),
+ *     d(T)/T = sum over the blended splats of d(alpha) / (1 - alpha).
+ * 0 (default): the locked comparisons, where the oracle composites AT the pipeline's values. */
+static double INPUT_EPS = 0.0;
+void oracle_set_input_eps(double e) { INPUT_EPS = e > 0.0 ? e : 0.0; }
+static int near_rel_m(double v, double thr, double extra) { return fabs(v - thr) <= (MARGIN + extra) * fabs(thr); }
+static double alpha_rel_err(double a, double b, double cc, double dx, double dy, double mx, double my) {
+    if (INPUT_EPS == 0.0) return 0.0;
+    return INPUT_EPS * (fabs(a * dx + b * dy) * fabs(mx) + fabs(b * dx + cc * dy) * fabs(my)
+                        + 0.5 * fabs(a * dx * dx) + 0.5 * fabs(cc * dy * dy) + fabs(b * dx * dy) + 1.0);
+}
 
 /* out_colors is HWC [H,W,D]; fragile [H,W] u8 (nullable). */
 void oracle_composite_fwd(int mode, int64_t n_isects, int D,
@@ -79,7 +94,7 @@ void oracle_composite_fwd(int mode, int64_t n_isects, int D,
                 const int px = tx * TILE + lx, py = ty * TILE + ly;
                 if (px >= width || py >= height) continue;
                 const double pxf = px + M.centre, pyf = py + M.centre;
-                double T = 1.0;
+                double T = 1.0, t_err = 0.0;
                 double acc[16];
                 for (int c = 0; c < D; ++c) acc[c] = 0.0;
                 int last = start;
@@ -91,11 +106,13 @@ void oracle_composite_fwd(int mode, int64_t n_isects, int D,
                     const double sigma = 0.5 * (a * dx * dx + cc * dy * dy) + b * dx * dy;
                     const double raw = (double)opacities[g] * exp(-sigma);
                     const double alpha = raw < M.alpha_max ? raw : M.alpha_max;
-                    if (near_rel(alpha, ALPHA_MIN) || fabs(sigma) < 1e-7) frag = 1;
+                    const double a_err = alpha_rel_err(a, b, cc, dx, dy, means2d[g * 2 + 0], means2d[g * 2 + 1]);
+                    if (near_rel_m(alpha, ALPHA_MIN, a_err) || fabs(sigma) < 1e-7) frag = 1;
                     if (sigma < 0.0 || alpha < ALPHA_MIN) continue;
-                    if (M.clamp_kills_grad && near_rel(raw, M.alpha_max)) frag = 1;
+                    if (M.clamp_kills_grad && near_rel_m(raw, M.alpha_max, a_err)) frag = 1;
                     const double next_T = T * (1.0 - alpha);
-                    if (near_rel(next_T, T_STOP)) frag = 1;
+                    t_err += a_err * alpha / (1.0 - alpha);
+                    if (near_rel_m(next_T, T_STOP, t_err)) frag = 1;
                     if (M.stop_inclusive ? (next_T <= T_STOP) : (next_T < T_STOP)) break;
                     const double w = alpha * T;
                     for (int c = 0; c < D; ++c) acc[c] += (double)colors[(int64_t)g * D + c] * w;
@@ -199,6 +216,100 @@ void oracle_composite_bwd(int mode, int N, int64_t n_isects, int D,
                     v_conics[g * 3 + 2] += 0.5 * v_sigma * dy * dy;
 #pragma omp atomic
                     v_opacities[g] += vis * v_alpha;
+                }
+            }
+        }
+    }
+}
+
+/*
+ * Attribution of the free-running tests' gradient tail: the splats whose gradient a flipped decision of a FRAGILE
+ * pixel can reach.  For every pixel flagged in fragile_px the whole list is walked front to back with the oracle's own (fp64)
+ * decisions, and every splat that is — or within MARGIN could be — blended there is marked: alpha >= ALPHA_MIN (1 - MARGIN) up to
+ * the transmittance stop; when the stop itself is the near-threshold decision (next_T within 1 % of T_STOP: one 1/255 flip in
+ * front of it moves T by at most 0.4 %) the walk continues on the path that does not stop there.  A splat's gradient is a sum
+ * over the pixels that blend it, and a flipped decision in a pixel moves the terms of every splat blended in that pixel (through
+ * T in front of it and the colour behind it): these are exactly the rows an fp32 implementation may legitimately miss by more
+ * than rounding.  fragile_g [N] u8, zeroed by the caller.
+ */
+void oracle_fragile_splats(int mode, int64_t n_isects,
+                           const double* means2d, const double* conics, const double* opacities,
+                           int width, int height, int tile_w, int tile_h,
+                           const int32_t* offsets, const int32_t* flatten_ids,
+                           const uint8_t* fragile_px, uint8_t* fragile_g) {
+    const mode_t_ M = mode_of(mode);
+    const int n_tiles = tile_w * tile_h;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int start = offsets[tile];
+        const int end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
+        const int tx = tile % tile_w, ty = tile / tile_w;
+        for (int ly = 0; ly < TILE; ++ly) {
+            for (int lx = 0; lx < TILE; ++lx) {
+                const int px = tx * TILE + lx, py = ty * TILE + ly;
+                if (px >= width || py >= height) continue;
+                if (!fragile_px[(int64_t)py * width + px]) continue;
+                const double pxf = px + M.centre, pyf = py + M.centre;
+                double T = 1.0;
+                for (int i = start; i < end; ++i) {
+                    const int g = flatten_ids[i];
+                    const double dx = means2d[g * 2 + 0] - pxf, dy = means2d[g * 2 + 1] - pyf;
+                    const double a = conics[g * 3 + 0], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
+                    const double sigma = 0.5 * (a * dx * dx + cc * dy * dy) + b * dx * dy;
+                    const double raw = opacities[g] * exp(-sigma);
+                    const double alpha = raw < M.alpha_max ? raw : M.alpha_max;
+                    const double a_err = alpha_rel_err(a, b, cc, dx, dy, means2d[g * 2 + 0], means2d[g * 2 + 1]);
+                    if (sigma < -1e-7 || alpha < ALPHA_MIN * (1.0 - MARGIN - a_err)) continue;
+#pragma omp atomic write
+                    fragile_g[g] = 1;
+                    if (alpha < ALPHA_MIN) continue;               /* the oracle skips it; an fp32 evaluation may blend it */
+                    const double next_T = T * (1.0 - alpha);
+                    const int stops = M.stop_inclusive ? (next_T <= T_STOP) : (next_T < T_STOP);
+                    if (stops && fabs(next_T - T_STOP) > 0.01 * T_STOP) break;
+                    T = next_T;
+                }
+            }
+        }
+    }
+}
+
+/*
+ * The one list-level decision a free-running comparison re-takes per PIXEL: the depth order of two splats that both blend there.
+ * The lists are sorted on the fp32 bits of the view-space depth (gaussian_projection.py:190-204); an fp32 pipeline and the fp64
+ * oracle round that depth differently in the last bits, so two splats whose depths agree to within `tol_rel` (a few fp32 ulps) may
+ * be composited in either order — which moves the pixel by up to alpha_i alpha_j |c_i - c_j| and the gradient terms of both.
+ * Flags (ORs into fragile_px) every pixel in which two blended splats are that close in depth.  depths [N] as the oracle's own.
+ */
+void oracle_fragile_order(int mode, int64_t n_isects,
+                          const double* means2d, const double* conics, const double* opacities, const double* depths,
+                          int width, int height, int tile_w, int tile_h,
+                          const int32_t* offsets, const int32_t* flatten_ids, double tol_rel, uint8_t* fragile_px) {
+    const mode_t_ M = mode_of(mode);
+    const int n_tiles = tile_w * tile_h;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int start = offsets[tile];
+        const int end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
+        const int tx = tile % tile_w, ty = tile / tile_w;
+        for (int ly = 0; ly < TILE; ++ly) {
+            for (int lx = 0; lx < TILE; ++lx) {
+                const int px = tx * TILE + lx, py = ty * TILE + ly;
+                if (px >= width || py >= height) continue;
+                const double pxf = px + M.centre, pyf = py + M.centre;
+                double T = 1.0, prev_depth = -1e300;
+                for (int i = start; i < end; ++i) {
+                    const int g = flatten_ids[i];
+                    const double dx = means2d[g * 2 + 0] - pxf, dy = means2d[g * 2 + 1] - pyf;
+                    const double a = conics[g * 3 + 0], b = conics[g * 3 + 1], cc = conics[g * 3 + 2];
+                    const double sigma = 0.5 * (a * dx * dx + cc * dy * dy) + b * dx * dy;
+                    const double raw = opacities[g] * exp(-sigma);
+                    const double alpha = raw < M.alpha_max ? raw : M.alpha_max;
+                    if (sigma < 0.0 || alpha < ALPHA_MIN) continue;
+                    if (fabs(depths[g] - prev_depth) <= tol_rel * fabs(depths[g])) { fragile_px[(int64_t)py * width + px] = 1; break; }
+                    prev_depth = depths[g];
+                    const double next_T = T * (1.0 - alpha);
+                    if (M.stop_inclusive ? (next_T <= T_STOP) : (next_T < T_STOP)) break;
+                    T = next_T;
                 }
             }
         }

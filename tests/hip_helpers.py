@@ -212,3 +212,127 @@ def assert_pixels_close(got, ref, tol=1e-5, frac_ok=0.999, tol_all=4e-3, name="r
         print(f"[tail] {name}: {int(bad.sum())} of {bad.size} values outside {tol:g} (max {d.max():.3e})")
     assert 1.0 - bad.mean() >= frac_ok, f"{name}: {bad.sum()} / {bad.size} outside {tol} (max {d.max():.3e})"
     assert d.max() <= tol_all, f"{name}: max |diff| {d.max():.3e} exceeds the tail bound {tol_all:g}"
+
+
+# ---------------------------------------------------------------------------------------------
+# attribution of the free-running tests' tail: not "at most so many elements may be off" but "an element that is
+# off belongs to a splat that a decision the fp32 pipeline may legitimately take the other way can reach"
+# ---------------------------------------------------------------------------------------------
+def fragile_rows(mode, r, W, H, bg, opacities=None, gpu_radii=None, tile=16, input_eps=4 * 2.0 ** -24, order_tol=4 * 2.0 ** -24):
+    """(rows [N] bool, fragile_px [H,W] bool) for an oracle render `r` (oracle.render_gsplat / render_inria: its per-splat values and
+    ITS lists).  A row is fragile when
+      * the splat is — or within the oracle's 2e-5 margin could be — blended in a pixel in which some discrete decision (1/255 skip,
+        transmittance stop, alpha clamp) sits within that margin of its threshold, or in which two blended splats are within a few
+        fp32 ulps of each other in depth (their order is the sort's decision on fp32 keys) — oracle.fragile_splats / fragile_order:
+        one flipped decision there moves the pixel by up to 1/255 and the gradient terms of EVERY splat blended in it; or
+      * the two sides disagree on the splat's integer extent (`gpu_radii` != the oracle's radii: ceil(3 sqrt(lambda)) within an ulp
+        of an integer, or the visibility test itself) — its tile lists differ.
+    Everything else has identical discrete decisions on both sides and must meet the plain tolerance."""
+    from oracle import gsplat_oracle as O
+    xy = r["xys"] if "xys" in r else r["xy"]
+    op = r["opacities"] if "opacities" in r else opacities
+    op = op.detach().reshape(-1) if hasattr(op, "detach") else np.asarray(op).reshape(-1)
+    _, _, _, frag = O.composite_fwd(mode, xy.detach(), r["conics"].detach(), r["rgbs"].detach(), op, bg, W, H, r["offsets"], r["flatten_ids"], tile=tile,
+                                    input_eps=input_eps)
+    # ... and the depth ORDER of two blended splats whose depths agree to a few fp32 ulps (the sort key is the fp32 depth)
+    frag = O.fragile_order(mode, xy.detach(), r["conics"].detach(), op, r["depths"].detach(), W, H, r["offsets"], r["flatten_ids"], fragile_px=frag, tile=tile,
+                           tol_rel=order_tol)
+    differ = None
+    if gpu_radii is not None:
+        ref_radii = np.asarray(r["radii"].detach().cpu().numpy() if hasattr(r["radii"], "detach") else r["radii"]).reshape(-1)
+        got_radii = np.asarray(gpu_radii.detach().cpu().numpy() if hasattr(gpu_radii, "detach") else gpu_radii).reshape(-1)
+        differ = ref_radii != got_radii
+        # a splat whose extent differs sits in other tiles' lists on the two sides: every pixel it can reach there (alpha at 3 sigma is
+        # up to 0.011 o: above 1/255 for an opaque splat) composites a different list — flagged, so that the splats blended with it
+        # count as reachable too
+        xyn = xy.detach().cpu().numpy()
+        for g in np.nonzero(differ)[0]:
+            rad = int(max(ref_radii[g], got_radii[g])) + 1
+            x0, x1 = int(max(np.floor(xyn[g, 0]) - rad, 0)), int(min(np.ceil(xyn[g, 0]) + rad + 1, W))
+            y0, y1 = int(max(np.floor(xyn[g, 1]) - rad, 0)), int(min(np.ceil(xyn[g, 1]) + rad + 1, H))
+            if x1 > x0 and y1 > y0:
+                frag[y0:y1, x0:x1] = 1
+    rows = O.fragile_splats(mode, xy.detach(), r["conics"].detach(), op, W, H, r["offsets"], r["flatten_ids"], frag, tile=tile, input_eps=input_eps)
+    if differ is not None:
+        rows = rows | differ
+    return rows, frag != 0
+
+
+def assert_close_attributed(got, ref, rel, name, rows, frac_ok=0.995, rel_all=0.5, slack=None, quiet=False, rel_firm=5e-3, frac_firm=2.5e-4):
+    """The free-running gradient check WITH attribution.  ratio = |got - ref| / (|ref| + rms(ref) [+ slack / rel]) per element;
+      1. EVERY element with ratio > `rel_firm` (5e-3: a hundredth of the cap on the fragile rows) lies in a row of `rows`
+         (hip_helpers.fragile_rows: a decision the fp32 pipeline may legitimately take the other way reaches that splat) — asserted;
+         and of the elements OUTSIDE those rows at most `frac_firm` (2.5e-4; at least one) lie between rel and rel_firm: with identical
+         decisions what is left is the SMOOTH effect of the few-ulp differences between the per-splat inputs the two sides composite
+         (a free-running oracle projects in fp64).  Measured (gpurun_out r20, profiles/r20_attribution.txt): scenes of 3-20 k splats —
+         none, worst unreachable element 9e-5; S-800-100k (3-pixel splats, the most sensitive) 22 of 120 k such elements, worst 5.3e-4;
+         1-6 M splats at 1080p 7-60 of 3-288 M, worst 8.5e-4; 5 M at SH degree 0 149 of 14 M, worst 3.0e-3.  The locked tests, which
+         composite AT the GPU's values, hold every such element to 1e-4;
+      2. the fragile rows themselves stay bounded: at least `frac_ok` of ALL elements within rel, every element within `rel_all`
+         (one flipped 1/255 decision on a splat that few pixels see is a sizeable share of a small gradient, not more);
+      3. printed, not asserted: how many elements rely on the attribution, and the quantiles of the PURE relative error
+         |got - ref| / |ref| over the elements with |ref| > 1e-3 rms (north_star says "1e-4 rel": read it off here)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    if ref.size == 0:
+        return
+    assert np.isfinite(got).all(), f"{name}: non-finite values"
+    rows = np.asarray(rows, bool).reshape(-1)
+    assert rows.shape[0] == ref.shape[0], (name, rows.shape, ref.shape)
+    rms = float(np.sqrt(np.mean(ref * ref))) + 1e-30
+    err = np.abs(got - ref)
+    ratio = err / (np.abs(ref) + rms + (0.0 if slack is None else np.asarray(slack, np.float64) / rel))
+    bad = ratio > rel
+    row_of = np.broadcast_to(rows.reshape((-1,) + (1,) * (ref.ndim - 1)), ref.shape)
+    unattributed = (ratio > rel_firm) & ~row_of
+    band = bad & ~row_of & ~unattributed
+    big = np.abs(ref) > 1e-3 * rms
+    pure = err[big] / np.abs(ref[big])
+    q = np.quantile(pure, [0.5, 0.99, 0.999]) if pure.size else [0, 0, 0]
+    if not quiet:
+        print(f"[attributed] {name}: {int(bad.sum())} of {bad.size} elements beyond {rel:g}: {int((bad & row_of).sum())} in the {int(rows.sum())} fragile rows of "
+              f"{rows.size}, {int(band.sum())} outside them up to {rel_firm:g}, {int(unattributed.sum())} outside them beyond it; worst ratio "
+              f"{float(ratio.max()):.2e} (non-fragile rows {float(ratio[~row_of].max()) if (~row_of).any() else 0.0:.2e}); "
+              f"pure |d|/|ref| p50 {q[0]:.1e} p99 {q[1]:.1e} p99.9 {q[2]:.1e}")
+    if unattributed.any():
+        i = int(np.argmax(np.where(unattributed, ratio, 0.0)))
+        row = np.unravel_index(i, ref.shape)[0]
+        raise AssertionError(f"{name}: {int(unattributed.sum())} element(s) beyond {rel_firm:g} in rows no fragile decision reaches; worst: row {row}, "
+                             f"got {got.flat[i]:.6e} ref {ref.flat[i]:.6e} ratio {ratio.flat[i]:.3e} (rms {rms:.3e})")
+    n_firm = int((~row_of).sum())
+    assert int(band.sum()) <= max(frac_firm * n_firm, 1.0), \
+        f"{name}: {int(band.sum())} of {n_firm} elements outside the fragile rows lie between {rel:g} and {rel_firm:g} (allowed {max(frac_firm * n_firm, 1.0):.1f})"
+    assert 1.0 - bad.mean() >= frac_ok, f"{name}: {int(bad.sum())} / {bad.size} outside rel={rel} (fragile rows included; worst {float(ratio.max()):.3e})"
+    assert float(ratio.max()) <= rel_all, f"{name}: worst element {float(ratio.max()):.3e} beyond the cap {rel_all:g} on a fragile row"
+
+
+def assert_pixels_attributed(got, ref, fragile_px, tol=1e-5, tol_all=4e-3, name="render"):
+    """EVERY pixel the oracle does not flag within `tol`; the flagged ones within one 8-bit step.  got / ref: [3,H,W] or [H,W,3] with
+    fragile_px [H,W]."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    d = np.abs(got - ref)
+    d = d.max(axis=0) if d.shape[0] == 3 and d.ndim == 3 and d.shape[1:] == fragile_px.shape else d.max(axis=-1)
+    firm = ~np.asarray(fragile_px, bool)
+    worst_firm, worst = float(d[firm].max()) if firm.any() else 0.0, float(d.max())
+    print(f"[attributed] {name}: {int((d > tol).sum())} of {d.size} pixels beyond {tol:g}; {int((~firm).sum())} flagged; worst unflagged {worst_firm:.2e}, worst {worst:.2e}")
+    assert worst_firm <= tol, f"{name}: an unflagged pixel differs by {worst_firm:.3e} (> {tol:g})"
+    assert worst <= tol_all, f"{name}: max |diff| {worst:.3e} exceeds the tail bound {tol_all:g}"
+
+
+def assert_pipeline_attributed(mode, r, W, H, bg, render, pairs, opacities=None, gpu_radii=None, pixel_tol=1e-5, rel=1e-4, slack=None, **kw):
+    """A whole pipeline against a FREE-RUNNING oracle render `r`: every pixel the oracle does not flag within `pixel_tol` (flagged ones
+    within one 8-bit step), and every gradient of `pairs` = [(name, got [N,...], ref [N,...]), ...] through `assert_close_attributed`
+    with the rows `fragile_rows` derives from r.  `slack`: {name: per-element allowance} (the conditioning of needles).
+    pixel_tol None: the pixel tiers of `assert_pixels_close` instead (scenes with needles: sigma of a 600-pixel splat is a difference of
+    terms of 1e5, and a few ulps on its conic move alpha by per cent WITHOUT any decision flipping — the locked tests own those)."""
+    rows, frag = fragile_rows(mode, r, W, H, bg, opacities=opacities, gpu_radii=gpu_radii)
+    print(f"[attributed] {int(frag.sum())} of {frag.size} pixels and {int(rows.sum())} of {rows.size} splats reachable by a fragile decision")
+    if render is not None:
+        ref_img = r["render"].detach().numpy() if hasattr(r["render"], "detach") else np.asarray(r["render"])
+        if pixel_tol is None:
+            assert_pixels_close(render, ref_img)
+        else:
+            assert_pixels_attributed(render, ref_img, frag, tol=pixel_tol)
+    for name, got, ref in pairs:
+        assert_close_attributed(got, ref, rel, name, rows, slack=None if slack is None else slack.get(name), **kw)
+    return rows, frag

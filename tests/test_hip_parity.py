@@ -41,7 +41,7 @@ def _cam_tensors(cam):
     return vm, K
 
 
-from hip_helpers import assert_pixels_close, assert_close_scaled, hip_composite_bwd, hip_composite_fwd, t32  # noqa: E402
+from hip_helpers import assert_pixels_close, assert_close_scaled, assert_pipeline_attributed, hip_composite_bwd, hip_composite_fwd, t32  # noqa: E402
 
 
 # ---------------------------------------------------------------------------------------------
@@ -655,11 +655,12 @@ def test_end_to_end_gsplat_api(hip):
     r = O.render_gsplat(*dl, 3, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W, H,
                         bg.double(), cam["camera_center"].double())
     (r["render"] * wimg.double()).sum().backward()
-    # a radius/ceil or fragile flip touches a few pixels: >= 99.9 % within 1e-5, ALL within 4e-3
-    assert_pixels_close(render.detach().cpu().numpy(), r["render"].detach().numpy())
+    # free-running, with ATTRIBUTION: every pixel the oracle does not flag within 1e-5 (a flagged one within one 8-bit
+    # step); every gradient element beyond the tolerance belongs to a splat that a flagged decision reaches (hip_helpers.fragile_rows)
     assert np.array_equal((radii > 0).cpu().numpy(), r["mask"].numpy())
-    for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
-        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=0.5)
+    assert_pipeline_attributed(O.MODE_GSPLAT, r, W, H, bg.double(), render.detach().cpu().numpy(),
+                               [(name, got.grad.cpu().numpy(), ref.grad.numpy()) for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs"))],
+                               gpu_radii=radii)
 
 
 def test_end_to_end_inria_api(hip):
@@ -679,13 +680,12 @@ def test_end_to_end_inria_api(hip):
     r = O.render_inria(*dl, 3, cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
                        cam["tanfovx"], cam["tanfovy"], W, H, bg.double())
     (r["render"] * wimg.double()).sum().backward()
-    assert_pixels_close(render.detach().cpu().numpy(), r["render"].detach().numpy())
     assert np.mean(radii.cpu().numpy() == r["radii"].numpy()) > 0.999
-    for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs")):
-        assert_close_scaled(got.grad.cpu().numpy(), ref.grad.numpy(), 1e-4, name, frac_ok=0.995, rel_all=0.5)
     # viewspace gradient in Inria units: pixel gradient * 0.5 * (W, H)
     ref_ndc = r["xy"].grad.numpy() * np.array([0.5 * W, 0.5 * H])
-    assert_close_scaled(screen.grad[:, :2].cpu().numpy(), ref_ndc, 1e-4, "viewspace_points.grad", frac_ok=0.995, rel_all=0.5)
+    assert_pipeline_attributed(O.MODE_INRIA, r, W, H, bg.double(), render.detach().cpu().numpy(),
+                               [(name, got.grad.cpu().numpy(), ref.grad.numpy()) for got, ref, name in zip(leaves, dl, ("means", "scales", "quats", "opacities", "shs"))]
+                               + [("viewspace_points.grad", screen.grad[:, :2].cpu().numpy(), ref_ndc)], opacities=dl[3], gpu_radii=radii)
     assert torch.all(screen.grad[:, 2] == 0)
 
 
