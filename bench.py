@@ -64,6 +64,10 @@ def parse():
     p.add_argument("--cameras", type=int, default=16,
                    help="size of the synthetic camera set the steps cycle through (one camera per rank per step, as the reference's data "
                         "loader hands them out, internal/dataset.py:146-184); 1 = the fixed camera of rounds 1-2")
+    p.add_argument("--cameras-set", default="heterogeneous", choices=["heterogeneous", "orbit"],
+                   help="heterogeneous (default since round 6): views at 0.55-1.75 x the workload's distance — list lengths spread 2.9 x around the orbit "
+                        "set's mean — served in a fresh random permutation every epoch, as the reference's loader serves a capture "
+                        "(internal/dataset.py:216-217); orbit: the near-identical views of rounds 3-5 (+-22 % in list length) in set order")
     p.add_argument("--no-stage-rooflines", action="store_true", help="skip the staged pass that times every stage for `stage_rooflines`")
     p.add_argument("--no-workload-stats", action="store_true",
                    help="skip the per-camera pass that counts I, I', V and the blended pairs after the timed regions (profiler runs: the last "
@@ -131,7 +135,7 @@ def _mark():
     return e
 
 
-def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prewarm=False, fuse_optimizer=False):
+def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prewarm=False, fuse_optimizer=False, view_stream=None, per_step=False):
     """`--loop reference-shaped` (images/s of the Lightning loop, not of a static-N step on activated leaves): the
     consumer side restated in bench_loop.py drives `HipVanillaRenderer` through what `GaussianSplatting.training_step` does
     (internal/gaussian_splatting.py:329-397) — raw parameters behind exp / normalize / sigmoid getters (fuse_activations: evaluated
@@ -176,12 +180,51 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
     targets, model, optimizers, controller = setup(wl["n"], 100, 100, 300)
     frames0, misses0, cold0 = (ops.SPECULATION[k] for k in ("frames", "misses", "cold"))
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-    res = BL.run(renderer, model, controller, optimizers, cams, targets, steps, bg, loss_fn, sh_degree_up_interval=150)
+    # per_step (the attribution run): host-side counters after every step — the caching allocator's hipMalloc count, the
+    # speculation's cold / missed frames, N and the SH degree — to say what the steps after a densification event or an SH-degree raise pay for
+    trace = []
+    def on_step(step, outputs):
+        trace.append((torch.cuda.memory_stats(dev).get("num_device_alloc", 0), ops.SPECULATION["misses"], ops.SPECULATION["cold"],
+                      model.n_gaussians, model.active_sh_degree))
+    res = BL.run(renderer, model, controller, optimizers, cams, targets, steps, bg, loss_fn, sh_degree_up_interval=150, view_stream=view_stream,
+                 on_step=on_step if per_step else None)
     event_steps = {e["step"] for e in controller.events}
     quiet = [ms for i, ms in enumerate(res["step_ms"], start=1) if i not in event_steps and (i - 1) not in event_steps and i > 5]
     loud = [ms for i, ms in enumerate(res["step_ms"], start=1) if i in event_steps]
     srt = sorted(quiet)
+    attribution = None
+    if per_step and trace:
+        # where the mean exceeds the quiet median: every step's excess over the quiet p50, binned by what preceded it
+        p50 = srt[len(srt) // 2] if srt else 0.0
+        sh_steps = {s_ for s_ in range(150, steps + 1, 150)}
+        rows, bins = [], {"event steps": 0.0, "1-10 steps after an event": 0.0, "1-10 steps after an SH-degree raise": 0.0, "steps 1-5 of the loop": 0.0, "every other step": 0.0}
+        prev = (mallocs0, misses0, cold0, None, None)
+        for i, ms in enumerate(res["step_ms"], start=1):
+            cur = trace[i - 1]
+            d_malloc, d_miss, d_cold = cur[0] - prev[0], cur[1] - prev[1], cur[2] - prev[2]
+            prev = cur
+            since_event = min((i - e for e in event_steps if e <= i), default=None)
+            since_sh = min((i - e for e in sh_steps if e < i), default=None)
+            excess = ms - p50
+            if i in event_steps:
+                key = "event steps"
+            elif since_event is not None and 1 <= since_event <= 10:
+                key = "1-10 steps after an event"
+            elif since_sh is not None and 1 <= since_sh <= 10:
+                key = "1-10 steps after an SH-degree raise"
+            elif i <= 5:
+                key = "steps 1-5 of the loop"
+            else:
+                key = "every other step"
+            bins[key] += excess
+            if key != "every other step" or d_malloc or d_miss or d_cold or excess > 0.25:
+                rows.append({"step": i, "ms": round(ms, 3), "excess_ms": round(excess, 3), "what": key, "device_mallocs": d_malloc, "misses": d_miss,
+                             "cold": d_cold, "n": cur[3], "sh_degree": cur[4]})
+        total_excess = sum(ms - p50 for ms in res["step_ms"])
+        attribution = {"quiet_p50_ms": round(p50, 4), "total_excess_ms": round(total_excess, 2), "excess_ms_by_cause": {k: round(v, 2) for k, v in bins.items()},
+                       "explained_share": round(1.0 - abs(bins["every other step"]) / max(total_excess, 1e-9), 3), "steps": rows}
     return {
+        "attribution": attribution,
         "what": "bench_loop.py: RawGaussians (exp / sigmoid / normalize getters) + restated VanillaDensityControllerImpl + FusedAdam x 2 "
                 "+ HipVanillaRenderer + fused 0.8 L1 + 0.2 (1 - SSIM), one camera of the set per step, targets = the unperturbed scene",
         "activations": ("inside the preprocess kernels (HipVanillaRenderer.fuse_activations, renderer.model_raw_parameters)" if fuse_activations
@@ -200,11 +243,12 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
     }
 
 
-def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
+def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1, stream=None):
+    """One training step (forward, loss, backward) on the next camera of `cams`: call k of rank r takes position k * world + r of the
+    job's view stream (`stream`: synthetic.ViewStream — a fresh permutation of the set per epoch; None: set order, cyclically).  With
+    state["marks"] = [] the step leaves three events per call (start, before backward, after backward) for the fwd_ms / bwd_ms of the
+    bench line."""
     sh_degree, absgrad = wl.get("sh_degree", 3), bool(wl.get("absgrad", False))
-    """One training step (forward, loss, backward) on the next camera of `cams` (call k of rank r takes camera (k * world + r) mod
-    len(cams)).  With state["marks"] = [] the step leaves three events per call (start, before backward, after backward) for the
-    fwd_ms / bwd_ms of the bench line."""
     import gspl_amd  # noqa: F401
     from gspl_amd import ops
     # the reference model's six parameters (shs_dc and shs_rest apart, vanilla_gaussian.py:266-300); five at SH degree 0
@@ -220,7 +264,8 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1):
         loss_fn = lambda img: (img - target).abs().mean()
 
     def next_camera():
-        i = (state["k"] * world + rank) % len(cams)
+        pos = state["k"] * world + rank
+        i = stream.view(pos) if stream is not None else pos % len(cams)
         state["k"] += 1
         state["camera"] = i
         return i
@@ -516,7 +561,10 @@ def main():
     # The camera set the steps cycle through: rank r takes camera (k * world + r) mod n at its step k (cameras sharded over the
     # ranks, one per rank per step).  Camera 0 is the pose the workload is defined on.
     n_cams = max(args.cameras, world)
-    cam_dicts = synthetic.camera_set(W, H, wl["fx"], count=n_cams, distance=wl.get("distance", 4.0))
+    cam_dicts = synthetic.camera_set(W, H, wl["fx"], count=n_cams, distance=wl.get("distance", 4.0), kind=args.cameras_set)
+    # the order the views are served in: a fresh random permutation per epoch (the reference's loader) for the heterogeneous set,
+    # set order for the orbit set (rounds 3-5); the same on every rank
+    view_stream = synthetic.ViewStream(n_cams, shuffled=(args.cameras_set == "heterogeneous"), seed=42)
     # eps 1e-15 as the reference (internal/models/vanilla_gaussian.py:266-300).  The bench tensors are ACTIVATED values
     # (post-exp scales, post-sigmoid opacities), so the reference's learning rates — meant for the raw parameters —
     # are scaled down by 1e3: the optimizer's cost is measured without letting the synthetic scene drift.
@@ -611,7 +659,7 @@ def main():
         def step():
             for t in tensors:
                 t.grad = None
-            mine = cams[(state.setdefault("k", 0) * world + rank) % len(cams)]
+            mine = cams[view_stream.view(state.setdefault("k", 0) * world + rank)]
             state["k"] += 1
             marks = state.get("marks")
             if marks is not None:
@@ -639,7 +687,7 @@ def main():
         # the reference model's parameters: the SH coefficients are two of them, shs_dc [N,1,3] and shs_rest [N,15,3]
         tensors = [t.contiguous().to(dev).requires_grad_(True) for t in (means, scales, quats, opac, shs[:, :1], shs[:, 1:]) if t.shape[1] > 0]
         N = wl["n"]
-        step = make_step(args.api, dev, wl, cam_dicts, tensors, args.loss, rank, world)
+        step = make_step(args.api, dev, wl, cam_dicts, tensors, args.loss, rank, world, stream=view_stream)
         lrs = (LRS[:4] + (LRS[4], LRS[4] / 20.0))[:len(tensors)]
 
         def stats(st, accum, denom, max_radii):
@@ -1010,27 +1058,37 @@ def main():
             "stage_rooflines": stage_rooflines,
             # device-side span of a step (start to start) over the timed region
             "step_ms": step_ms,
-            # list-length speculation of the binning (the guess is the previous frame's length x 1.25 + 64 K; a miss repeats emission,
-            # sort and compositing): frames of the timed region, frames without a guess, frames whose guess was too low
+            # list-length speculation of the binning (room = a decayed running maximum of the list entries per splat x N x 1.125 + 64 K,
+            # ops._state.ListCapacity; a miss repeats emission, sort and compositing): frames of the timed region, frames without any
+            # history, frames that needed more room than they were given
             "speculation": {**speculation, "miss_rate": round(speculation["misses"] / max(speculation["frames"], 1), 4)},
             "allocator": {"device_mallocs_in_timed_region": device_mallocs},
             "untimed_before_warmup": (None if args.no_workload_stats else
                                       "one forward + backward per camera of the set, no parameter update (the workload-statistics pass / first pass over the data set)"),
-            "cameras": {"count": len(cam_dicts), "per_camera": per_cam if len(per_cam) <= 64 else None},
+            "cameras": {"count": len(cam_dicts), "set": args.cameras_set,
+                        "order": ("a fresh random permutation per epoch (synthetic.epoch_order, seed 42; internal/dataset.py:216-217)"
+                                  if view_stream.shuffled else "set order, cyclically"),
+                        "list_length_max_over_min": (round(max(e["list_entries"] for e in per_cam) / max(min(e["list_entries"] for e in per_cam), 1), 3)
+                                                     if per_cam and "list_entries" in per_cam[0] else None),
+                        "per_camera": per_cam if len(per_cam) <= 64 else None},
         }
         if world == 1 and mode == "single" and args.loop == "reference-shaped" and api == "vanilla" and SH_DEGREE == 3:
             try:
-                line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, prewarm=True)
+                line["reference_shaped_loop"] = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, prewarm=True, view_stream=view_stream)
                 # the same loop with the activations left to torch (what the reference's renderer does with the same model)
                 if not args.no_loop_comparison:
-                    other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False)
+                    other = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_activations=False, view_stream=view_stream)
                     line["reference_shaped_loop"]["with_torch_activations"] = {
                         k: other[k] for k in ("activations", "images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end")}
                     # ... and with the optimizers' updates applied by the rasterizer's backward (opt-in; on a densification step the
                     # reference drops the step's gradients — the surgery replaces the Parameters before step() — here they were applied)
-                    fused = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_optimizer=True)
+                    fused = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, fuse_optimizer=True, view_stream=view_stream)
                     line["reference_shaped_loop"]["with_fused_bwd_adam"] = {
                         k: fused[k] for k in ("images_per_s_densifying", "ms_per_step_mean", "ms_per_step_between_events_p50", "n_end", "loss_first_last")}
+                    # ... and once more with host-side counters read after every step (hipMallocs, cold / missed speculation): where the
+                    # mean's excess over the quiet median goes; its own timing is not reported as a rate
+                    traced = reference_shaped_loop(dev, wl, cam_dicts, args.loop_steps, view_stream=view_stream, per_step=True)
+                    line["reference_shaped_loop"]["attribution"] = traced["attribution"]
             except Exception as e:  # an extra: it must never take the bench line down
                 line["reference_shaped_loop"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

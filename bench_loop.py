@@ -216,9 +216,10 @@ def perturbed(params, seed=7):
 
 
 def run(renderer, model: RawGaussians, controller: DensityController, optimizers, cameras: list, targets: list, steps: int, background,
-        loss_fn, sh_degree_up_interval: int = 1000, on_step=None) -> dict:
+        loss_fn, sh_degree_up_interval: int = 1000, on_step=None, view_stream=None) -> dict:
     """The training loop; every step leaves a device event, so the per-step spans come out without a host synchronisation inside
-    the loop.  Returns the history and the timing."""
+    the loop.  Returns the history and the timing.  `view_stream` (synthetic.ViewStream): the order the views are served in — a fresh
+    permutation per epoch, as the reference's loader (internal/dataset.py:216-217); None: set order, cyclically."""
     marks, n_hist, losses = [], [], []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -226,7 +227,7 @@ def run(renderer, model: RawGaussians, controller: DensityController, optimizers
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         marks.append(e)
-        k = (step - 1) % len(cameras)
+        k = view_stream.view(step - 1) if view_stream is not None else (step - 1) % len(cameras)
         outputs = renderer(cameras[k], model, background)
         loss = loss_fn(outputs["render"], targets[k])
         controller.before_backward(outputs, step)

@@ -24,8 +24,13 @@ static constexpr int RADIX_BINS = 256;                 // row width of the histo
 #ifndef GSPL_RS_TILE_U64
 #define GSPL_RS_TILE_U64 4096
 #endif
+// Workgroups of a pass per CU (capped by RADIX_MAX_WG and by the number of tiles).  Round 6: 3 -> 8 (= 2048 on 256 CUs).  The spans
+// (keys per workgroup) are fixed by the plan's item count, and the tile sort is planned for the list CAPACITY of a speculative
+// frame: with 768 spans over a capacity 2-3 x the real length only a third of the workgroups had keys (binning 0.269 -> 0.348 ms at
+// 3 x over-capacity); with 2048 the same frame costs 0.272 ms, a tight capacity 0.264 instead of 0.269, and the 6 M scene's depth
+// and tile sorts gain as well (binning 1.38 -> 1.21 ms); 4096 is no better (gpurun_out r21: profiles/r21_sort_workgroups.txt).
 #ifndef GSPL_RS_WG_PER_CU
-#define GSPL_RS_WG_PER_CU 3
+#define GSPL_RS_WG_PER_CU 8
 #endif
 static constexpr int RADIX_TILE_U32 = GSPL_RS_TILE_U32;   // items per tile of the (u32 key, u32 value) sort: 512 threads x 4
 static constexpr int RADIX_TILE_U64 = GSPL_RS_TILE_U64;   // items per tile of the u64 sorts: 512 threads x 8

@@ -5,7 +5,8 @@ internal/viewer/client.py:114) never share a slot that belongs to another device
 
     STATE.fused_inria, .device_side_list_length, .speculative_emit, .track_hit_pixels, .keep_last_raster, .side_low_priority,
           .segmented_backward
-    STATE.last_isects[(device index, tiles x, tiles y)]    list length of the last frame = the guess of the next speculative emission
+    STATE.last_isects[(device index, tiles x, tiles y)]    list length of the last frame (introspection)
+    STATE.capacity                                          ListCapacity: the room the next frame's speculative emission gets (per device, tile grid)
     STATE.speculation                                       how the guesses fared (frames / cold / misses; bench.py reports them)
     STATE.events[device index], .pinned_words, .pinned_ends[C]    free lists (an event / a pinned word costs ~15 us to construct)
     STATE.pending_updates[data_ptr]                         parameter updates in flight on the colour stream (optimizers.FusedAdam)
@@ -23,10 +24,45 @@ import os
 from typing import Optional
 
 
+class ListCapacity:
+    """Room (list entries) the next frame's SPECULATIVE emission is given, per (device index, tiles x, tiles y): the emission, the
+    tile sort and the compositing launch are enqueued before the host knows the frame's list length, on buffers and grids sized by
+    this number; a frame that needs more repeats them (a "miss": emission + sort + compositing again and a host wait, 0.35-0.45 ms).
+
+    Policy (round 6): a DECAYED RUNNING MAXIMUM of the list entries PER SPLAT, times the frame's splat count, times a
+    margin.  Rounds 3-5 used the previous frame's length x 1.25: right for a camera path that changes slowly, wrong for what the
+    reference's data loader serves — a fresh random permutation of the training views every epoch (internal/dataset.py:216-217,
+    258-259), neighbours in the stream whose lists differ by 2-3 x.  After one pass over the views the maximum covers all of them;
+    per splat, so that a densification step (N grows by tens of per cent at once, the lists with it) is covered as well; decayed
+    slowly (half-life ~3500 frames) so that a scene that shrinks for good — opacity reset, pruning — gives the room back.
+    What over-capacity costs: address space (24 B per entry of capacity from the caching allocator: tens of MB against 288 GB)
+    and workgroups of the capacity-sized sort grids that find nothing to do (measured: profiles/r20_capacity_*.txt)."""
+    MARGIN, PAD, DECAY = float(os.environ.get("GSPL_CAPACITY_MARGIN", "1.125")), 65536, 0.9998      # (the env knob: A/B runs of what room costs)
+
+    def __init__(self):
+        self.peak: dict = {}
+
+    def hint(self, key, n_splats: int) -> int:
+        r = self.peak.get(key)
+        return 0 if not r else int(r * max(int(n_splats), 1) * self.MARGIN) + self.PAD
+
+    def observe(self, key, n_splats: int, n_isects: int) -> None:
+        r = float(n_isects) / max(int(n_splats), 1)
+        old = self.peak.get(key)
+        self.peak[key] = r if old is None else max(r, old * self.DECAY)
+
+    def set(self, key, n_splats: int, n_isects: int) -> None:
+        """Tests: pretend the history so far consisted of one frame of `n_isects` entries for `n_splats` splats."""
+        self.peak[key] = float(n_isects) / max(int(n_splats), 1)
+
+    def clear(self) -> None:
+        self.peak.clear()
+
+
 class RuntimeState:
     __slots__ = ("fused_inria", "device_side_list_length", "speculative_emit", "track_hit_pixels", "keep_last_raster", "side_low_priority",
                  "segmented_backward",
-                 "last_isects", "speculation", "events", "pinned_words", "pinned_ends", "pending_updates", "last_raster", "consts",
+                 "last_isects", "capacity", "speculation", "events", "pinned_words", "pinned_ends", "pending_updates", "last_raster", "consts",
                  "identity_slots", "zero_scalars", "new_event", "backward_optimizers", "stats_in_backward", "backward_stats")
 
     def __init__(self):
@@ -52,6 +88,7 @@ class RuntimeState:
         _seg = env("GSPL_SEGMENTED_BWD", "1")
         self.segmented_backward = False if _seg == "0" else ("always" if _seg == "always" else True)
         self.last_isects: dict = {}
+        self.capacity = ListCapacity()
         self.speculation: dict = {"frames": 0, "cold": 0, "misses": 0}
         self.events: dict = {}
         self.pinned_words: list = []

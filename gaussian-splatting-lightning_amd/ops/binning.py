@@ -137,9 +137,9 @@ def bin_gaussians_begin(xys: Tensor, depths: Tensor, radii: Tensor, img_height: 
         # Speculative emission: the emit kernel's grid depends on N only, so it is launched NOW with room for a guess of
         # the list length (the last frame's, plus a margin) and runs while the host waits for the real number; a guess
         # that turns out too low costs one repeated emission in `bin_gaussians_end`.
-        guess = S.last_isects.get((dev.index, p.tile_w, p.tile_h), 0)
+        guess = S.capacity.hint((dev.index, p.tile_w, p.tile_h), N)      # decayed running maximum per splat x N x margin (ops._state.ListCapacity)
         if S.speculative_emit and guess > 0:
-            p.capacity = min(int(guess * 1.25) + 65536, MAX_ISECTS)
+            p.capacity = min(guess, MAX_ISECTS)
             p.ws2_bytes = lib.gspl_bin_workspace_bytes(N, p.capacity)
             if p.ws2_bytes == 0:
                 raise RuntimeError("gspl_bin_workspace_bytes failed: " + lib.gspl_last_error().decode())
@@ -205,6 +205,7 @@ def _bin_count_arrived(p: _PendingBins) -> int:
         raise RuntimeError(f"{n_isects} (tile, Gaussian) intersections in one frame: the per-tile lists of this library hold at most "
                            f"2^30-1 = {MAX_ISECTS} entries (fewer / smaller Gaussians, a larger tile size or a lower resolution)")
     S.last_isects[(p.dev.index, p.tile_w, p.tile_h)] = n_isects
+    S.capacity.observe((p.dev.index, p.tile_w, p.tile_h), p.N, n_isects)
     S.speculation["frames"] += 1
     if p.capacity == 0:
         S.speculation["cold"] += 1

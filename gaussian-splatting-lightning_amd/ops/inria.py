@@ -210,8 +210,7 @@ class _InriaFusedFn(torch.autograd.Function):
         radii = torch.empty((N,), dtype=torch.int32, device=dev)
         tile_w, tile_h = (W + 15) // 16, (H + 15) // 16
         key = (dev.index, tile_w, tile_h)
-        guess = S.last_isects.get(key, 0)
-        hint = min(int(guess * 1.25) + 65536, MAX_ISECTS) if (S.speculative_emit and guess > 0) else 0
+        hint = min(S.capacity.hint(key, N), MAX_ISECTS) if S.speculative_emit else 0      # (0: no history for this device and tile grid yet)
         state = L.InriaState()
         state.flags = (L.GSPL_INRIA_RAW_PARAMS if raw_params else 0) | ((L.GSPL_INRIA_FORCE_SEGMENTS if S.segmented_backward == "always" else 0)
                        if (S.segmented_backward and any(ctx.needs_input_grad)) else L.GSPL_INRIA_NO_SEGMENTS)      # (only a frame that can have a backward)
@@ -250,6 +249,7 @@ class _InriaFusedFn(torch.autograd.Function):
             for t in holder.get(L.GSPL_BUF_GEOMETRY, []):
                 t.record_stream(side.stream)
         S.last_isects[key] = int(state.n_isects)
+        S.capacity.observe(key, N, int(state.n_isects))
         S.speculation["frames"] += 1
         if hint == 0:
             S.speculation["cold"] += 1

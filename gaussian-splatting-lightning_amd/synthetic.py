@@ -166,19 +166,57 @@ def camera_looking_at_origin(width: int, height: int, fx: float, yaw: float, pit
             "cx": width / 2.0, "cy": height / 2.0, "width": width, "height": height, "tanfovx": tanx, "tanfovy": tany}
 
 
-def camera_set(width: int, height: int, fx: float, count: int = 16, distance: float = 4.0):
-    """`count` training views of a synthetic scene, as a data loader would hand them out one per step (internal/dataset.py:146-184):
-    view 0 is `camera()` (the pose the workload's intersection count is quoted on), the others orbit the cloud within +-0.45 rad of
-    yaw, +-0.25 rad of pitch and +-12 % of the distance — different visible sets and tile-list lengths (about -20 % ... +30 %)."""
+def camera_set(width: int, height: int, fx: float, count: int = 16, distance: float = 4.0, kind: str = "heterogeneous"):
+    """`count` training views of a synthetic scene, as a data loader would hand them out one per step (internal/dataset.py:146-184).
+    View 0 is always `camera()` (the pose the workload's intersection count is quoted on).
+
+    kind "heterogeneous" (default since round 6): views of very DIFFERENT footprint, as a capture has them — the others
+        look at the cloud from within +-0.45 rad of yaw and +-0.25 rad of pitch at distances between 0.55 x and 1.75 x `distance`
+        (2.2 ... 7 for the default 4), close-ups and far views alternating along the set.  At S-1080p-1M the rect intersections run
+        from 6.7 M to 19.8 M (2.9 x), their mean 14.06 M — equal to the orbit set's (14.06 M) by construction of the exponent below,
+        so that step times of the two sets compare at equal mean work.  Served in a fresh random permutation every epoch
+        (`epoch_order`), as the reference's loader does (internal/dataset.py:216-217,258-259).
+    kind "orbit" (rounds 3-5): +-12 % of the distance, list lengths within 22 % of each other, meant to be served in set order."""
     import math
+    if kind not in ("heterogeneous", "orbit"):
+        raise ValueError(f"camera_set kind must be heterogeneous | orbit, got {kind!r}")
     cams = [camera(width, height, fx, distance=distance)]
     for k in range(1, count):
         a = 2.0 * math.pi * k / count
         yaw = 0.45 * math.sin(a) + 0.08 * math.sin(3 * a)
         pitch = 0.25 * math.sin(2 * a + 0.7)
-        dist = distance * (1.0 + 0.12 * math.cos(5 * a + 0.3))
+        if kind == "orbit":
+            dist = distance * (1.0 + 0.12 * math.cos(5 * a + 0.3))
+        else:
+            u = ((k * 7) % (count - 1)) / max(count - 2, 1) if count > 2 else 0.5      # a permutation of 0 .. 1: neighbours far apart
+            dist = distance * (0.55 + 1.2 * u ** 1.6)
         cams.append(camera_looking_at_origin(width, height, fx, yaw, pitch, dist))
     return cams
+
+
+def epoch_order(n_views: int, epoch: int, seed: int = 42):
+    """The order in which epoch `epoch` serves the `n_views` training views: a fresh `torch.randperm` per epoch from one seeded
+    generator per loader, as `CacheDataLoader.__iter__` draws it (internal/dataset.py:216-217,258-259) — here a function of
+    (seed, epoch), so that every rank of a job computes the same order without talking."""
+    g = torch.Generator().manual_seed(int(seed) * 1_000_003 + int(epoch))
+    return torch.randperm(int(n_views), generator=g).tolist()
+
+
+class ViewStream:
+    """Position k of the job's view stream -> index into the camera set.  `shuffled`: epoch e = positions [e n, (e + 1) n) in
+    `epoch_order(n, e)`; otherwise set order, cyclically (rounds 3-5).  Rank r of W takes positions k W + r."""
+
+    def __init__(self, n_views: int, shuffled: bool = True, seed: int = 42):
+        self.n, self.shuffled, self.seed = int(n_views), bool(shuffled), int(seed)
+        self._epoch, self._order = -1, None
+
+    def view(self, position: int) -> int:
+        e, i = divmod(int(position), self.n)
+        if not self.shuffled:
+            return i
+        if e != self._epoch:
+            self._epoch, self._order = e, epoch_order(self.n, e, self.seed)
+        return self._order[i]
 
 
 class CameraObject:

@@ -66,6 +66,7 @@ def recorded_abi(monkeypatch):
     monkeypatch.setattr(ops.STATE, "new_event", _Event)
     monkeypatch.setattr(ops, "_EVENTS", {})
     monkeypatch.setattr(ops, "_LAST_ISECTS", {})
+    monkeypatch.setattr(ops.STATE, "capacity", type(ops.STATE.capacity)())
     monkeypatch.setattr(ops, "_PINNED_ENDS", {})
     monkeypatch.setattr(ops, "_PINNED_WORDS", [])
     return calls
