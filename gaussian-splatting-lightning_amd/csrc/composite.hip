@@ -64,6 +64,19 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     int start, end;      // the list of the LIST tile this 8x8 block lies in (n_tiles / tile_w are the 16x16 compute grid)
     block_list_range(lt, (tile % tile_w) * 2 + (w & 1), (tile / tile_w) * 2 + (w >> 1), width, height, n_isects, offsets, start, end);
 
+    if (seg.walk && blockIdx.x == 0) {
+        // the walk statistics the LAST backward left (complete: it is behind us on the stream): does the frame have a tail?
+        static_assert(SEG_WALK_SLOTS == 64, "one slot per lane");
+        uint32_t sum = seg.walk[l * 4 + 0], mx = seg.walk[l * 4 + 1], cnt = seg.walk[l * 4 + 2];
+        seg.walk[l * 4 + 0] = 0u; seg.walk[l * 4 + 1] = 0u; seg.walk[l * 4 + 2] = 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off);
+            const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx;
+        }
+        if (l == 0 && seg.host_flag && cnt > 0u && mx > (uint32_t)SEG_TRIGGER && 2ull * mx * cnt > (unsigned long long)SEG_TAIL_X2 * sum)
+            *(volatile uint32_t*)seg.host_flag = 1u;
+    }
     float T = 1.f;
     float acc[D];
 #pragma unroll

@@ -40,8 +40,8 @@ static constexpr int B2_NT = 64 * B2_NW;
 static_assert(B2CHUNK <= B2_NT || B2_NW == 2, "a round is staged by one pass of the workgroup's threads");
 
 
-// SEGM (gspl_composite.h, SegState) — 0: the plain walk, one workgroup per tile, whole list (it raises the host's flag when it meets
-// a walk longer than SEG: the next frames then run segmented).  1: the workgroup walks segment 0 of its tile — the whole walk when it
+// SEGM (gspl_composite.h, SegState) — 0: the plain walk, one workgroup per tile, whole list (it leaves its walk lengths for the next
+// forward, which decides whether the following frames run segmented).  1: the workgroup walks segment 0 of its tile — the whole walk when it
 // is at most SEG entries — and publishes the other segments of a longer walk as work items.  2: the launch behind it: one workgroup
 // per item slot, the published items are served, the other workgroups leave at once.
 template <int D, int MODE, bool CHW, bool ABS, bool PACKED, int SEGM = 0>
@@ -142,10 +142,15 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
     const int wave_last = wl;
     // the list range [seg_lo, seg_hi) this workgroup walks: the whole walk [start, block_last), or one segment of a long one
     int seg_lo = start, seg_hi = block_last;
-    if constexpr (SEGM == 0) {
-        // a walk longer than a segment: tell the host (a word of pinned memory it looks at before the next frames) — it switches the
-        // segmented form on.  A frame of short walks never gets here.
-        if (seg.host_flag && t == 0 && block_last - start > SEG_TRIGGER) *(volatile uint32_t*)seg.host_flag = 1u;
+    if constexpr (SEGM != 2) {
+        // this tile's walk, for the next forward's "does the frame have a tail" (gspl_composite.h, ADAPTIVE): fire-and-forget atomics
+        // on one of 64 rows
+        if (seg.walk && t == 0 && block_last > start) {
+            uint32_t* row = seg.walk + (size_t)((unsigned)tile & (SEG_WALK_SLOTS - 1)) * 4u;
+            atomicAdd(row + 0, (uint32_t)(block_last - start));
+            atomicMax(row + 1, (uint32_t)(block_last - start));
+            atomicAdd(row + 2, 1u);
+        }
     }
     if constexpr (SEGM != 0) {
         const int walked = block_last - start;
@@ -156,7 +161,6 @@ __global__ __launch_bounds__(B2_NT, GSPL_BWD2_WAVES) void composite_bwd2_kernel(
                 const uint32_t pos = atomicAdd(seg.count(), (uint32_t)(nseg - 1));
                 for (int sgm = 1; sgm < nseg; ++sgm)
                     if (pos + (uint32_t)(sgm - 1) < seg.slots) seg.work()[pos + (uint32_t)(sgm - 1)] = ((uint32_t)tile << 8) | (uint32_t)sgm;
-                if (seg.host_flag && walked > SEG_TRIGGER) *(volatile uint32_t*)seg.host_flag = 1u;      // (keeps the segmented form on)
             }
         }
         if (nseg > 1) {
@@ -552,7 +556,7 @@ static int launch_bwd(bool absgrad, int n_tiles, int tile_w, int width, int heig
         return check_launch("composite_bwd");
     }
     SegState plain = {};
-    if (seg_in) plain.host_flag = seg_in->host_flag;
+    if (seg_in) { plain.host_flag = seg_in->host_flag; plain.walk = seg_in->walk; }
     if constexpr (D == 3 && CHW && PACKED) {
         // the segmented form (the fused Inria call with checkpoints from its forward): regular gradients only — the deterministic mode
         // and absgrad keep the one-workgroup-per-tile walk

@@ -92,6 +92,24 @@ static uint32_t* seg_flag_word() {
     }
     return g_seg_flag[dev];
 }
+// the table the backward workgroups leave their walk lengths in (SEG_WALK_SLOTS rows of four words), one per device, zero at first
+static uint32_t* g_seg_walk[64] = {};
+static uint32_t* seg_walk_words() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_seg_mu);
+    if (!g_seg_walk[dev]) {
+        void* q = nullptr;
+        const size_t bytes = (size_t)SEG_WALK_SLOTS * 4 * sizeof(uint32_t);
+        if (hipMalloc(&q, bytes) != hipSuccess || hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            if (q) (void)hipFree(q);
+            return nullptr;
+        }
+        g_seg_walk[dev] = (uint32_t*)q;
+    }
+    return g_seg_walk[dev];
+}
 // the forward's decision for this frame: `force` (GSPL_INRIA_FORCE_SEGMENTS) or a long walk seen within the last 64 frames
 static bool seg_wanted(bool force) {
     uint32_t* flag = seg_flag_word();
@@ -242,15 +260,18 @@ extern "C" int gspl_rasterize_inria_fwd(
     // deterministic mode (its backward writes one row per list entry) and when the caller's allocator says no.
     SegState seg = {};
     const bool want_seg = !(flags & GSPL_INRIA_NO_SEGMENTS) && gspl_get_deterministic() == 0 && seg_wanted((flags & GSPL_INRIA_FORCE_SEGMENTS) != 0);
+    // (with or without checkpoints the forward kernel reduces the walk table the last backward left and raises the host's word)
+    const bool adaptive = !(flags & GSPL_INRIA_NO_SEGMENTS) && gspl_get_deterministic() == 0;
     auto make_seg = [&](int64_t cap) -> const SegState* {
         seg = SegState{};
+        if (adaptive) { seg.walk = seg_walk_words(); seg.host_flag = seg_flag_word(); }
         st->seg_ckpt = nullptr; st->seg_words = nullptr; st->seg_slots = 0u;
-        if (!want_seg || cap <= SEG) return nullptr;
+        if (!want_seg || cap <= SEG) return adaptive ? &seg : nullptr;
         const uint32_t slots = (uint32_t)(cap >> SEG_LOG2) + 2u;
         const size_t words = 2 + (size_t)slots;
         const size_t head = up256(words * sizeof(uint32_t));
         char* blk = (char*)alloc(alloc_ctx, GSPL_BUF_CHECKPOINTS, head + (size_t)slots * 256 * sizeof(float4));
-        if (!blk) return nullptr;
+        if (!blk) return adaptive ? &seg : nullptr;
         uint32_t* wds = (uint32_t*)blk;
         seg.words = wds; seg.slots = slots;      // (the item counter is cleared by the forward kernel itself)
         seg.ckpt = (float4*)(blk + head);
@@ -372,7 +393,7 @@ extern "C" int gspl_rasterize_inria_fwd(
     ProfScope prof(0, s);
     return composite_fwd_impl(N, n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height, tile,
                               tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s,
-                              seg.ckpt ? &seg : nullptr);
+                              (seg.ckpt || seg.walk) ? &seg : nullptr);
 }
 
 namespace gspl {
@@ -453,7 +474,7 @@ static int gspl::rasterize_inria_bwd_impl(
             seg.ckpt = (float4*)st->seg_ckpt;
             seg.words = st->seg_words; seg.slots = st->seg_slots;
         }
-        if (!(st->flags & GSPL_INRIA_NO_SEGMENTS)) seg.host_flag = seg_flag_word();      // plain or segmented: long walks are reported
+        if (!(st->flags & GSPL_INRIA_NO_SEGMENTS) && gspl_get_deterministic() == 0) seg.walk = seg_walk_words();      // plain or segmented: the walk lengths are left for the next forward
         ProfScope prof(1, s);
         rc = composite_bwd_packed_impl(N, st->n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width,
                                        height, tile, tile_w, tile_h, st->offsets, st->flatten_ids, st->final_Ts, st->last_ids, v_out_color, nullptr,

@@ -78,7 +78,12 @@ def request_stats_in_backward(radii: Tensor, xyz_gradient_accum: Tensor, denom: 
     (the preprocess-backward kernel has the row's gradient in registers).  Call it between the render and `loss.backward()`;
     afterwards `request.applied` says whether that backward ran and did it (it does so once) — if not, call
     `update_densification_stats` as before.  None: not possible here (switched off, not the fused call's radii, unfit buffers).
-    One request is pending at a time; a newer one replaces it, `withdraw_stats_request` drops it."""
+    One request is pending at a time; a newer one replaces it, `withdraw_stats_request` drops it.
+    Single-consumer assumption: the backward adds the gradient the RASTERIZER hands to `means2D`.  The reference reads the leaf's
+    accumulated `viewspace_points.grad` (vanilla_density_controller.py:111-117); the two are the same thing as long as nothing else
+    back-propagates into that tensor — true for the reference's loop and renderers (the tensor exists only to carry this gradient).  A
+    loss that also differentiates `viewspace_points` must not make this request (GSPL_STATS_IN_BACKWARD=0, or call
+    `update_densification_stats` itself)."""
     from .ops._state import STATE
     if not (STATE.stats_in_backward and STATE.fused_inria):
         return None

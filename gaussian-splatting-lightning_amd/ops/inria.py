@@ -315,11 +315,15 @@ class _InriaFusedFn(torch.autograd.Function):
                 plan = claim_backward_update(dict(means=means3D, scales=scales, rotations=rotations, opacities=opac, shs=sh, shs_rest=sh_rest))
                 if plan is not None:
                     scratch, v_ndc = E(N, 3), E(N, 3)
-                    with torch.cuda.device(dev):
-                        L.call("gspl_rasterize_inria_bwd_adam", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh),
-                               L.ptr(sh_rest), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier,
-                               L.ptr(radii), ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(scratch), L.ptr(v_ndc),
-                               ctypes.byref(plan), L.stream())
+                    try:
+                        with torch.cuda.device(dev):
+                            L.call("gspl_rasterize_inria_bwd_adam", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh),
+                                   L.ptr(sh_rest), L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier,
+                                   L.ptr(radii), ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(scratch), L.ptr(v_ndc),
+                                   ctypes.byref(plan), L.stream())
+                    except Exception:
+                        _poison(ctx, stats)
+                        raise
                     if stats is not None:
                         stats.applied = True
                         ctx.state.stats_accum = ctx.state.stats_denom = ctx.state.stats_max_radii = None
@@ -335,21 +339,37 @@ class _InriaFusedFn(torch.autograd.Function):
         v_sh_rest = None if sh_rest is None else torch.empty_like(sh_rest)
         v_cp = E(N, 3) if has_precomp_colors else None
         if N > 0:
-            with torch.cuda.device(dev):
-                L.call("gspl_rasterize_inria_bwd", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh), L.ptr(sh_rest),
-                       L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
-                       ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_sh_rest),
-                       L.ptr(v_cp), L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
+            try:
+                with torch.cuda.device(dev):
+                    L.call("gspl_rasterize_inria_bwd", degree, n_coeffs, L.ptr(means3D), L.ptr(scales), L.ptr(rotations), L.ptr(sh), L.ptr(sh_rest),
+                           L.ptr(opac), L.ptr(viewm), L.ptr(projm), L.ptr(campos), L.ptr(bg), tanfovx, tanfovy, scale_modifier, L.ptr(radii),
+                           ctypes.byref(ctx.state), L.ptr(v_out), L.ptr(packed), L.ptr(hit), L.ptr(v_means), L.ptr(v_ndc), L.ptr(v_sh), L.ptr(v_sh_rest),
+                           L.ptr(v_cp), L.ptr(v_opac), L.ptr(v_scales), L.ptr(v_quats), L.ptr(v_cov), L.stream())
+            except Exception:
+                _poison(ctx, stats)
+                raise
             if stats is not None:
                 stats.applied = True
                 ctx.state.stats_accum = ctx.state.stats_denom = ctx.state.stats_max_radii = None
             if hit is not None and ctx.means2D_ref is not None:
                 ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
+            if S.keep_last_raster and S.last_raster is not None:
+                # introspection (tests): the compositing backward's own per-splat rows, x y | a b c | opacity | r g b
+                S.last_raster["packed_grads"] = packed
         else:
             for t in (v_means, v_ndc, v_opac):
                 t.zero_()
         ctx.holder = None
         return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest, None
+
+
+def _poison(ctx, stats):
+    """A fused backward call that raised: the statistics pointers leave the frame's state — a retried backward must not hand
+    them to the kernel again — and the request counts as consumed: part of the launch sequence may have run and added the frame's
+    statistics already, so the controller's fall-back launch must not add them a second time."""
+    ctx.state.stats_accum = ctx.state.stats_denom = ctx.state.stats_max_radii = None
+    if stats is not None:
+        stats.applied = True
 
 
 def _mark_fused(out):

@@ -53,7 +53,15 @@ class _FusedAdamBase(torch.optim.Optimizer):
         the rasterizer differentiates (means, scales, rotations, opacities, SH) belongs to optimizers built with this flag and is
         handed to the rasterizer as it is stored (the renderer plugins do that for the reference's model) — otherwise the backward
         writes gradients as always and `step()` applies them; (4) hyper-parameters are read when the backward runs (a scheduler that
-        stepped after the previous `step()` is seen, as with torch.optim.Adam)."""
+        stepped after the previous `step()` is seen, as with torch.optim.Adam); (5) the rasterizer must be the ONLY autograd consumer
+        of those parameters in a step: a second path into them — a scale or opacity regulariser, a depth loss on the means — leaves a
+        gradient in `.grad` next to the update the backward has already applied (and may have been differentiated at parameters that
+        had already moved); `step()` then RAISES instead of applying a second update with a second step count — train
+        such a loss with the default two-kernel path; (6) on a densification step the reference DROPS the step's update (the density
+        controller replaces the Parameters in `after_backward`, before `step()` runs: internal/density_controllers/
+        vanilla_density_controller.py:125-178 behind gaussian_splatting.py:380-397) — here the rows were updated during the backward,
+        before the surgery copies them: one more Adam update on those steps than the reference applies (a few steps in thirty
+        thousand; the bench's reference-shaped loop reports both forms)."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         if weight_decay != 0.0 or amsgrad or maximize:
@@ -165,6 +173,15 @@ class _FusedAdamBase(torch.optim.Optimizer):
     def _launch(self, visibility: Optional[torch.Tensor]):
         L.lib()
         self.join()
+        if self._claimed:
+            # a parameter the backward has ALREADY updated must not carry a gradient now: something else differentiated it too, and
+            # applying that as a second update (a second step count, possibly evaluated at the moved parameter) would be silently wrong
+            stray = [group.get("name", "?") for group in self.param_groups for p in group["params"] if id(p) in self._claimed and p.grad is not None]
+            if stray:
+                self._claimed.clear()
+                raise RuntimeError("fused Adam (fuse_into_backward): parameter(s) " + ", ".join(map(str, stray)) + " were updated by the rasterizer's "
+                                   "backward AND received a gradient from a second autograd path (a regulariser / an extra loss on the same "
+                                   "parameters); use the default two-kernel path (fuse_into_backward=False) for such a step")
         self._claimed.clear()      # parameters a backward updated have no .grad: the loop below passes them by
         # tensors are batched per (N, betas, eps, step count): the reference has one parameter per group, all [N, ...]
         batches, later = {}, {}

@@ -270,3 +270,23 @@ def test_torch_reads_of_a_deferred_parameter_wait_for_its_update(reader):
             before = settled
     finally:
         opt.join()
+
+
+def test_a_stray_gradient_on_a_parameter_the_backward_has_updated_raises():
+    """with `fuse_into_backward` the rasterizer's backward updates a claimed parameter in place.  A second autograd
+    path into the same parameter (a regulariser, an extra loss) leaves a gradient in `.grad`; `step()` used to apply it as a SECOND
+    Adam update with a second step count.  Now it raises, names the parameter, and the optimizer is usable again afterwards (host
+    logic only: the claim is made by hand, nothing is launched)."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd.optimizers import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(8, 3))
+    q = torch.nn.Parameter(torch.zeros(8, 1))
+    opt = FusedAdam([{"params": [p], "name": "scales", "lr": 1e-3}, {"params": [q], "name": "opacities", "lr": 1e-3}], fuse_into_backward=True)
+    opt._claimed.update({id(p), id(q)})          # what the rasterizer's backward leaves behind (optimizers.claim_backward_update)
+    p.grad = torch.ones_like(p)                  # ... and what a regulariser on the scales adds
+    with pytest.raises(RuntimeError, match="second autograd path") as e:
+        opt.step()
+    assert "scales" in str(e.value) and "opacities" not in str(e.value)
+    assert not opt._claimed and opt.state[p].get("step", 0) in (0, None)      # nothing was applied, the claim is gone
+    p.grad = None
+    opt.step()                                   # nothing to do, nothing raised
