@@ -257,8 +257,18 @@ class _InriaFusedFn(torch.autograd.Function):
             S.speculation["misses"] += 1
         holder.pop(L.GSPL_BUF_BINNING, None)           # scratch of the count half and of the tile sort: not needed again
         holder.pop(L.GSPL_BUF_LISTS_WORK, None)
-        ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest)
-        ctx.holder, ctx.state = holder, state
+        # The frame's device buffers (projected splats, tile lists, per-pixel state, checkpoints: torch byte tensors the library carved up)
+        # are SAVED TENSORS of the node: autograd frees them when the graph is released — right after the backward, or, with
+        # `retain_graph=True`, when the graph dies — and a second backward through a released graph raises autograd's own error, as with
+        # the Inria op this replaces (round 6, VERDICT r5 #8b: rounds 1-5 dropped the buffers by hand after the first backward).
+        for tag in (L.GSPL_BUF_LISTS, L.GSPL_BUF_CHECKPOINTS):      # a frame whose room was too small allocated these twice: the first blocks are abandoned
+            if len(holder.get(tag, ())) > 1:
+                holder[tag] = holder[tag][-1:]
+        frame_buffers = [t for tag, ts in holder.items() if isinstance(ts, list) for t in ts]
+        ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest, *frame_buffers)
+        ctx.state, ctx.backwards_run = state, 0
+        # (the error slot must not outlive the call: an allocation the library handled gracefully — checkpoints it can do without — is not an error)
+        holder.pop("error", None)
         ctx.cfg = (H, W, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), colors_precomp is not None,
                    cov3D_precomp is not None, opacities.shape)
         ctx.set_materialize_grads(False)
@@ -285,14 +295,16 @@ class _InriaFusedFn(torch.autograd.Function):
     @_guarded(0)
     def backward(ctx, v_out, _v_radii):
         import ctypes
-        means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest = ctx.saved_tensors
+        means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest, *frame_buffers = ctx.saved_tensors      # (a released graph raises here)
         H, W, degree, n_coeffs, tanfovx, tanfovy, scale_modifier, has_precomp_colors, use_cov, opac_shape = ctx.cfg
         N = means3D.shape[0]
         dev = means3D.device
-        if ctx.holder is None:
-            # the frame's device buffers (projected splats, tile lists, per-pixel state) were handed back after the first backward
-            raise RuntimeError("GaussianRasterizer: this frame's backward has run already and its buffers are released "
-                               "(a second backward through the same render — retain_graph — is not supported; render again)")
+        ctx.backwards_run += 1
+        if ctx.backwards_run > 1 and ctx.state.seg_ckpt:
+            # retain_graph: the segmented backward counts the segments it publishes in two words the FORWARD kernel cleared — clear them again
+            for t in frame_buffers:
+                if t.data_ptr() <= ctx.state.seg_words < t.data_ptr() + t.numel():
+                    _view(t, ctx.state.seg_words, (2,), torch.int32).zero_()
         v_out = _grad_or_zeros(v_out, (3, H, W), dev)
         E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         packed = E(N, 9)
@@ -329,7 +341,6 @@ class _InriaFusedFn(torch.autograd.Function):
                         ctx.state.stats_accum = ctx.state.stats_denom = ctx.state.stats_max_radii = None
                     if hit is not None and ctx.means2D_ref is not None:
                         ctx.means2D_ref.has_hit_any_pixels = hit.view(torch.bool)
-                    ctx.holder = None
                     return None, v_ndc, None, None, None, None, None, None, None, None, None
         v_means, v_ndc, v_opac = E(N, 3), E(N, 3), E(N)
         v_scales = None if use_cov else E(N, 3)
@@ -359,7 +370,6 @@ class _InriaFusedFn(torch.autograd.Function):
         else:
             for t in (v_means, v_ndc, v_opac):
                 t.zero_()
-        ctx.holder = None
         return v_means, v_ndc, v_sh, v_cp, v_opac.reshape(opac_shape), v_scales, v_quats, v_cov, None, v_sh_rest, None
 
 

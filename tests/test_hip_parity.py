@@ -950,6 +950,42 @@ def test_a_fourfold_jump_in_list_length_misses_once_and_the_shuffled_stream_neve
     assert hip.SPECULATION["misses"] - misses0 == 1, "a view the running maximum already covers must not miss"
 
 
+@pytest.mark.parametrize("segmented", [False, "always"])
+def test_a_second_backward_through_a_retained_graph(hip, segmented):
+    """VERDICT r5 #8b: the Inria op this replaces keeps its buffers with the graph and supports `retain_graph=True` — a regulariser
+    that back-propagates twice through one frame.  The frame's device buffers are saved tensors of the node: a second backward
+    through a retained graph gives the same gradients (deterministic mode: bit for bit), also with the segmented walk (whose work
+    counter the forward cleared once), and a backward through a RELEASED graph gets autograd's own error."""
+    if not hip.FUSED_INRIA:
+        pytest.skip("GSPL_FUSED_INRIA=0")
+    means, scales, quats, opac, shs, cam, wimg, bg = _e2e_scene(n=6000, seed=45)
+    W, H = cam["width"], cam["height"]
+    saved = hip.SEGMENTED_BACKWARD
+    hip.SEGMENTED_BACKWARD = segmented
+    was = hip.set_deterministic(not segmented)      # (the deterministic mode keeps the plain walk: bit-exact there, atomics' spread with segments)
+    try:
+        leaves = [t.requires_grad_(True) for t in _cuda(means, scales * 6.0, quats, opac, shs)]
+        m, sc, q, o, c = leaves
+        screen = torch.zeros_like(m, requires_grad=True)
+        img, radii = hip.GaussianRasterizer(_inria_settings(hip, cam, bg, W, H))(means3D=m, means2D=screen, opacities=o, shs=c, scales=sc, rotations=q)
+        loss = (img * wimg.to(_dev())).sum()
+        g1 = torch.autograd.grad(loss, leaves + [screen], retain_graph=True)
+        g2 = torch.autograd.grad(loss, leaves + [screen], retain_graph=True)
+        for a, b in zip(g1, g2):
+            if segmented:
+                assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+            else:
+                assert torch.equal(a, b)
+        assert float(g1[0].abs().sum()) > 0
+        g3 = torch.autograd.grad(loss, leaves + [screen])              # releases the graph ...
+        assert float((g3[0] - g1[0]).abs().max()) <= 2e-5 * max(1.0, float(g1[0].abs().max()))
+        with pytest.raises(RuntimeError):                              # ... and then autograd refuses, as for any op
+            torch.autograd.grad(loss, leaves + [screen])
+    finally:
+        hip.set_deterministic(was)
+        hip.SEGMENTED_BACKWARD = saved
+
+
 def test_degenerate_inputs(hip):
     """Everything behind the camera, a single huge splat covering the whole image, image smaller than a tile."""
     d = _dev()
