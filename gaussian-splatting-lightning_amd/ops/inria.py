@@ -304,7 +304,7 @@ class _InriaFusedFn(torch.autograd.Function):
             # retain_graph: the segmented backward counts the segments it publishes in two words the FORWARD kernel cleared — clear them again
             for t in frame_buffers:
                 if t.data_ptr() <= ctx.state.seg_words < t.data_ptr() + t.numel():
-                    _view(t, ctx.state.seg_words, (2,), torch.int32).zero_()
+                    _view(t.data, ctx.state.seg_words, (2,), torch.int32).zero_()      # (.data: the saved tensor's version counter must not move)
         v_out = _grad_or_zeros(v_out, (3, H, W), dev)
         E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         packed = E(N, 9)
