@@ -182,12 +182,21 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     # per_step (the attribution run): host-side counters after every step — the caching allocator's hipMalloc count, the
     # speculation's cold / missed frames, N and the SH degree — to say what the steps after a densification event or an SH-degree raise pay for
-    trace = []
+    trace, comp = [], {}
+    RESET_STEP = 300
     def on_step(step, outputs):
         trace.append((torch.cuda.memory_stats(dev).get("num_device_alloc", 0), ops.SPECULATION["misses"], ops.SPECULATION["cold"],
                       model.n_gaussians, model.active_sh_degree))
+        if step == RESET_STEP:      # the compositing launches' durations up to the opacity reset and after it, apart (one synchronisation, traced run only)
+            comp["before_reset"] = _lib.profile_stop()
+            _lib.profile_start(("gspl_composite_bwd_packed", "gspl_composite_fwd"), period=1)
+    if per_step:
+        from gspl_amd import _lib
+        _lib.profile_start(("gspl_composite_bwd_packed", "gspl_composite_fwd"), period=1)
     res = BL.run(renderer, model, controller, optimizers, cams, targets, steps, bg, loss_fn, sh_degree_up_interval=150, view_stream=view_stream,
                  on_step=on_step if per_step else None)
+    if per_step:
+        comp["after_reset" if "before_reset" in comp else "before_reset"] = _lib.profile_stop()
     event_steps = {e["step"] for e in controller.events}
     quiet = [ms for i, ms in enumerate(res["step_ms"], start=1) if i not in event_steps and (i - 1) not in event_steps and i > 5]
     loud = [ms for i, ms in enumerate(res["step_ms"], start=1) if i in event_steps]
@@ -197,7 +206,9 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
         # where the mean exceeds the quiet median: every step's excess over the quiet p50, binned by what preceded it
         p50 = srt[len(srt) // 2] if srt else 0.0
         sh_steps = {s_ for s_ in range(150, steps + 1, 150)}
-        rows, bins = [], {"event steps": 0.0, "1-10 steps after an event": 0.0, "1-10 steps after an SH-degree raise": 0.0, "steps 1-5 of the loop": 0.0, "every other step": 0.0}
+        AFTER_RESET = "steps after the opacity reset (every opacity at 0.01: no pixel saturates, the compositing kernels walk the whole lists)"
+        rows, bins = [], {"event steps": 0.0, AFTER_RESET: 0.0, "1-10 steps after an event": 0.0, "1-10 steps after an SH-degree raise": 0.0,
+                          "steps 1-5 of the loop": 0.0, "every other step": 0.0}
         prev = (mallocs0, misses0, cold0, None, None)
         for i, ms in enumerate(res["step_ms"], start=1):
             cur = trace[i - 1]
@@ -208,6 +219,8 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
             excess = ms - p50
             if i in event_steps:
                 key = "event steps"
+            elif i > RESET_STEP:
+                key = AFTER_RESET
             elif since_event is not None and 1 <= since_event <= 10:
                 key = "1-10 steps after an event"
             elif since_sh is not None and 1 <= since_sh <= 10:
@@ -217,12 +230,17 @@ def reference_shaped_loop(dev, wl, cam_dicts, steps, fuse_activations=True, prew
             else:
                 key = "every other step"
             bins[key] += excess
-            if key != "every other step" or d_malloc or d_miss or d_cold or excess > 0.25:
-                rows.append({"step": i, "ms": round(ms, 3), "excess_ms": round(excess, 3), "what": key, "device_mallocs": d_malloc, "misses": d_miss,
-                             "cold": d_cold, "n": cur[3], "sh_degree": cur[4]})
+            if (key not in ("every other step", AFTER_RESET)) or d_malloc or d_miss or d_cold or (key == "every other step" and excess > 0.25):
+                rows.append({"step": i, "ms": round(ms, 3), "excess_ms": round(excess, 3), "what": key if key != AFTER_RESET else "after the opacity reset",
+                             "device_mallocs": d_malloc, "misses": d_miss, "cold": d_cold, "n": cur[3], "sh_degree": cur[4]})
         total_excess = sum(ms - p50 for ms in res["step_ms"])
-        attribution = {"quiet_p50_ms": round(p50, 4), "total_excess_ms": round(total_excess, 2), "excess_ms_by_cause": {k: round(v, 2) for k, v in bins.items()},
-                       "explained_share": round(1.0 - abs(bins["every other step"]) / max(total_excess, 1e-9), 3), "steps": rows}
+        mean_of = lambda pr, k: round(sum(pr.get(k, [])) / max(len(pr.get(k, [])), 1), 4) if pr.get(k) else None
+        attribution = {"what": "sum over the loop's steps of (step time - the quiet median), binned by what the step follows; the traced run reads host-side counters "
+                               "after every step and synchronises once (at the reset step), its own rate is not reported",
+                       "quiet_p50_ms": round(p50, 4), "total_excess_ms": round(total_excess, 2), "excess_ms_by_cause": {k: round(v, 2) for k, v in bins.items()},
+                       "explained_share": round(1.0 - abs(bins["every other step"]) / max(total_excess, 1e-9), 3),
+                       "compositing_ms_per_step": {w: {"fwd": mean_of(pr, "gspl_composite_fwd"), "bwd": mean_of(pr, "gspl_composite_bwd_packed")} for w, pr in comp.items()},
+                       "steps": rows}
     return {
         "attribution": attribution,
         "what": "bench_loop.py: RawGaussians (exp / sigmoid / normalize getters) + restated VanillaDensityControllerImpl + FusedAdam x 2 "
