@@ -220,7 +220,7 @@ def main():
         radii_max = max(radii_max, float(module.density_controller.max_radii2D.max()))
     module.eval()
     with torch.no_grad():
-        mine = [(j * WORLD + RANK) % len(cameras) for j in range(len(cameras) // WORLD)]     # every rank renders ITS cameras, in step
+        mine = [(j * WORLD + RANK) % len(cameras) for j in range(max(len(cameras) // WORLD, 1))]     # every rank renders ITS cameras, in step
         finals = [module(cameras[k])["render"] for k in mine]
     psnr = float(np.mean([T.psnr(f, targets[k]) for f, k in zip(finals, mine)]))
     lrs = [m for _, m in trainer.logger.metrics]

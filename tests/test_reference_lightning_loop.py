@@ -117,6 +117,42 @@ def test_unchanged_lightning_module_trains_on_two_ranks_with_the_sharded_plugin(
     assert total[86] == total[95] and (ranks[0]["counts"][86], ranks[1]["counts"][86]) != (ranks[0]["counts"][95], ranks[1]["counts"][95])
 
 
+@needs_reference
+def test_unchanged_lightning_module_trains_on_eight_ranks_with_the_sharded_plugin():
+    """`configs/distributed.yaml` at the world size it is written for (`devices: -1` on an 8-GPU node; BASELINE configs[3] / [4];
+    VERDICT r5 #1c): eight gloo processes run the reference's unchanged LightningModule with `HipGSplatDistributedRenderer` +
+    `DistributedVanillaDensityController`.  2000 Gaussians are cut into eight shards of 250 by `training_setup`, every step each rank
+    projects its shard for EIGHT cameras, the records cross in an eight-way all-to-all, every rank densifies its own rows, and the
+    redistribution after step 90 moves rows and their Adam moments between eight owners."""
+    from conftest import free_port
+    port, steps, world = free_port(), 100, 8
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")             # eight processes share the host's cores
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "reference_loop_worker.py"), REF_ROOT, str(steps), "hip-distributed",
+                               str(r), str(world), str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=1500))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-4000:]
+    ranks = [json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]) for so, _ in outs]
+    for r, d in enumerate(ranks):
+        first, last = float(np.mean(d["losses"][:12])), float(np.mean(d["losses"][-12:]))
+        print(f"rank {r}: loss {first:.4f} -> {last:.4f}, N {d['counts'][0]} -> {d['counts'][-1]}, PSNR of its camera {d['psnr']:.2f} dB, "
+              f"exchange {d['last_exchange']}, redistributions {d['redistributions']}")
+        assert d["rank"] == r and d["world"] == world and d["inside_reference"] is True
+        assert d["counts"][0] == 250 and max(d["counts"]) > 1.3 * d["counts"][0]                 # 2000 rows in eight shards, then densified
+        assert last < 0.8 * first and all(np.isfinite(d["losses"])) and d["psnr"] > 20.0
+        assert d["redistributions"] == 1 and d["accum_max"] > 0.0 and d["last_exchange"] in ("counted", "padded")
+    total = [sum(d["counts"][i] for d in ranks) for i in range(steps)]
+    # the redistribution (after step 90; densification at 80) changes who holds the rows, not how many there are
+    assert total[86] == total[95] and [d["counts"][86] for d in ranks] != [d["counts"][95] for d in ranks]
+
+
 def test_launcher_registers_the_stand_ins_before_the_entry_point_is_imported(tmp_path):
     """`python -m gspl_amd.launch <script> args...`: on a machine without the CUDA packages the reference's entry points import
     `diff_gaussian_rasterization` before their CLI has seen `--model.renderer`; the launcher registers the stand-ins first and then
