@@ -581,7 +581,7 @@ def main():
     import gspl_amd  # noqa: F401
     from gspl_amd import _lib, ops, synthetic
     from gspl_amd import distributed as gdist
-    from gspl_amd.density import update_densification_stats
+    from gspl_amd.density import update_densification_stats, update_densification_stats_views
     _lib.lib()
     if args.init_dist:
         gdist.SINGLE_RANK_SHORTCUT = False
@@ -708,10 +708,10 @@ def main():
             return state
         step.state = state
 
-        def stats(st, accum, denom, max_radii):           # DistributedVanillaDensityControllerImpl.update_states, fused kernel
+        def stats(st, accum, denom, max_radii):           # DistributedVanillaDensityControllerImpl.update_states: every camera of the step, one launch
             out = st["out"]
-            for r, vis in zip(out["projection_results_list"], out["visible_mask_list"]):
-                update_densification_stats(r[1].grad, vis, r[0], accum, denom, max_radii, scale=grad_scale)
+            update_densification_stats_views([r[1].grad for r in out["projection_results_list"]], out["visible_mask_list"],
+                                             [r[0] for r in out["projection_results_list"]], accum, denom, max_radii, scale=grad_scale)
         visible = None
         api = "gsplat"
     else:

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "gspl_composite_scores": (c_int, [c_int, c_int64, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                                       _P, _P, _P, _P, _P, _P, _P]),
     "gspl_densify_stats": (c_int, [c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gspl_densify_stats_views": (c_int, [c_int, c_int, _P, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "gspl_knn_workspace_bytes": (c_size_t, [c_int]),
     "gspl_knn3_mean_dist2": (c_int, [c_int, _P, _P, _P, c_size_t, _P]),
     "gspl_bin_count": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

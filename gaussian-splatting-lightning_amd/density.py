@@ -57,6 +57,54 @@ def update_densification_stats(grad: Tensor, visibility_filter: Optional[Tensor]
                L.ptr(xyz_gradient_accum), L.ptr(denom), L.ptr(max_radii2D), L.stream())
 
 
+@torch.no_grad()
+def update_densification_stats_views(grads, visibility_filters, radii, xyz_gradient_accum: Tensor, denom: Tensor,
+                                     max_radii2D: Optional[Tensor], scale: Union[None, float, int, Tensor] = None) -> None:
+    """`update_densification_stats` for the cameras of ONE Gaussian-sharded step — the loop of
+    `DistributedVanillaDensityControllerImpl.update_states` (distributed_vanilla_density_controller.py:22-47) — in one launch
+    instead of one per camera (eight at W = 8): grads / visibility_filters / radii are lists with one entry per camera
+    (`projection_results_list[i][1].grad`, `visible_mask_list[i]`, `projection_results_list[i][0]`).  The views are applied in list
+    order per Gaussian: bit-identical to the sequential calls.  More than 16 views, or inputs the kernel does not take (float radii,
+    non-contiguous gradients), fall back to the per-view launches."""
+    import ctypes
+    n_views = len(grads)
+    if n_views == 0:
+        return
+    ok = 1 <= n_views <= 16 and all(isinstance(g, Tensor) and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.dim() == 2 for g in grads)
+    ok = ok and all(r is not None and r.dtype == torch.int32 and r.is_contiguous() and r.numel() == grads[0].shape[0] for r in radii)
+    ok = ok and len({tuple(g.shape) for g in grads}) == 1 and (scale is None or isinstance(scale, (Tensor, float, int)))
+    if not ok:
+        for g, v, r in zip(grads, visibility_filters, radii):
+            update_densification_stats(g, v, r, xyz_gradient_accum, denom, max_radii2D, scale=scale)
+        return
+    N, stride = grads[0].shape
+    if N == 0:
+        return
+    for t, name in ((xyz_gradient_accum, "xyz_gradient_accum"), (denom, "denom"), (max_radii2D, "max_radii2D")):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != N):
+            raise RuntimeError(f"{name}: a contiguous float32 tensor with one element per Gaussian is needed")
+    vis = []
+    for v in visibility_filters:
+        if v is None:
+            vis.append(None)
+            continue
+        v = v.reshape(-1)
+        vis.append((v if v.dtype in (torch.bool, torch.uint8) else v != 0).contiguous().view(torch.uint8))
+    sx = sy = 1.0
+    s_dev = None
+    if isinstance(scale, Tensor):
+        s_dev = scale.detach().to(device=grads[0].device, dtype=torch.float32).reshape(-1)
+        s_dev = (s_dev.expand(2) if s_dev.numel() == 1 else s_dev[:2]).contiguous()
+    elif scale is not None:
+        sx = sy = float(scale)
+    PA = ctypes.c_void_p * n_views
+    addr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(grads[0].device):
+        L.call("gspl_densify_stats_views", N, n_views, PA(*[addr(g) for g in grads]), stride, sx, sy, L.ptr(s_dev),
+               PA(*[addr(v) for v in vis]) if any(v is not None for v in vis) else None, PA(*[addr(r.reshape(-1)) for r in radii]),
+               L.ptr(xyz_gradient_accum), L.ptr(denom), L.ptr(max_radii2D), L.stream())
+
+
 class StatsRequest:
     """A frame's statistics handed to that frame's backward: `applied` turns True once the fused Inria backward that owns `radii`
     has run the update of `update_densification_stats(viewspace.grad, None, radii, ...)` inside its last kernel."""
@@ -140,3 +188,35 @@ class HipDensityStatsMixin:
         grad = vp.absgrad if getattr(self.config, "absgrad", False) is True else vp.grad
         update_densification_stats(grad, outputs["visibility_filter"], outputs["radii"], self.xyz_gradient_accum, self.denom,
                                    self.max_radii2D, scale=outputs.get("viewspace_points_grad_scale", None))
+
+
+class HipDistributedDensityStatsMixin:
+    """`update_states` of the reference's `DistributedVanillaDensityControllerImpl`
+    (internal/density_controllers/distributed_vanilla_density_controller.py:22-47: a Python loop over the step's cameras, a dozen torch
+    launches each) on ONE launch for all cameras of the step (`update_densification_stats_views`); same reads of `outputs` —
+    `cameras`, `projection_results_list`, `visible_mask_list`, `xys_grad_scale_required`, `config.absgrad` — same buffers:
+
+        class HipDistributedVanillaDensityControllerImpl(HipDistributedDensityStatsMixin, DistributedVanillaDensityControllerImpl):
+            pass
+
+    Cameras of different sizes (a per-view gradient scale) take one launch per view."""
+
+    def update_states(self, outputs):
+        cameras, results, masks = outputs["cameras"], outputs["projection_results_list"], outputs["visible_mask_list"]
+        absgrad = getattr(self.config, "absgrad", False) is True
+        grads = [(r[1].absgrad if absgrad else r[1].grad) for r in results]
+        radii = [r[0] for r in results]
+        scale, per_view = None, None
+        if outputs.get("xys_grad_scale_required", False) is True:
+            dev = results[0][1].device
+            sizes = [(int(c.width), int(c.height)) for c in cameras]
+            if len(set(sizes)) == 1:
+                scale = 0.5 * torch.tensor(sizes[0], dtype=torch.float32, device=dev)
+            else:
+                per_view = [0.5 * torch.tensor(wh, dtype=torch.float32, device=dev) for wh in sizes]
+        accum, denom = self.xyz_gradient_accum.reshape(-1), self.denom.reshape(-1)
+        if per_view is None:
+            update_densification_stats_views(grads, masks, radii, accum, denom, self.max_radii2D, scale=scale)
+        else:
+            for g, m, r, s_ in zip(grads, masks, radii, per_view):
+                update_densification_stats(g, m, r, accum, denom, self.max_radii2D, scale=s_)

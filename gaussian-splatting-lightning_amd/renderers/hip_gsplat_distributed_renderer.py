@@ -272,11 +272,29 @@ class HipGSplatDistributedRendererImpl(Renderer):
         # gsplat_distributed_appearance_embedding_renderer.py:67-84): per camera, as the reference calls it (:308)
         return results, [self.get_rgbs(pc, cam, r) for cam, r in zip(cameras, results)]
 
+    def _camera_rows(self, c, device):
+        """(view matrix [4,4], intrinsics [3,3], centre [3]) of ONE camera, built once per camera: the intrinsics matrix alone is an
+        `eye` and four element copies — six tiny launches.  An entry KEEPS its source tensors and is valid only while every one of
+        them is the same object at the same version (as `GSplatV1.preprocess_camera`): an address handed out again by the allocator
+        to a new camera's tensor can never match, an in-place pose edit misses."""
+        src = (c.world_to_camera, c.camera_center, c.fx, c.fy, c.cx, c.cy)
+        key = tuple((id(v), v._version) if isinstance(v, torch.Tensor) else float(v) for v in src) + (str(device),)
+        cache = self.__dict__.setdefault("_camera_rows_cache", {})
+        hit = cache.get(key)
+        if hit is not None and all((a is b) if isinstance(b, torch.Tensor) else (a == b) for a, b in zip(hit[0], src)):
+            return hit[1]
+        if len(cache) > 4096:
+            cache.clear()
+        rows = (c.world_to_camera.T.contiguous(), GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, device), c.camera_center)
+        cache[key] = (src, rows)
+        return rows
+
     def _camera_batch(self, cameras, device):
-        """Stacked view matrices [W,4,4], intrinsics [W,3,3] and centres [W,3] of a camera set, built once per set: a training
-        run cycles through a fixed set of (camera, camera, ...) tuples, and the three stacks cost a dozen small launches.
-        A cache entry KEEPS its source tensors and is valid only while every one of them is the same object at the same version
-        (as `GSplatV1.preprocess_camera`): an address handed out again by the allocator to a new camera's tensor can never match."""
+        """Stacked view matrices [W,4,4], intrinsics [W,3,3] and centres [W,3] of this step's cameras.  Two levels of caching: the
+        per-CAMERA rows (`_camera_rows`: a data set's cameras are built once) and the stacks of a camera TUPLE.  A loader that serves
+        a fresh permutation every epoch (the reference's, internal/dataset.py:216-217) hands W > 1 ranks a new tuple nearly every step:
+        with the tuple cache alone that was ~50 tiny launches per step at W = 8 (profiles/r27_w8_shared_gpu_sequence_process_0.txt:
+        eight times `eye` + four element copies, plus the stacks); now it is the three `stack` launches."""
         src = tuple(v for c in cameras for v in (c.world_to_camera, c.camera_center, c.fx, c.fy, c.cx, c.cy))
         key = tuple((id(v), v._version) if isinstance(v, torch.Tensor) else float(v) for v in src) + (str(device),)
         cache = self.__dict__.setdefault("_camera_batches", {})
@@ -285,9 +303,8 @@ class HipGSplatDistributedRendererImpl(Renderer):
             return hit[1]
         if len(cache) > 256:
             cache.clear()
-        stacks = (torch.stack([c.world_to_camera.T for c in cameras]).contiguous(),
-                  torch.stack([GSplatV1.get_intrinsics_matrix(c.fx, c.fy, c.cx, c.cy, device) for c in cameras]).contiguous(),
-                  torch.stack([c.camera_center for c in cameras]).contiguous())
+        rows = [self._camera_rows(c, device) for c in cameras]
+        stacks = tuple(torch.stack([r[k] for r in rows]).contiguous() for k in range(3))
         cache[key] = (src, stacks)
         return stacks
 

@@ -651,6 +651,17 @@ int gspl_densify_stats(int N, const float* grad, int grad_stride, float scale_x,
                        const float* scale_dev /*nullable*/, const uint8_t* visible /*nullable*/,
                        const int32_t* radii_i32 /*nullable*/, const float* radii_f32 /*nullable*/,
                        float* accum, float* denom, float* max_radii /*nullable*/, void* stream);
+/* The same update for the n_views (<= GSPL_STATS_MAX_VIEWS) cameras of ONE Gaussian-sharded step in one launch — the loop over
+ * `projection_results_list` of `DistributedVanillaDensityControllerImpl.update_states`
+ * (internal/density_controllers/distributed_vanilla_density_controller.py:22-47): grads / visible / radii_i32 are HOST arrays of
+ * n_views device pointers ([N, grad_stride] f32, [N] u8 or NULL entries, [N] i32 or NULL entries; `visible` / `radii_i32` themselves may
+ * be NULL); the views are applied in array order per Gaussian: the buffers equal those of n_views sequential gspl_densify_stats
+ * calls bit for bit.  (Additive to ABI 34: round 6.) */
+#define GSPL_STATS_MAX_VIEWS 16
+int gspl_densify_stats_views(int N, int n_views, const float* const* grads, int grad_stride, float scale_x, float scale_y,
+                             const float* scale_dev /*nullable*/, const uint8_t* const* visible /*nullable*/,
+                             const int32_t* const* radii_i32 /*nullable*/,
+                             float* accum, float* denom, float* max_radii /*nullable*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 12. Per-splat statistics of a compositing pass (hit-pixel count / rasterize_to_weights).

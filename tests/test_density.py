@@ -72,3 +72,46 @@ def test_mixin_reads_outputs_like_the_reference_controller():
     ref = D.update_states(mr, acc, den, grad.abs(), vis, radii, scale=scale.cpu())
     assert torch.equal(c.max_radii2D.cpu(), ref[0]) and torch.equal(c.denom.cpu(), ref[2])
     np.testing.assert_allclose(c.xyz_gradient_accum.cpu().numpy(), ref[1].numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_views", [1, 3, 8])
+def test_stats_of_every_camera_of_a_sharded_step_in_one_launch(n_views):
+    """`update_densification_stats_views` (gspl_densify_stats_views; round 6): the loop over the step's cameras of
+    `DistributedVanillaDensityControllerImpl.update_states` (distributed_vanilla_density_controller.py:22-47) as one launch —
+    the buffers equal those of one `update_densification_stats` call per camera, in list order, bit for bit; and the mixin reads
+    `outputs` the way the reference's controller does."""
+    import types
+    import gspl_amd  # noqa: F401
+    from gspl_amd.density import update_densification_stats, update_densification_stats_views, HipDistributedDensityStatsMixin
+    dev, n = "cuda:0", 50_003
+    g = torch.Generator().manual_seed(n_views)
+    grads = [torch.randn(n, 2, generator=g).to(dev) for _ in range(n_views)]
+    radii = [torch.randint(0, 40, (n,), generator=g, dtype=torch.int32).to(dev) * (torch.rand(n, generator=g) > 0.3).to(dev) for _ in range(n_views)]
+    masks = [r > 0 for r in radii]
+    scale = 0.5 * torch.tensor([[640.0, 480.0]], device=dev)
+    start = [torch.rand(n, generator=g).to(dev), torch.randint(0, 5, (n,), generator=g).float().to(dev), torch.randint(0, 30, (n,), generator=g).float().to(dev)]
+    seq = [t.clone() for t in start]
+    for gr, m, r in zip(grads, masks, radii):
+        update_densification_stats(gr, m, r, *seq, scale=scale)
+    one = [t.clone() for t in start]
+    update_densification_stats_views(grads, masks, radii, *one, scale=scale)
+    assert all(torch.equal(a, b) for a, b in zip(one, seq))
+    assert not torch.equal(one[0], start[0])
+    # the mixin, on an `outputs` dictionary as HipGSplatDistributedRenderer returns it
+    class _Base:
+        def update_states(self, outputs):
+            raise AssertionError("the mixin must not fall through")
+    class Ctrl(HipDistributedDensityStatsMixin, _Base):
+        pass
+    c = Ctrl()
+    c.config = types.SimpleNamespace(absgrad=False)
+    c.xyz_gradient_accum, c.denom, c.max_radii2D = start[0].clone().reshape(n, 1), start[1].clone().reshape(n, 1), start[2].clone()
+    xys = []
+    for gr in grads:
+        x = torch.zeros(n, 2, device=dev, requires_grad=True)
+        x.grad = gr.clone()
+        xys.append(x)
+    cams = [types.SimpleNamespace(width=torch.tensor(640), height=torch.tensor(480)) for _ in range(n_views)]
+    c.update_states({"cameras": cams, "projection_results_list": [(r, x) for r, x in zip(radii, xys)], "visible_mask_list": masks, "xys_grad_scale_required": True})
+    assert torch.equal(c.xyz_gradient_accum.reshape(-1), seq[0]) and torch.equal(c.denom.reshape(-1), seq[1]) and torch.equal(c.max_radii2D, seq[2])
