@@ -74,8 +74,11 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
             sum += __shfl_xor(sum, off); cnt += __shfl_xor(cnt, off);
             const uint32_t o = __shfl_xor(mx, off); mx = o > mx ? o : mx;
         }
-        if (l == 0 && seg.host_flag && cnt > 0u && mx > (uint32_t)SEG_TRIGGER && 2ull * mx * cnt > (unsigned long long)SEG_TAIL_X2 * sum)
-            *(volatile uint32_t*)seg.host_flag = 1u;
+        if (l == 0 && seg.host_flag) {
+            const bool tail = cnt > 0u && mx > (uint32_t)SEG_TRIGGER && 2ull * mx * cnt > (unsigned long long)SEG_TAIL_X2 * sum;
+            // (cnt == 0: no backward ran since the last forward — no verdict, the slot keeps its old ticket)
+            if (cnt > 0u) *(volatile uint32_t*)seg.host_flag = (seg.ticket << 1) | (tail ? 1u : 0u);
+        }
     }
     float T = 1.f;
     float acc[D];

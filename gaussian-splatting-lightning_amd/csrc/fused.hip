@@ -12,6 +12,7 @@
 // pinned word per thread for the one read-back of the frame (the list length that sizes the tile sort).
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 #include "gspl_composite.h"
@@ -78,19 +79,59 @@ static bool wait_for_ticket(const int64_t* host, unsigned long long ticket, hipS
 // whenever it lands), and the number of frames the segmented form stays on after the word was last seen raised.  Process-wide:
 // autograd runs the backward on a thread of its own.
 static std::mutex g_seg_mu;
-static uint32_t* g_seg_flag[64] = {};
-static int g_seg_sticky[64] = {};
-static uint32_t* seg_flag_word() {
+// Per device: a ring of pinned host words the forward kernels store their verdicts into ((ticket << 1) | tail, about the PREVIOUS frame's
+// backward), the view each slot's verdict is about, the verdicts per view, and the stream-level stickiness for views without one.
+static constexpr unsigned SEG_RING = 16;
+struct SegAdaptive {
+    uint32_t* ring = nullptr;                 // pinned, SEG_RING words
+    uint32_t slot_ticket[SEG_RING] = {};      // ticket a slot is waiting for (0: free)
+    uintptr_t slot_view[SEG_RING] = {};       // ... and the view that verdict will be about
+    uint32_t next = 1;
+    uintptr_t prev_view = 0;                  // the view of the last forward (whose backward the next forward's kernel judges)
+    int sticky = 0;
+    std::unordered_map<uintptr_t, uint8_t> verdict;      // view -> 1 tail / 0 no tail
+};
+static SegAdaptive g_seg[64];
+// Called by the forward of a frame that may be segmented: collect the verdicts that have landed, decide for `view`, and hand out the ring
+// slot + ticket this forward's kernel reports under.
+static bool seg_decide(bool force, uintptr_t view, uint32_t** slot_out, uint32_t* ticket_out) {
+    *slot_out = nullptr; *ticket_out = 0u;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return force;
     std::lock_guard<std::mutex> lk(g_seg_mu);
-    if (!g_seg_flag[dev]) {
+    SegAdaptive& a = g_seg[dev];
+    if (!a.ring) {
         void* q = nullptr;
-        if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        g_seg_flag[dev] = (uint32_t*)q;
-        *g_seg_flag[dev] = 0u;
+        if (hipHostMalloc(&q, SEG_RING * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return force; }
+        a.ring = (uint32_t*)q;
+        for (unsigned i = 0; i < SEG_RING; ++i) a.ring[i] = 0u;
     }
-    return g_seg_flag[dev];
+    for (unsigned i = 0; i < SEG_RING; ++i) {
+        if (!a.slot_ticket[i]) continue;
+        const uint32_t v = __atomic_load_n(a.ring + i, __ATOMIC_RELAXED);
+        if ((v >> 1) != (a.slot_ticket[i] & 0x7fffffffu)) continue;      // not landed yet
+        const bool tail = (v & 1u) != 0u;
+        if (a.slot_view[i]) {
+            if (a.verdict.size() > 65536) a.verdict.clear();
+            a.verdict[a.slot_view[i]] = tail ? 1 : 0;
+        }
+        if (tail) a.sticky = 64;
+        a.slot_ticket[i] = 0u;
+    }
+    bool on = force;
+    const auto it = view ? a.verdict.find(view) : a.verdict.end();
+    if (it != a.verdict.end()) on = on || it->second != 0;
+    else on = on || a.sticky > 0;
+    if (a.sticky > 0) --a.sticky;
+    // this forward's kernel judges the backward of the previous forward's view
+    const unsigned slot = a.next % SEG_RING;
+    const uint32_t ticket = a.next & 0x7fffffffu;
+    ++a.next; if ((a.next & 0x7fffffffu) == 0u) a.next = 1;
+    a.slot_ticket[slot] = ticket;              // (an older verdict still waited for in this slot is given up: it never landed in 16 frames)
+    a.slot_view[slot] = a.prev_view;
+    a.prev_view = view;
+    *slot_out = a.ring + slot; *ticket_out = ticket;
+    return on;
 }
 // the table the backward workgroups leave their walk lengths in (SEG_WALK_SLOTS rows of four words), one per device, zero at first
 static uint32_t* g_seg_walk[64] = {};
@@ -109,18 +150,6 @@ static uint32_t* seg_walk_words() {
         g_seg_walk[dev] = (uint32_t*)q;
     }
     return g_seg_walk[dev];
-}
-// the forward's decision for this frame: `force` (GSPL_INRIA_FORCE_SEGMENTS) or a long walk seen within the last 64 frames
-static bool seg_wanted(bool force) {
-    uint32_t* flag = seg_flag_word();
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return force;
-    std::lock_guard<std::mutex> lk(g_seg_mu);
-    if (flag && __atomic_load_n(flag, __ATOMIC_RELAXED) != 0u) { __atomic_store_n(flag, 0u, __ATOMIC_RELAXED); g_seg_sticky[dev] = 64; }
-    const bool on = force || g_seg_sticky[dev] > 0;
-    if (g_seg_sticky[dev] > 0) --g_seg_sticky[dev];
-    return on;
 }
 
 static unsigned long long next_ticket() {
@@ -259,12 +288,14 @@ extern "C" int gspl_rasterize_inria_fwd(
     // are: the guess, or the real length), from one allocation kept until the backward.  Off with GSPL_INRIA_NO_SEGMENTS, in the
     // deterministic mode (its backward writes one row per list entry) and when the caller's allocator says no.
     SegState seg = {};
-    const bool want_seg = !(flags & GSPL_INRIA_NO_SEGMENTS) && gspl_get_deterministic() == 0 && seg_wanted((flags & GSPL_INRIA_FORCE_SEGMENTS) != 0);
-    // (with or without checkpoints the forward kernel reduces the walk table the last backward left and raises the host's word)
     const bool adaptive = !(flags & GSPL_INRIA_NO_SEGMENTS) && gspl_get_deterministic() == 0;
+    uint32_t* verdict_slot = nullptr;
+    uint32_t verdict_ticket = 0u;
+    const bool want_seg = adaptive && seg_decide((flags & GSPL_INRIA_FORCE_SEGMENTS) != 0, (uintptr_t)viewmatrix, &verdict_slot, &verdict_ticket);
+    // (with or without checkpoints the forward kernel reduces the walk table the last backward left and reports its verdict)
     auto make_seg = [&](int64_t cap) -> const SegState* {
         seg = SegState{};
-        if (adaptive) { seg.walk = seg_walk_words(); seg.host_flag = seg_flag_word(); }
+        if (adaptive) { seg.walk = seg_walk_words(); seg.host_flag = verdict_slot; seg.ticket = verdict_ticket; }
         st->seg_ckpt = nullptr; st->seg_words = nullptr; st->seg_slots = 0u;
         if (!want_seg || cap <= SEG) return adaptive ? &seg : nullptr;
         const uint32_t slots = (uint32_t)(cap >> SEG_LOG2) + 2u;

@@ -137,18 +137,19 @@ __device__ __forceinline__ unsigned band_half_mask(float mx, float my, float a, 
 //             a tile with a longer walk PUBLISHES its segments 1.. as work items, and the second launch — one workgroup per item
 //             slot (list capacity / SEG: what the host knows) — serves them.  No workgroup waits for another; nothing depends on
 //             dispatch order.
-//   ADAPTIVE  a frame is segmented only while the walks have a TAIL: every backward workgroup adds its tile's walk length to a small
-//             table of device words (sum, maximum, non-empty tiles; 64 slots by tile index, fire-and-forget atomics), the NEXT frame's
-//             forward kernel — behind that backward on the stream, so the table is complete — reduces it, raises a word of pinned host
-//             memory when the longest walk exceeds SEG_TRIGGER entries AND 6 x the mean walk of the non-empty tiles (SEG_TAIL_X2 / 2;
-//             measured per view, profiles/r23_walk_tail_probe.txt: with a longest walk above 768 the plain kernel wins by 44-61 us up to
-//             a ratio of 3.3, the segmented form by 43-960 us from 5.6 on.  The switch is per FRAME STREAM, not per view — 64 frames
-//             of stickiness — so the threshold sits above the one far view of the metric workload's camera set that would gain, ratio
-//             5.7, 131 us, and drag the fifteen views that lose 14-61 us each along: 830 against 795 images/s), and clears the table; the host looks
-//             at the word — no synchronisation — before a later forward and keeps the segmented form on for the following 64 frames.
-//             (Round 5's trigger was the length alone.  Round 6's close-up views of the uniform cloud walk 800-1000 entries in EVERY tile:
-//             no tail, nothing to spread — and the segmented form cost those frames 38 us, checkpoints + second launch,
-//             profiles/r22_records_48B_ab.txt.)  A scene without a tail never leaves the plain kernels: no checkpoint, no second launch.
+//   ADAPTIVE  a frame is segmented only when ITS VIEW's walks have a tail.  Every backward workgroup adds its tile's walk length to a small
+//             table of device words (sum, maximum, non-empty tiles; 64 rows by tile index, fire-and-forget atomics); the NEXT frame's
+//             forward kernel — behind that backward on the stream, so the table is complete — reduces it, stores a verdict into the slot of
+//             a small ring of pinned host words it was given (ticket << 1 | tail; tail = the longest walk exceeds SEG_TRIGGER entries AND
+//             4.5 x the mean walk of the non-empty tiles, SEG_TAIL_X2 / 2) and clears the table.  The host — no synchronisation — reads the
+//             slots that have landed before a later forward and remembers the verdict PER VIEW (the address of the view matrix the
+//             previous frame was rendered with: a data set's cameras are persistent tensors); a frame is segmented when its view's last
+//             verdict was "tail", a view without a verdict follows the stream (segmented for 64 frames after any "tail").
+//             Measured per view (profiles/r23_walk_tail_probe.txt): with a longest walk above 768 the plain kernel wins by 44-61 us up
+//             to a ratio of 3.3, the segmented form by 43-960 us from 5.6 on — every view of a trained-scene-shaped frame, and ONE far
+//             view of the metric workload's heterogeneous set (-131 us), which a per-stream switch could not take without dragging the
+//             fifteen views that lose 14-61 us along.  (Round 5's trigger was the length alone: close-up views of the uniform cloud walk
+//             800-1000 entries in EVERY tile — no tail, nothing to spread — and paid 38 us for checkpoints and a second launch.)
 // D == 3 only (a checkpoint is one float4); off (ckpt == nullptr) everywhere else.
 #ifndef GSPL_SEG_LOG2
 #define GSPL_SEG_LOG2 8      // 256 entries per segment (measured on scene_surfaces, per step: 64 -> 1.63 ms, 128 -> 1.45, 256 -> 1.47, 512 -> 1.56, 1024 -> 1.72;
@@ -157,13 +158,14 @@ __device__ __forceinline__ unsigned band_half_mask(float mx, float my, float a, 
 static constexpr int SEG_LOG2 = GSPL_SEG_LOG2;
 static constexpr int SEG = 1 << SEG_LOG2;
 static constexpr int SEG_TRIGGER = 3 * SEG;    // a walk longer than this (and SEG_TAIL x the mean walk) switches the segmented form on (a tile of two segments is not worth a second launch)
-static constexpr int SEG_TAIL_X2 = 12;         // ... the launch lasts as long as its longest tile only when that tile is far longer than the bulk: 2 x longest > 12 x mean
+static constexpr int SEG_TAIL_X2 = 9;          // ... the launch lasts as long as its longest tile only when that tile is far longer than the bulk: 2 x longest > 9 x mean
 static constexpr int SEG_WALK_SLOTS = 64;      // rows of (sum, max, non-empty tiles, -) in SegState::walk
 static constexpr int SEG_MAX = 255;            // segments per tile (8 bits in a work item); the last one takes whatever is left
 struct SegState {
     float4* ckpt;
     uint32_t* words;      // [0]: published work items (zero before the backward); [2 .. 2 + slots): the items, (tile << 8) | segment
-    uint32_t* host_flag;  // pinned host word: "the walks of a frame had a tail" (nullable)
+    uint32_t* host_flag;  // pinned host word (a slot of the verdict ring): receives (ticket << 1) | "the last backward's walks had a tail" (nullable)
+    uint32_t ticket;      // ... of this forward
     uint32_t* walk;       // device, [SEG_WALK_SLOTS][4]: the backward's walk statistics, reduced and cleared by the next forward (nullable)
     uint32_t slots;
     __host__ __device__ uint32_t* count() const { return words; }

@@ -107,7 +107,7 @@ def test_a_frame_of_short_walks_lists_no_segment():
 
 
 def test_the_adaptive_switch_asks_for_a_tail_not_for_length():
-    """Round 6: the segmented form switches itself on when the longest walk of a frame exceeds 768 entries AND six times the mean walk
+    """Round 6: the segmented form switches itself on when the longest walk of a frame exceeds 768 entries AND 4.5 times the mean walk, and remembers the verdict per view
     (gspl_composite.h, ADAPTIVE: every backward leaves its tiles' walk lengths, the next forward reduces them).  A trained-scene-shaped
     frame (heavy tail) turns it on within a few frames; a frame whose walks are uniformly long — every tile of a close-up view of a
     translucent cloud — must NOT (there is no tail to spread; the checkpoints and the second launch cost 38 us per step at S-1080p-1M,
