@@ -125,6 +125,9 @@ def all_to_all_route(send_counts: Sequence[int], recv_counts: Sequence[int], gro
             lambda v_rows: _all_to_all_rows_raw(v_rows, recv_counts, send_counts, group))
 
 
+_TRACKER_LOCK = __import__("threading").Lock()
+
+
 class HostMailbox:
     """What the ranks of ONE node have to agree on before a step — camera id, local Gaussian count, vote on the exchange format:
     a short row of integers per rank — through POSIX shared memory instead of a collective: every rank stores its row and a sequence
@@ -140,15 +143,6 @@ class HostMailbox:
         self.width, self.seq = int(width), 0
         # the collectives' patience, not a few seconds: a rank that writes a checkpoint or logs images keeps the others waiting here
         self.timeout_s = float(os.environ.get("GSPL_MAILBOX_TIMEOUT_S", "1800"))
-        if self.world > 1:
-            # ONE node, verified collectively: on a second node `SharedMemory(name=...)` would fail on those ranks only and leave
-            # the first node's ranks in the barrier below — every rank raises, or none
-            import socket
-            hosts = [None] * self.world
-            dist.all_gather_object(hosts, socket.gethostname(), group=group)
-            if len(set(hosts)) != 1:
-                raise RuntimeError(f"HostMailbox: the ranks of the group run on {len(set(hosts))} hosts ({sorted(set(hosts))}); shared host memory "
-                                   "(and the peer transport that uses it) is a one-node transport — use exchange_transport='collective'")
         # two copies of the table, used alternately: a rank can be one call ahead of the slowest reader of the previous call (never
         # two: the call after the next needs everybody's rows of the next), so its new row must not land where that reader looks
         nbytes = 8 * 2 * self.world * (self.width + 1)
@@ -159,18 +153,44 @@ class HostMailbox:
             names = [self._shm.name]
         if self.world > 1:
             dist.broadcast_object_list(names, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        attach_error = None
         if self.rank != 0:
             # Python < 3.13 registers an ATTACHED segment with the resource tracker too (no `track=False` yet).  The segment belongs to
             # rank 0: an attaching rank must leave no trace there — registering and unregistering again is not the same thing when the
             # ranks share one tracker (multiprocessing children do): the name is one set entry, and rank 0's unlink would then
-            # unregister a name that is already gone (a KeyError traceback from the tracker at exit)
-            from multiprocessing import resource_tracker
-            register = resource_tracker.register
-            resource_tracker.register = lambda *a, **k: None
+            # unregister a name that is already gone (a KeyError traceback from the tracker at exit).  The tracker's `register` is
+            # swapped out under a process-wide lock, for the attach alone (another thread creating a segment of its own at
+            # that moment waits for the lock instead of going untracked).
+            import sys
             try:
-                self._shm = shared_memory.SharedMemory(name=names[0])
-            finally:
-                resource_tracker.register = register
+                if sys.version_info >= (3, 13):
+                    self._shm = shared_memory.SharedMemory(name=names[0], track=False)
+                else:
+                    from multiprocessing import resource_tracker
+                    with _TRACKER_LOCK:
+                        register = resource_tracker.register
+                        resource_tracker.register = lambda *a, **k: None
+                        try:
+                            self._shm = shared_memory.SharedMemory(name=names[0])
+                        finally:
+                            resource_tracker.register = register
+            except Exception as e:      # noqa: BLE001 — a rank on another node (or in another IPC namespace) cannot see the segment
+                attach_error = f"rank {self.rank}: {e!r}"
+        if self.world > 1:
+            # ONE node (one IPC namespace), verified collectively BY THE ATTACH ITSELF (host names lie in both directions —
+            # containers of one node differ, nodes of a cluster may share one): every rank says whether it sees rank 0's segment, and a
+            # failure anywhere is raised everywhere — nobody is left in the barrier below
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, attach_error, group=group)
+            failed = [v for v in verdicts if v is not None]
+            if failed:
+                if getattr(self, "_shm", None) is not None:
+                    self._shm.close()
+                    if self.rank == 0:
+                        self._shm.unlink()
+                    self._shm = None
+                raise RuntimeError("HostMailbox: shared host memory (and the peer transport that uses it) is a one-node transport — "
+                                   f"{len(failed)} rank(s) cannot attach rank 0's segment ({'; '.join(failed)}); use exchange_transport='collective'")
         self._rows = np.ndarray((2, self.world, self.width + 1), dtype=np.int64, buffer=self._shm.buf)      # [..., -1] = sequence number
         if self.world > 1:
             dist.barrier(group=group)
@@ -236,9 +256,10 @@ class PeerExchange:
     Buffers grow (x 1.5, identically on every rank) when the Gaussian counts outgrow them; the handles are exchanged again then."""
 
     FLOATS = RECORD_FLOATS
-    # Polls (~1 us each) before a device-side wait gives up and raises the error word instead of hanging the GPU.  A collective would
-    # block for the process group's timeout (minutes): the default is of that scale — a peer that is merely slow (a first-use path, an
-    # allocator stall, a checkpoint on another rank) must not turn into an error; GSPL_PEER_MAX_POLLS overrides it.
+    # Polls (~1 us each: a system-scope load + s_sleep 32) before a device-side wait gives up and raises the error word instead of hanging
+    # the GPU.  A collective would block for the process group's timeout (minutes): the default is of that scale — 120 M polls = about
+    # TWO MINUTES during which the waiting stream holds one wave busy-polling — so that a peer that is merely slow (a first-use path, an
+    # allocator stall, a checkpoint on another rank) does not turn into an error; GSPL_PEER_MAX_POLLS overrides it (tests: 3e5 = 0.3 s).
     MAX_POLLS = int(os.environ.get("GSPL_PEER_MAX_POLLS", "120000000"))
 
     def __init__(self, rank: int, group, device):
