@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSPL_HIP_LIB", os.path.join(_PKG_DIR, "libgspl_hip.so"))   # override: A/B builds of the same ABI
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 GSPL_RECORD_FLOATS = 12
 GSPL_CAMERA_PINHOLE, GSPL_CAMERA_ORTHO, GSPL_CAMERA_FISHEYE = 0, 1, 2
@@ -30,6 +30,8 @@ GSPL_INRIA_GEOMETRY, GSPL_INRIA_COLOURS, GSPL_INRIA_ALL = 1, 2, 3
 GSPL_INRIA_RAW_PARAMS = 1      # gspl_inria_state.flags: scales / rotations / opacities are the model's raw parameters
 GSPL_INRIA_NO_SEGMENTS = 2     # ... never segment the backward (the plain one-workgroup-per-tile walk)
 GSPL_INRIA_FORCE_SEGMENTS = 4  # ... always (default: adaptively, while walks longer than a segment are being met)
+GSPL_INRIA_WILL_BACKWARD = 8   # ... IN: a backward follows: the forward clears the backward's packed rows (GSPL_BUF_PACKED)
+GSPL_INRIA_PACKED_READY = 16   # ... OUT: it did
 GSPL_BIN_SPAN_BYTES = 64
 GSPL_ADAM_MAX_TENSORS = 16
 
@@ -56,7 +58,7 @@ class HipLibraryError(RuntimeError):
 
 
 # `gspl_alloc_fn` / `gspl_inria_state` of include/gspl_hip.h (the fused Inria entry points)
-GSPL_BUF_GEOMETRY, GSPL_BUF_BINNING, GSPL_BUF_IMAGE, GSPL_BUF_LISTS_WORK, GSPL_BUF_LISTS, GSPL_BUF_CHECKPOINTS = 1, 2, 3, 4, 5, 6
+GSPL_BUF_GEOMETRY, GSPL_BUF_BINNING, GSPL_BUF_IMAGE, GSPL_BUF_LISTS_WORK, GSPL_BUF_LISTS, GSPL_BUF_CHECKPOINTS, GSPL_BUF_PACKED = 1, 2, 3, 4, 5, 6, 7
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t)
 
 

@@ -9,6 +9,6 @@ void set_error(const char* where, const char* what) {
 }
 }  // namespace gspl
 
-extern "C" int gspl_abi_version(void) { return 34; }
+extern "C" int gspl_abi_version(void) { return 35; }
 extern "C" const char* gspl_last_error(void) { return gspl::g_err; }
 extern "C" size_t gspl_inria_state_bytes(void) { return sizeof(gspl_inria_state); }

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(
     int start, end;      // the list of the LIST tile this 8x8 block lies in (n_tiles / tile_w are the 16x16 compute grid)
     block_list_range(lt, (tile % tile_w) * 2 + (w & 1), (tile / tile_w) * 2 + (w >> 1), width, height, n_isects, offsets, start, end);
 
+    zero_table(seg.zero_p, seg.zero_n16);      // the backward's packed rows (this kernel waits for VALU issue: the stores ride for free)
     if (seg.walk && blockIdx.x == 0) {
         // the walk statistics the LAST backward left (complete: it is behind us on the stream): does the frame have a tail?
         static_assert(SEG_WALK_SLOTS == 64, "one slot per lane");
@@ -206,6 +207,7 @@ static int launch_fwd(int n_tiles, int tile_w, int width, int height, int64_t n_
                       const SegState* seg_in) {
     SegState seg = {};
     if (seg_in && D == 3 && lt.log2 == 4) seg = *seg_in;      // checkpoints: 16-pixel list tiles, three channels
+    else if (seg_in) { seg.zero_p = seg_in->zero_p; seg.zero_n16 = seg_in->zero_n16; }
     if (hit_flags)
         hipLaunchKernelGGL((composite_fwd_kernel<D, MODE, CHW, true>), dim3(4 * n_tiles), dim3(64), 0, s,
                            n_tiles, tile_w, width, height, n_isects, means2d, conics, colors, opacities, backgrounds,

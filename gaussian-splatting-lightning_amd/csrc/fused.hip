@@ -264,7 +264,7 @@ extern "C" int gspl_rasterize_inria_fwd(
     const int tile = 16, tile_w = (width + 15) / 16, tile_h = (height + 15) / 16, n_tiles = tile_w * tile_h;
     hipStream_t s = (hipStream_t)stream, ss = (hipStream_t)side_stream;
     const int flags = st->flags;
-    if (flags & ~(GSPL_INRIA_RAW_PARAMS | GSPL_INRIA_NO_SEGMENTS | GSPL_INRIA_FORCE_SEGMENTS)) return fail_arg("rasterize_inria_fwd: unknown state->flags (zero the struct before the call)");
+    if (flags & ~(GSPL_INRIA_RAW_PARAMS | GSPL_INRIA_NO_SEGMENTS | GSPL_INRIA_FORCE_SEGMENTS | GSPL_INRIA_WILL_BACKWARD)) return fail_arg("rasterize_inria_fwd: unknown state->flags (zero the struct before the call)");
     const bool raw = (flags & GSPL_INRIA_RAW_PARAMS) != 0;
     if (raw && (cov3D_precomp || (N > 0 && (!scales || !rotations)))) return fail_arg("rasterize_inria_fwd: raw parameters need scales and rotations");
     memset(st, 0, sizeof(*st));
@@ -293,16 +293,26 @@ extern "C" int gspl_rasterize_inria_fwd(
     uint32_t verdict_ticket = 0u;
     const bool want_seg = adaptive && seg_decide((flags & GSPL_INRIA_FORCE_SEGMENTS) != 0, (uintptr_t)viewmatrix, &verdict_slot, &verdict_ticket);
     // (with or without checkpoints the forward kernel reduces the walk table the last backward left and reports its verdict)
+    // the backward's packed rows, cleared by the forward's compositing kernel (GSPL_INRIA_WILL_BACKWARD, ABI 35)
+    uint4* packed_zero = nullptr;
+    uint32_t packed_n16 = 0u;
+    if ((flags & GSPL_INRIA_WILL_BACKWARD) && N > 0) {
+        const size_t bytes = ((size_t)N * 9 * sizeof(float) + 15) & ~(size_t)15;
+        packed_zero = (uint4*)alloc(alloc_ctx, GSPL_BUF_PACKED, bytes);
+        if (packed_zero && bytes / 16 <= 0xffffffffull) { packed_n16 = (uint32_t)(bytes / 16); st->flags |= GSPL_INRIA_PACKED_READY; }
+        else packed_zero = nullptr;
+    }
     auto make_seg = [&](int64_t cap) -> const SegState* {
         seg = SegState{};
+        seg.zero_p = packed_zero; seg.zero_n16 = packed_n16;
         if (adaptive) { seg.walk = seg_walk_words(); seg.host_flag = verdict_slot; seg.ticket = verdict_ticket; }
         st->seg_ckpt = nullptr; st->seg_words = nullptr; st->seg_slots = 0u;
-        if (!want_seg || cap <= SEG) return adaptive ? &seg : nullptr;
+        if (!want_seg || cap <= SEG) return (adaptive || packed_zero) ? &seg : nullptr;
         const uint32_t slots = (uint32_t)(cap >> SEG_LOG2) + 2u;
         const size_t words = 2 + (size_t)slots;
         const size_t head = up256(words * sizeof(uint32_t));
         char* blk = (char*)alloc(alloc_ctx, GSPL_BUF_CHECKPOINTS, head + (size_t)slots * 256 * sizeof(float4));
-        if (!blk) return adaptive ? &seg : nullptr;
+        if (!blk) return (adaptive || packed_zero) ? &seg : nullptr;
         uint32_t* wds = (uint32_t*)blk;
         seg.words = wds; seg.slots = slots;      // (the item counter is cleared by the forward kernel itself)
         seg.ckpt = (float4*)(blk + head);
@@ -424,7 +434,7 @@ extern "C" int gspl_rasterize_inria_fwd(
     ProfScope prof(0, s);
     return composite_fwd_impl(N, n_isects, 3, GSPL_MODE_INRIA, GSPL_LAYOUT_CHW, st->means2d, st->conics, st->colors, opacities, bg, width, height, tile,
                               tile_w, tile_h, st->offsets, st->flatten_ids, out_color, st->alphas, st->final_Ts, st->last_ids, nullptr, s,
-                              (seg.ckpt || seg.walk) ? &seg : nullptr);
+                              (seg.ckpt || seg.walk || seg.zero_p) ? &seg : nullptr);
 }
 
 namespace gspl {
@@ -487,8 +497,11 @@ static int gspl::rasterize_inria_bwd_impl(
     if (!packed || !v_out_color || !v_means3D || !v_means2D_ndc || !v_opacities) return fail_arg("rasterize_inria_bwd: NULL required pointer");
     const int tile = 16, tile_w = (width + 15) / 16, tile_h = (height + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(packed, 0, (size_t)N * 9 * sizeof(float), s);      // x y | a b c | opacity | r g b
-    if (e != hipSuccess) return check_hip(e, "rasterize_inria_bwd: clear");
+    hipError_t e = hipSuccess;
+    if (!(st->flags & GSPL_INRIA_PACKED_READY)) {      // (else `packed` is the forward's GSPL_BUF_PACKED block, cleared by its compositing kernel)
+        e = hipMemsetAsync(packed, 0, (size_t)N * 9 * sizeof(float), s);      // x y | a b c | opacity | r g b
+        if (e != hipSuccess) return check_hip(e, "rasterize_inria_bwd: clear");
+    }
     if (hit_flags) {
         e = hipMemsetAsync(hit_flags, 0, (size_t)N, s);
         if (e != hipSuccess) return check_hip(e, "rasterize_inria_bwd: clear");

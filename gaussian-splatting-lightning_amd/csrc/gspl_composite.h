@@ -167,6 +167,8 @@ struct SegState {
     uint32_t* host_flag;  // pinned host word (a slot of the verdict ring): receives (ticket << 1) | "the last backward's walks had a tail" (nullable)
     uint32_t ticket;      // ... of this forward
     uint32_t* walk;       // device, [SEG_WALK_SLOTS][4]: the backward's walk statistics, reduced and cleared by the next forward (nullable)
+    uint4* zero_p;        // forward only: a block this launch clears on behalf of the backward (its packed rows: GSPL_BUF_PACKED), 16-byte units
+    uint32_t zero_n16;
     uint32_t slots;
     __host__ __device__ uint32_t* count() const { return words; }
     __host__ __device__ uint32_t* work() const { return words + 2; }

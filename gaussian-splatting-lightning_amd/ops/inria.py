@@ -212,8 +212,11 @@ class _InriaFusedFn(torch.autograd.Function):
         key = (dev.index, tile_w, tile_h)
         hint = min(S.capacity.hint(key, N), MAX_ISECTS) if S.speculative_emit else 0      # (0: no history for this device and tile grid yet)
         state = L.InriaState()
+        will_backward = any(ctx.needs_input_grad)
         state.flags = (L.GSPL_INRIA_RAW_PARAMS if raw_params else 0) | ((L.GSPL_INRIA_FORCE_SEGMENTS if S.segmented_backward == "always" else 0)
-                       if (S.segmented_backward and any(ctx.needs_input_grad)) else L.GSPL_INRIA_NO_SEGMENTS)      # (only a frame that can have a backward)
+                       if (S.segmented_backward and will_backward) else L.GSPL_INRIA_NO_SEGMENTS)      # (only a frame that can have a backward)
+        if will_backward:
+            state.flags |= L.GSPL_INRIA_WILL_BACKWARD      # the forward's compositing kernel clears the backward's packed rows (no fill command there)
         holder = {"device": dev}
         _ALLOC_TLS.holder = holder
         side = _side_stream(dev)
@@ -267,6 +270,7 @@ class _InriaFusedFn(torch.autograd.Function):
         frame_buffers = [t for tag, ts in holder.items() if isinstance(ts, list) for t in ts]
         ctx.save_for_backward(means3D, scales, rotations, sh, opac, viewm, projm, campos, bg, radii, sh_rest, *frame_buffers)
         ctx.state, ctx.backwards_run = state, 0
+        ctx.packed_at = holder[L.GSPL_BUF_PACKED][-1].data_ptr() if (state.flags & L.GSPL_INRIA_PACKED_READY) else 0
         # (the error slot must not outlive the call: an allocation the library handled gracefully — checkpoints it can do without — is not an error)
         holder.pop("error", None)
         ctx.cfg = (H, W, int(s.sh_degree), n_coeffs, float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier), colors_precomp is not None,
@@ -307,7 +311,17 @@ class _InriaFusedFn(torch.autograd.Function):
                     _view(t.data, ctx.state.seg_words, (2,), torch.int32).zero_()      # (.data: the saved tensor's version counter must not move)
         v_out = _grad_or_zeros(v_out, (3, H, W), dev)
         E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        packed = E(N, 9)
+        packed = None
+        if ctx.packed_at:      # the block the forward's compositing kernel cleared (GSPL_INRIA_PACKED_READY): the C side clears nothing
+            for t in frame_buffers:
+                if t.data_ptr() == ctx.packed_at:
+                    packed = _view(t.data, ctx.packed_at, (N, 9), torch.float32)
+                    if ctx.backwards_run > 1:
+                        packed.zero_()      # retain_graph: the rows hold the first backward's sums
+        if packed is None:
+            packed = E(N, 9)
+            if ctx.packed_at:
+                raise RuntimeError("GaussianRasterizer: the forward's packed block is gone")
         hit = torch.empty((N,), dtype=torch.uint8, device=dev) if S.track_hit_pixels else None
         # the density controller's statistics of THIS frame (density.request_stats_in_backward: the request names the radii this
         # forward returned): the preprocess-backward kernel applies them, once

@@ -386,7 +386,9 @@ int gspl_inria_preprocess_bwd(int N, int degree, int n_coeffs,
  *    n_isects (the list length — feed it back as the next frame's hint); its `flags` field is read BEFORE it is filled.
  * ---------------------------------------------------------------------------------------- */
 enum { GSPL_BUF_GEOMETRY = 1, GSPL_BUF_BINNING = 2, GSPL_BUF_IMAGE = 3, GSPL_BUF_LISTS_WORK = 4, GSPL_BUF_LISTS = 5,
-       GSPL_BUF_CHECKPOINTS = 6 /* segmented backward: 4 KB per 256 list entries of capacity; kept until the backward like IMAGE / LISTS */ };
+       GSPL_BUF_CHECKPOINTS = 6 /* segmented backward: 4 KB per 256 list entries of capacity; kept until the backward like IMAGE / LISTS */,
+       GSPL_BUF_PACKED = 7 /* ABI 35, only with GSPL_INRIA_WILL_BACKWARD: 36 N bytes (rounded up to 16), the backward's per-splat rows
+                              x y | a b c | opacity | r g b, CLEARED by the forward's compositing kernel — hand it to the backward as `packed` */ };
 typedef void* (*gspl_alloc_fn)(void* ctx, int tag, size_t bytes);      /* device memory, 256-byte aligned; NULL = failure */
 typedef struct gspl_inria_state {
     int N, width, height;
@@ -413,7 +415,12 @@ typedef struct gspl_inria_state {
  *    kernels; the backward returns the gradients of the raw parameters.  Needs scales + rotations (no cov3D_precomp). */
 enum { GSPL_INRIA_RAW_PARAMS = 1,
        GSPL_INRIA_NO_SEGMENTS = 2 /* never: the backward walks every tile's list with one workgroup, however long */,
-       GSPL_INRIA_FORCE_SEGMENTS = 4 /* always take checkpoints (default: only while walks longer than a segment are being met) */ };
+       GSPL_INRIA_FORCE_SEGMENTS = 4 /* always take checkpoints (default: only while walks longer than a segment are being met) */,
+       GSPL_INRIA_WILL_BACKWARD = 8 /* ABI 35, IN: a backward will follow — the forward asks `alloc` for GSPL_BUF_PACKED and its compositing
+                                       kernel (VALU-bound, the memory system idle) clears it, instead of a 7 us fill command in front of the
+                                       backward's first kernel */,
+       GSPL_INRIA_PACKED_READY = 16 /* OUT (set by the forward in state->flags): the GSPL_BUF_PACKED block is cleared and the backward will NOT
+                                       clear its `packed` argument — which must be that block */ };
 size_t gspl_rasterize_inria_geometry_bytes(int N);
 size_t gspl_rasterize_inria_image_bytes(int width, int height);
 size_t gspl_inria_state_bytes(void);      /* sizeof(gspl_inria_state) as the library was built: a binding checks its own layout against it */
@@ -656,7 +663,7 @@ int gspl_densify_stats(int N, const float* grad, int grad_stride, float scale_x,
  * (internal/density_controllers/distributed_vanilla_density_controller.py:22-47): grads / visible / radii_i32 are HOST arrays of
  * n_views device pointers ([N, grad_stride] f32, [N] u8 or NULL entries, [N] i32 or NULL entries; `visible` / `radii_i32` themselves may
  * be NULL); the views are applied in array order per Gaussian: the buffers equal those of n_views sequential gspl_densify_stats
- * calls bit for bit.  (Additive to ABI 34: round 6.) */
+ * calls bit for bit.  (ABI 35: round 6.) */
 #define GSPL_STATS_MAX_VIEWS 16
 int gspl_densify_stats_views(int N, int n_views, const float* const* grads, int grad_stride, float scale_x, float scale_y,
                              const float* scale_dev /*nullable*/, const uint8_t* const* visible /*nullable*/,
