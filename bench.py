@@ -289,10 +289,15 @@ def make_step(api, dev, wl, cams, tensors, loss_kind="l1", rank=0, world=1, stre
         return i
     if api == "vanilla":
         from gspl_amd.density import request_stats_in_backward
+        # the cameras' device tensors are made ONCE per camera dictionary (a data set's cameras are persistent: the per-camera pass and the
+        # timed steps see the same view matrices — what the rasterizer's per-view memory of the segmented backward is keyed on)
+        for cam in cams:
+            if "_device_tensors" not in cam or cam["_device_tensors"][0] != str(dev):
+                cam["_device_tensors"] = (str(dev), cam["world_to_camera"].to(dev), cam["full_projection"].to(dev), cam["camera_center"].to(dev))
         rasts = [ops.GaussianRasterizer(ops.GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, scale_modifier=1.0,
-            viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=sh_degree,
-            campos=cam["camera_center"].to(dev))) for cam in cams]
+            viewmatrix=cam["_device_tensors"][1], projmatrix=cam["_device_tensors"][2], sh_degree=sh_degree,
+            campos=cam["_device_tensors"][3])) for cam in cams]
 
         def step():
             for t in tensors:
