@@ -1,0 +1,86 @@
+"""A fixed slice of the randomised campaigns (tools/fuzz_parity.py, tools/fuzz_differential.py; results of the full campaigns:
+profiles/r38_fuzz/) as a regression guard for the shapes the hand-written cases do not have: one-pixel-wide and one-pixel-high images,
+1 / 2 / 7 / 63 / 64 / 65 Gaussians, sub-pixel and screen-filling splats, cameras inside the cloud.
+
+  * the package's own code paths against each other: the Inria rasterizer fused / stage by stage / without speculative emission / with the
+    host-side list length / a second frame on warm speculation state — images and radii BIT-equal, gradients finite and equal within the
+    re-ordering of fp32 atomic sums; checkpointed frames within 4e-6;
+  * both APIs against the fp64 oracle: the image bars of the campaign (an unflagged pixel within 5e-5 — the fp32 spacing of the screen
+    position under a sub-pixel splat costs up to 3.4e-5, profiles/r38_fuzz/README.md — every pixel within one 8-bit step) and visibility.
+The gradient bars against the oracle stay with the calibrated scenes of test_hip_parity.py / test_metric_point_parity.py."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+
+
+@pytest.fixture(scope="module")
+def campaigns():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import fuzz_differential as FD
+    import fuzz_parity as FP
+    return FP, FD
+
+
+def test_inria_code_paths_agree_on_random_cases(campaigns):
+    FP, FD = campaigns
+    plain = dict(segmented_backward=False)
+    loose = dict(rel=2e-4, frac=0.99, cap=5e-2)
+    shapes = set()
+    for seed in range(5000, 5240):
+        desc, case = FP.random_case(seed)
+        shapes.add((desc["W"] == 1, desc["H"] == 1, desc["n"] <= 7))
+        base = FD.inria(case, **plain)
+        FD.same(FD.inria(case, **plain), base, f"seed {seed} {desc}: warm second frame", **loose)
+        FD.same(FD.inria(case, fused_inria=False, **plain), base, f"seed {seed} {desc}: stage by stage", **loose)
+        FD.same(FD.inria(case, speculative_emit=False, **plain), base, f"seed {seed} {desc}: no speculative emission", **loose)
+        FD.same(FD.inria(case, fused_inria=False, device_side_list_length=False, **plain), base, f"seed {seed} {desc}: host-side list length", **loose)
+        FD.same(FD.inria(case, segmented_backward="always"), base, f"seed {seed} {desc}: segmented backward", img_tol=4e-6, **loose)
+    assert len(shapes) >= 4, shapes      # the slice holds one-pixel-wide, one-pixel-high and few-splat cases
+
+
+@pytest.mark.parametrize("api", ["gsplat", "inria"])
+def test_images_against_the_oracle_on_random_cases(campaigns, api):
+    FP, _ = campaigns
+    from hip_helpers import fragile_rows
+    O, hip, dev = FP.O, FP.hip, FP.dev
+    from gspl_amd.ops._state import STATE as S
+    for seed in range(1000, 1096):
+        desc, (means, scales, quats, opac, shs, cam, wimg, bg) = FP.random_case(seed)
+        W, H = cam["width"], cam["height"]
+        deg = int(math.isqrt(shs.shape[1])) - 1
+        m, s, q, o, c = FP.cuda(means, scales, quats, opac, shs)
+        dl = [t.double() for t in (means, scales, quats, opac, shs)]
+        if api == "gsplat":
+            vm = cam["world_to_camera"].T.contiguous().float().to(dev)
+            xys, depths, radii, conics, comp, tiles, _ = hip.project_gaussians(m, s, 1.0, q, vm[:3], cam["fx"], cam["fy"], cam["cx"], cam["cy"], H, W, 16)
+            rgbs = hip.sh_view_colors(deg, m, cam["camera_center"].to(dev), c, None, radii > 0)
+            img = hip.rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, o * comp[:, None], H, W, 16, bg.to(dev)).permute(2, 0, 1)
+            r = O.render_gsplat(*dl, deg, cam["world_to_camera"].double(), cam["fx"], cam["fy"], cam["cx"], cam["cy"], W, H, bg.double(), cam["camera_center"].double())
+            differ = int(np.sum((radii > 0).cpu().numpy() != r["mask"].numpy()))
+            mode = O.MODE_GSPLAT
+        else:
+            st = hip.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg.to(dev), scale_modifier=1.0,
+                                                   viewmatrix=cam["world_to_camera"].to(dev), projmatrix=cam["full_projection"].to(dev), sh_degree=deg,
+                                                   campos=cam["camera_center"].to(dev))
+            img, radii = hip.GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), opacities=o, shs=c, scales=s, rotations=q)
+            r = O.render_inria(*dl, deg, cam["world_to_camera"].double(), cam["full_projection"].double(), cam["camera_center"].double(),
+                               cam["tanfovx"], cam["tanfovy"], W, H, bg.double())
+            differ = int(np.sum(radii.cpu().numpy() != r["radii"].numpy()))
+            mode = O.MODE_INRIA
+        assert differ <= max(1, len(means) // 500), f"seed {seed} {desc}: extents differ on {differ} splats"
+        assert bool(torch.isfinite(img).all())
+        _, frag = fragile_rows(mode, r, W, H, bg.double(), opacities=dl[3], gpu_radii=radii)
+        d = np.abs(img.detach().cpu().numpy().astype(np.float64) - r["render"].detach().numpy()).max(axis=0)
+        firm = ~frag
+        worst_firm = float(d[firm].max()) if firm.any() else 0.0
+        assert worst_firm <= 5e-5, f"seed {seed} {desc}: an unflagged pixel differs by {worst_firm:.3e}"
+        assert float(d.max()) <= 4e-3, f"seed {seed} {desc}: a pixel differs by {float(d.max()):.3e}"
+    assert S is not None
