@@ -103,3 +103,28 @@ def test_hip_fused_ssim_api_and_full_size():
     # photometric_loss = 0.8 L1 + 0.2 (1 - SSIM)
     pl = ops.photometric_loss(c.cuda(), d.cuda())
     assert abs(float(pl) - float(O.photometric_loss(c.double(), d.double()))) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 1, 100), (3, 100, 1), (3, 32, 64), (3, 33, 65), (3, 31, 63), (1, 97, 129), (3, 75, 200), (2, 11, 257),
+                                   (3, 43, 128), (3, 10, 10), (3, 64, 192), (4, 65, 127)])
+def test_hip_matches_oracle_at_the_strip_and_chunk_boundaries(shape):
+    """The kernels walk strips of 64 columns and chunks of 32 rows with 5-pixel halos: sizes one below / at / one above those edges, one-pixel
+    wide and one-pixel high planes, planes smaller than the 11-tap window — value and gradient against the fp64 oracle."""
+    import gspl_amd  # noqa: F401
+    from gspl_amd import ops
+    C, H, W = shape
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    base = 0.5 + 0.3 * torch.sin(xx * 0.37 + yy * 0.21)[None] * torch.linspace(0.5, 1.0, C)[:, None, None]
+    a0 = (base + 0.08 * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+    b0 = (base + 0.08 * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+    a = a0.cuda().requires_grad_(True)
+    l1, s = ops.l1_ssim(a, b0.cuda())
+    (0.8 * l1 + 0.2 * (1.0 - s)).backward()
+    a64 = a0.double().requires_grad_(True)
+    l1d, sd = O.l1_ssim(a64, b0.double())
+    (gd,) = torch.autograd.grad(0.8 * l1d + 0.2 * (1.0 - sd), a64)
+    assert abs(float(l1) - float(l1d)) <= 1e-6 and abs(float(s) - float(sd)) <= 1e-5
+    assert bool(torch.isfinite(a.grad).all())
+    assert float((a.grad.cpu().double() - gd).abs().max()) <= 1e-4 * float(gd.abs().max()) + 1e-9
