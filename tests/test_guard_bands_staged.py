@@ -16,8 +16,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 
 class Guards:
-    def __init__(self, monkeypatch):
+    def __init__(self, monkeypatch, poison=None):
+        """poison: a byte every handed-out buffer is filled with (0xFF: NaN as fp32, -1 as an index) — results that depend on what
+        `torch.empty` happened to leave in a buffer change with it."""
         self.blocks = []
+        self.poison = poison
         real_empty, real_empty_like = torch.empty, torch.empty_like
         guards = self
 
@@ -35,6 +38,8 @@ class Guards:
             outer[:GUARD] = 0xA5
             outer[GUARD + n:] = 0xA5
             guards.blocks.append((n, outer))
+            if guards.poison is not None:
+                outer[GUARD:GUARD + n] = guards.poison
             return outer[GUARD:GUARD + n].view(dtype).view(tuple(shape))
 
         def empty(*size, dtype=None, device=None, **kw):
@@ -171,3 +176,39 @@ def test_no_write_outside_the_buffers_of_the_renderer_plugins(monkeypatch):
             (out["render"] * wimg.to(dev)).sum().backward()
             total += g.check(f"seed {seed} {desc}: {name}")
     assert total > 1500
+
+
+
+def test_results_do_not_depend_on_what_the_buffers_held(monkeypatch):
+    """Every buffer the package takes from `torch.empty` (and every block of the fused call's allocator) pre-filled with 0xFF — NaN as
+    fp32, -1 as an index or a count — and again with 0x00: the images are bit-equal to each other and the gradients finite and equal
+    within the re-ordering of atomic sums, i.e. nothing is read before it is written."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import fuzz_parity as FP
+    import fuzz_differential as FD
+    from gspl_amd import _lib as L
+    from gspl_amd.ops import inria
+    g = Guards(monkeypatch, poison=0xFF)
+
+    def filled(_ctx, tag, nbytes):      # the fused call's allocation call-back
+        holder = inria._ALLOC_TLS.holder
+        try:
+            t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=holder["device"])      # (guarded + poisoned by `g`)
+            holder.setdefault(tag, []).append(t)
+            return t.data_ptr()
+        except Exception as e:      # noqa: BLE001
+            holder["error"] = e
+            return 0
+
+    monkeypatch.setattr(inria, "_ALLOC_CB", L.ALLOC_FN(filled))
+    loose = dict(rel=2e-4, frac=0.99, cap=5e-2)
+    for seed in range(9500, 9530):
+        desc, case = FP.random_case(seed)
+        runs = {}
+        for poison in (0xFF, 0x00):
+            g.poison = poison
+            runs[poison] = (FD.inria(case, segmented_backward=False), FD.inria(case, segmented_backward="always"),
+                            FD.inria(case, fused_inria=False, segmented_backward=False), FD.gsplat(case, 16))
+            g.check(f"seed {seed} {desc}: poison {poison:#x}")
+        for a, b, what in zip(runs[0xFF], runs[0x00], ("fused", "fused, segmented", "staged", "gsplat ops")):
+            FD.same(a, b, f"seed {seed} {desc}: {what}, buffers pre-filled with 0xFF against 0x00", **loose)
