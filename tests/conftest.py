@@ -13,11 +13,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+_PORTS_HANDED_OUT = set()
+
+
 def free_port() -> int:
-    """A TCP port nobody listens on right now (rendezvous of the multi-process tests): asked from the kernel per test, so that
-    two tests of one session never meet on a port that is still in TIME_WAIT."""
+    """A TCP port nobody listens on right now (rendezvous of the multi-process tests): a fresh one per test, so that two tests of one
+    session never meet on a port that is still in TIME_WAIT — and taken BELOW the kernel's ephemeral range (/proc/sys/net/ipv4/
+    ip_local_port_range, 32768+ by default): a port the kernel hands out for `bind(0)` can be given to any other process's outgoing
+    connection between this probe and the rendezvous that binds it a moment later."""
+    import os
+    import random
     import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    lo = 32768
+    try:
+        lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    top = max(min(lo, 32768), 12000)
+    rng = random.Random(os.getpid() * 1000003 + len(_PORTS_HANDED_OUT))
+    for _ in range(200):
+        port = rng.randrange(10000, top)
+        if port in _PORTS_HANDED_OUT:
+            continue
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+        _PORTS_HANDED_OUT.add(port)
+        return port
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:      # (fallback: the kernel's choice)
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
