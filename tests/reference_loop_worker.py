@@ -233,7 +233,11 @@ def main():
     if WORLD > 1:
         import torch.distributed as dist
         dist.barrier()
-        dist.destroy_process_group()
+        # leave without the collective tear-down and without interpreter finalisation (conftest.leave_process_group: a gloo thread torn
+        # down while the peers close their ends was seen to abort one rank of eight after everything had passed)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -57,8 +57,11 @@ def _worker(rank, world, port, tmpdir):
         dist.broadcast(other, src=0)
         assert torch.equal(flat, other)
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
-    finally:
+    except BaseException:
         dist.destroy_process_group()
+        raise
+    from conftest import leave_process_group
+    leave_process_group(dist)
 
 
 @pytest.mark.gpu

@@ -84,8 +84,11 @@ def _worker(rank, world, port, tmpdir):
         assert torch.equal(accum, torch.tensor([1.0, 2.0, 3.0]) * tri) and torch.equal(denom, torch.tensor([1.0, 0.0, 1.0]) * world)
         assert torch.equal(maxr, torch.tensor([max(5.0, world - 1.0), 7.0, 0.0]))
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
-    finally:
+    except BaseException:
         dist.destroy_process_group()
+        raise
+    from conftest import leave_process_group
+    leave_process_group(dist)
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -121,8 +124,11 @@ def _mailbox_worker(rank, world, port, tmpdir):
             assert rows == [[call * 10 + r, 1000 + r, -call] for r in range(world)], (call, rows)
         box.close()
         open(os.path.join(tmpdir, f"mb{rank}"), "w").write("ok")
-    finally:
+    except BaseException:
         dist.destroy_process_group()
+        raise
+    from conftest import leave_process_group
+    leave_process_group(dist)
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

@@ -373,8 +373,11 @@ def _worker(rank, world, port, tmpdir, on_gpu, exchange="counted"):
         renderer.after_training_step(20, module)
         assert calls == ([1] if min(counts) * renderer.config.redistribute_threshold < max(counts) else [])
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
-    finally:
+    except BaseException:
         dist.destroy_process_group()
+        raise
+    from conftest import leave_process_group
+    leave_process_group(dist)
 
 
 def _run(tmp_path, on_gpu, world=2, exchange="counted"):

@@ -115,8 +115,11 @@ def _worker(rank, world, port, tmpdir):
             one_step(step, N2)
             init_now = [p.detach().clone() for p in params]
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
-    finally:
+    except BaseException:
         dist.destroy_process_group()
+        raise
+    from conftest import leave_process_group
+    leave_process_group(dist)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -119,8 +119,11 @@ def _failing_setup_worker(rank, world, port, tmpdir, fail_at):
         dist.barrier()
         px.close()
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
-    finally:
+    except BaseException:
         dist.destroy_process_group()
+        raise
+    from conftest import leave_process_group
+    leave_process_group(dist)
 
 
 @pytest.mark.gpu

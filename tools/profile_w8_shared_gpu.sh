@@ -10,7 +10,7 @@ out=${1:-gpurun_out/w8}; case $out in /*) ;; *) out=$root/$out;; esac; mkdir -p 
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_w8
 port=$(python -c "import socket;s=socket.socket();s.bind(('127.0.0.1',0));print(s.getsockname()[1])")
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_w8 -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+GSPL_BENCH_SOFT_EXIT=1 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_w8 -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
   --master-port $port $root/bench.py --gpus 8 --steps 6 --warmup 2 --workload S-800-100k --share-device --dist-backend gloo --no-workload-stats \
   > $out/w8_launch_line.txt 2> /tmp/log_w8.txt || tail -20 /tmp/log_w8.txt
 tail -1 $out/w8_launch_line.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['n_gpus'], d['value'], d['ms_per_step'], d['config']['parallelism'])" | tee $out/w8_summary.txt
